@@ -1,0 +1,75 @@
+"""ctypes binding of ``libbevmsda.so`` (C ABI in include/bevmsda.h).
+
+This is the only place the product path touches native code.  There is no CPU
+fallback: if the shared object is missing or does not export the ABI the import
+of anything that computes fails loudly.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c_int = ctypes.c_int
+_c_void_p = ctypes.c_void_p
+
+ABI_VERSION = 1
+
+
+class Tuning(ctypes.Structure):
+    """Mirror of ``struct bevmsda_tuning``."""
+    _fields_ = [("variant", ctypes.c_int32), ("qtile", ctypes.c_int32),
+                ("xcd_remap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+
+
+_DIMS = [_c_int] * 7
+# name -> argtypes; every symbol the header declares is listed (tests check it)
+SIGNATURES = {
+    "bevmsda_abi_version": ([], _c_int),
+    "bevmsda_error_string": ([_c_int], ctypes.c_char_p),
+    "bevmsda_forward_f32": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p], _c_int),
+    "bevmsda_backward_f32": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_forward_bf16": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p], _c_int),
+    "bevmsda_backward_bf16": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_forward_f32_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
+                                                            ctypes.POINTER(Tuning)], _c_int),
+    "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4
+                                + [ctypes.POINTER(Tuning)], _c_int),
+}
+
+_lib = None
+
+
+class BevMsdaError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises if unavailable."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("BEVMSDA_LIBRARY", LIB_PATH)
+    if not os.path.exists(p):
+        raise BevMsdaError(
+            f"{p} not found: the HIP library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+            "there is no CPU fallback for this path.")
+    lib = ctypes.CDLL(p)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BevMsdaError(f"{p} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.bevmsda_abi_version() != ABI_VERSION:
+        raise BevMsdaError(f"{p}: ABI version {lib.bevmsda_abi_version()} != {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().bevmsda_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,210 @@
+// C ABI of libbevmsda.so (declared in include/bevmsda.h): argument checks,
+// kernel selection and launches.  No torch, no allocation, no global state.
+#include "../../include/bevmsda.h"
+#include "msda_kernels.h"
+
+namespace {
+
+using bevmsda::KArgs;
+using bevmsda::bf16_t;
+
+// library defaults (chosen from the sweeps recorded in DESIGN.md)
+constexpr int kDefaultQtileFwd = 8;
+constexpr int kDefaultQtileBwd = 8;
+
+inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+int check_common(const void *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
+                 const float *attn, int N, int S, int M, int D, int L, int Q, int P) {
+  if (N < 0 || S < 0 || M < 0 || D < 0 || L < 0 || Q < 0 || P < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  const long long rows = 1LL * N * Q * M;
+  if (rows == 0 || D == 0) return 1;  // nothing to compute
+  if (L > 0 && P > 0) {
+    if (!shapes || !lstart || !loc || !attn) return BEVMSDA_ERR_NULL_POINTER;
+    if (S > 0 && !value) return BEVMSDA_ERR_NULL_POINTER;
+    if (misaligned(value) || misaligned(loc) || misaligned(attn)) return BEVMSDA_ERR_MISALIGNED;
+  }
+  if (1LL * S * M * D >= (1LL << 31) || 1LL * L * P * 2 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  return BEVMSDA_OK;
+}
+
+int resolve_qtile(const bevmsda_tuning *t, int dflt, long NQ) {
+  int q = (t && t->qtile > 0) ? t->qtile : dflt;
+  if (q < 1 || q > 1024) return -1;
+  (void)NQ;
+  return q;
+}
+
+template <typename T, int CPL, int LPG, bool BWD>
+int launch_grouped(const KArgs &base, hipStream_t stream) {
+  KArgs a = base;
+  constexpr int GPB = 256 / LPG;
+  const long tiles = (a.NQ + a.qtile - 1) / a.qtile;
+  const long groups = tiles * a.qtile * a.M;
+  const long nb = (groups + GPB - 1) / GPB;
+  if (nb >= (1LL << 31) - 8) return BEVMSDA_ERR_TOO_LARGE;
+  a.nblocks = static_cast<int>(nb);
+  const unsigned grid = a.xcd_remap ? static_cast<unsigned>(((nb + 7) / 8) * 8) : static_cast<unsigned>(nb);
+  if (BWD) {
+    switch (a.P) {
+      case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 4>), dim3(grid), dim3(256), 0, stream, a); break;
+      case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 8>), dim3(grid), dim3(256), 0, stream, a); break;
+      default: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 0>), dim3(grid), dim3(256), 0, stream, a); break;
+    }
+  } else {
+    switch (a.P) {
+      case 4: hipLaunchKernelGGL((bevmsda::msda_fwd_kernel<T, CPL, LPG, 4>), dim3(grid), dim3(256), 0, stream, a); break;
+      case 8: hipLaunchKernelGGL((bevmsda::msda_fwd_kernel<T, CPL, LPG, 8>), dim3(grid), dim3(256), 0, stream, a); break;
+      default: hipLaunchKernelGGL((bevmsda::msda_fwd_kernel<T, CPL, LPG, 0>), dim3(grid), dim3(256), 0, stream, a); break;
+    }
+  }
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+template <typename T, bool BWD>
+int launch_scalar(const KArgs &a, hipStream_t stream) {
+  const long long total = 1LL * a.NQ * a.M * a.D;
+  const long long nb = (total + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  if (BWD) {
+    const size_t npts = static_cast<size_t>(a.NQ) * a.M * a.L * a.P;
+    if (hipMemsetAsync(a.grad_attn, 0, npts * sizeof(float), stream) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
+    if (hipMemsetAsync(a.grad_loc, 0, npts * 2 * sizeof(float), stream) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
+    hipLaunchKernelGGL((bevmsda::msda_bwd_scalar_kernel<T>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((bevmsda::msda_fwd_scalar_kernel<T>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+// CPL = channels per lane for the 16-byte path of element type T
+template <typename T> struct Wide;
+template <> struct Wide<float> { static constexpr int cpl = 4; };
+template <> struct Wide<bf16_t> { static constexpr int cpl = 8; };
+
+template <typename T, bool BWD>
+int dispatch(const KArgs &a, int variant, hipStream_t stream) {
+  constexpr int CPL = Wide<T>::cpl;
+  const int D = a.D;
+  if (variant == 2 || D % CPL != 0) return launch_scalar<T, BWD>(a, stream);
+  switch (D / CPL) {
+    case 1: return launch_grouped<T, CPL, 1, BWD>(a, stream);
+    case 2: return launch_grouped<T, CPL, 2, BWD>(a, stream);
+    case 4: return launch_grouped<T, CPL, 4, BWD>(a, stream);
+    case 8: return launch_grouped<T, CPL, 8, BWD>(a, stream);
+    case 16: return launch_grouped<T, CPL, 16, BWD>(a, stream);
+    case 32: return launch_grouped<T, CPL, 32, BWD>(a, stream);
+    case 64: return launch_grouped<T, CPL, 64, BWD>(a, stream);
+    default: return launch_scalar<T, BWD>(a, stream);
+  }
+}
+
+template <typename T>
+int forward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
+                 const float *attn, int N, int S, int M, int D, int L, int Q, int P, T *out,
+                 void *stream, const bevmsda_tuning *tuning) {
+  const int rc = check_common(value, shapes, lstart, loc, attn, N, S, M, D, L, Q, P);
+  if (rc < 0) return rc;
+  if (rc == 1) return BEVMSDA_OK;
+  if (!out) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(out)) return BEVMSDA_ERR_MISALIGNED;
+  KArgs a{};
+  a.value = value; a.shapes = shapes; a.lstart = lstart; a.loc = loc; a.attn = attn; a.out = out;
+  a.NQ = 1L * N * Q; a.N = N; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
+  a.qtile = resolve_qtile(tuning, kDefaultQtileFwd, a.NQ);
+  if (a.qtile < 0) return BEVMSDA_ERR_BAD_OPTION;
+  const int xr = tuning ? tuning->xcd_remap : 0;
+  if (xr < 0 || xr > 2) return BEVMSDA_ERR_BAD_OPTION;
+  a.xcd_remap = (xr == 1) ? 0 : 1;
+  const int variant = tuning ? tuning->variant : 0;
+  if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  return dispatch<T, false>(a, variant, static_cast<hipStream_t>(stream));
+}
+
+template <typename T>
+int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
+                  const float *attn, const T *grad_out, int N, int S, int M, int D, int L, int Q,
+                  int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream,
+                  const bevmsda_tuning *tuning) {
+  const int rc = check_common(value, shapes, lstart, loc, attn, N, S, M, D, L, Q, P);
+  if (rc < 0) return rc;
+  if (rc == 1 || L == 0 || P == 0) return BEVMSDA_OK;
+  if (!grad_out || !grad_loc || !grad_attn || (S > 0 && !grad_value)) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(grad_out) || misaligned(grad_value) || misaligned(grad_loc) || misaligned(grad_attn))
+    return BEVMSDA_ERR_MISALIGNED;
+  KArgs a{};
+  a.value = value; a.shapes = shapes; a.lstart = lstart; a.loc = loc; a.attn = attn;
+  a.grad_out = grad_out; a.grad_value = grad_value; a.grad_loc = grad_loc; a.grad_attn = grad_attn;
+  a.NQ = 1L * N * Q; a.N = N; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
+  a.qtile = resolve_qtile(tuning, kDefaultQtileBwd, a.NQ);
+  if (a.qtile < 0) return BEVMSDA_ERR_BAD_OPTION;
+  const int xr = tuning ? tuning->xcd_remap : 0;
+  if (xr < 0 || xr > 2) return BEVMSDA_ERR_BAD_OPTION;
+  a.xcd_remap = (xr == 1) ? 0 : 1;
+  const int variant = tuning ? tuning->variant : 0;
+  if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int bevmsda_abi_version(void) { return BEVMSDA_ABI_VERSION; }
+
+const char *bevmsda_error_string(int code) {
+  switch (code) {
+    case BEVMSDA_OK: return "ok";
+    case BEVMSDA_ERR_NULL_POINTER: return "null pointer";
+    case BEVMSDA_ERR_BAD_SHAPE: return "bad shape";
+    case BEVMSDA_ERR_TOO_LARGE: return "problem too large for 32-bit indexing";
+    case BEVMSDA_ERR_MISALIGNED: return "pointer not 16-byte aligned";
+    case BEVMSDA_ERR_LAUNCH: return "kernel launch failed";
+    case BEVMSDA_ERR_BAD_OPTION: return "bad tuning option";
+    default: return "unknown error";
+  }
+}
+
+int bevmsda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                        const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
+                        int P, float *out, void *stream) {
+  return forward_impl<float>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, nullptr);
+}
+
+int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
+                           int P, float *out, void *stream, const bevmsda_tuning *tuning) {
+  return forward_impl<float>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, tuning);
+}
+
+int bevmsda_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                         const float *loc, const float *attn, const float *grad_out, int N, int S, int M,
+                         int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                         void *stream) {
+  return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
+                              grad_value, grad_loc, grad_attn, stream, nullptr);
+}
+
+int bevmsda_backward_f32_ex(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, const float *grad_out, int N, int S, int M,
+                            int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                            void *stream, const bevmsda_tuning *tuning) {
+  return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
+                              grad_value, grad_loc, grad_attn, stream, tuning);
+}
+
+int bevmsda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                         const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
+                         int P, uint16_t *out, void *stream) {
+  return forward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, nullptr);
+}
+
+int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const float *loc, const float *attn, const uint16_t *grad_out, int N, int S, int M,
+                          int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                          void *stream) {
+  return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
+                               grad_value, grad_loc, grad_attn, stream, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+/* bevmsda — C ABI of the MI355X-native multi-scale deformable attention path.
+ *
+ * This header is the drop-in boundary for BEVFormer's BEV-encoder hot path.
+ * The entry points replace the two functions the reference binds from
+ * mmcv-full's `_ext` module
+ *     ext_loader.load_ext('_ext', ['ms_deform_attn_backward', 'ms_deform_attn_forward'])
+ *     (projects/mmdet3d_plugin/bevformer/modules/multi_scale_deformable_attn_function.py:10-12)
+ * and are what `bevformer_amd/ext.py` (the `_ext`-shaped Python module) calls
+ * through ctypes.  Plain pointers and sizes only: no torch types, no ownership
+ * transfer, no allocation — the caller owns every buffer, exactly as in the
+ * reference where Python allocates the gradient buffers
+ * (multi_scale_deformable_attn_function.py:146-148).
+ *
+ * Conventions (identical to the reference op, ibid. :97-112):
+ *   value          (N, S, M, D)        contiguous, S = sum_l H_l*W_l
+ *   spatial_shapes (L, 2) int64        (H_l, W_l), DEVICE memory
+ *   level_start    (L,)   int64        first row of level l in S, DEVICE memory
+ *   loc            (N, Q, M, L, P, 2)  fp32 (x, y), normalised to [0,1]
+ *   attn           (N, Q, M, L, P)     fp32
+ *   out / grad_out (N, Q, M*D)
+ * All device pointers must be 16-byte aligned (torch allocations are).
+ * `stream` is a hipStream_t (NULL = the null stream).  Every function is
+ * asynchronous with respect to the host, re-entrant, keeps no global state and
+ * never throws; it returns BEVMSDA_OK or a negative error code.
+ */
+#ifndef BEVMSDA_H_
+#define BEVMSDA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVMSDA_ABI_VERSION 1
+
+enum {
+  BEVMSDA_OK = 0,
+  BEVMSDA_ERR_NULL_POINTER = -1, /* a required pointer is NULL               */
+  BEVMSDA_ERR_BAD_SHAPE = -2,    /* negative dim, or a dim of 0 where illegal */
+  BEVMSDA_ERR_TOO_LARGE = -3,    /* S*M*D or Q*M*L*P*2 does not fit int32     */
+  BEVMSDA_ERR_MISALIGNED = -4,   /* pointer not 16-byte aligned               */
+  BEVMSDA_ERR_LAUNCH = -5,       /* hipLaunchKernel failed (see hipGetLastError) */
+  BEVMSDA_ERR_BAD_OPTION = -6    /* unknown tuning value                      */
+};
+
+/* Optional launch tuning (benchmark sweeps).  Zero-initialise for defaults. */
+typedef struct bevmsda_tuning {
+  int32_t variant;   /* 0 = library default; otherwise a kernel id, see DESIGN.md */
+  int32_t qtile;     /* 0 = default; queries of one head handled by adjacent lane groups */
+  int32_t xcd_remap; /* 0 = default, 1 = off, 2 = on: contiguous row ranges per XCD */
+  int32_t reserved[5];
+} bevmsda_tuning;
+
+int bevmsda_abi_version(void);
+const char *bevmsda_error_string(int code);
+
+/* ms_deform_attn_forward (call site: multi_scale_deformable_attn_function.py:118-124).
+ * Writes every element of `out`. */
+int bevmsda_forward_f32(const float *value, const int64_t *spatial_shapes,
+                        const int64_t *level_start, const float *loc, const float *attn,
+                        int N, int S, int M, int D, int L, int Q, int P, float *out,
+                        void *stream);
+
+/* ms_deform_attn_backward (call site: ibid. :150-160).
+ * grad_value is ACCUMULATED into (the caller zeroes it, ibid. :146);
+ * grad_loc and grad_attn are fully overwritten. */
+int bevmsda_backward_f32(const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const float *loc, const float *attn,
+                         const float *grad_out, int N, int S, int M, int D, int L, int Q, int P,
+                         float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+
+/* bf16 storage variants: value / out / grad_out are bfloat16 (uint16_t bit
+ * patterns), sampling locations, attention weights and all arithmetic stay
+ * fp32; grad_value is accumulated in fp32.  No reference semantics exist for
+ * this (the reference always up-casts to fp32, ibid. :93) — tolerance is
+ * stated against the fp32 oracle in tests/. */
+int bevmsda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const float *loc, const float *attn,
+                         int N, int S, int M, int D, int L, int Q, int P, uint16_t *out,
+                         void *stream);
+int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start, const float *loc, const float *attn,
+                          const uint16_t *grad_out, int N, int S, int M, int D, int L, int Q,
+                          int P, float *grad_value, float *grad_loc, float *grad_attn,
+                          void *stream);
+
+/* Same as above with explicit tuning. */
+int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start, const float *loc, const float *attn,
+                           int N, int S, int M, int D, int L, int Q, int P, float *out,
+                           void *stream, const bevmsda_tuning *tuning);
+int bevmsda_backward_f32_ex(const float *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start, const float *loc, const float *attn,
+                            const float *grad_out, int N, int S, int M, int D, int L, int Q,
+                            int P, float *grad_value, float *grad_loc, float *grad_attn,
+                            void *stream, const bevmsda_tuning *tuning);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVMSDA_H_ */

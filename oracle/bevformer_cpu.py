@@ -1,0 +1,278 @@
+"""TEST INFRASTRUCTURE — CPU restatement ("port") of the reference's BEV-encoder
+path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this file; the product path never does.
+
+It restates, as plain functions over a reference-keyed ``state_dict`` and fp32
+CPU tensors, what these reference files compute (all paths relative to
+/root/reference/projects/mmdet3d_plugin/bevformer/modules/):
+
+  encoder.py:46-85            reference points (3d pillar anchors / 2d BEV grid)
+  encoder.py:88-149           camera projection + visibility mask
+  encoder.py:151-239          encoder driver (hybrid prev/cur value, layer loop)
+  encoder.py:287-406          layer op-order interpreter
+  temporal_self_attention.py:128-272
+  spatial_cross_attention.py:76-175, 273-399
+  custom_base_transformer_layer.py:72-163   (FFN/LayerNorm construction)
+  mmcv-full 1.4.0 (not on disk): multi_scale_deformable_attn_pytorch, FFN
+
+Pinning status: the reference ships no tests or golden vectors for this path
+(SURVEY.md §4, §8c), so this restatement is pinned against the reference's own
+files executed here under ``oracle/mmcv_stub.py`` (tests/test_oracle_vs_reference.py,
+fixtures in tests/golden/ made by oracle/make_golden.py).  The third-party
+deformable-attention CPU fallback is restated from its published algorithm
+(Deformable-DETR: per-level ``grid_sample(bilinear, zeros, align_corners=False)``
+on ``2*loc-1`` followed by the attention-weighted sum) and cross-checked
+against an independent loop implementation (``msda_loops``, oracle/msda_ref.c)
+and HuggingFace's copy of the same algorithm.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# multi-scale deformable attention (operator level)
+# --------------------------------------------------------------------------
+
+def msda_gridsample(value, value_spatial_shapes, sampling_locations, attention_weights):
+    """mmcv's CPU fallback, called at spatial_cross_attention.py:394-395 and
+    temporal_self_attention.py:252-253.
+
+    value (N,S,M,D); value_spatial_shapes (L,2) as (H,W); sampling_locations
+    (N,Q,M,L,P,2) as (x,y) in [0,1]; attention_weights (N,Q,M,L,P) -> (N,Q,M*D)."""
+    N, _, M, D = value.shape
+    _, Q, _, L, P, _ = sampling_locations.shape
+    sizes = [int(h) * int(w) for h, w in value_spatial_shapes]
+    grids = 2 * sampling_locations - 1
+    per_level = []
+    for lvl, chunk in enumerate(value.split(sizes, dim=1)):
+        h, w = int(value_spatial_shapes[lvl][0]), int(value_spatial_shapes[lvl][1])
+        fmap = chunk.flatten(2).transpose(1, 2).reshape(N * M, D, h, w)
+        grid = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)          # (N*M,Q,P,2)
+        per_level.append(F.grid_sample(fmap, grid, mode="bilinear",
+                                       padding_mode="zeros", align_corners=False))
+    sampled = torch.stack(per_level, dim=-2).flatten(-2)                   # (N*M,D,Q,L*P)
+    w = attention_weights.transpose(1, 2).reshape(N * M, 1, Q, L * P)
+    out = (sampled * w).sum(-1).view(N, M * D, Q)
+    return out.transpose(1, 2).contiguous()
+
+
+def msda_loops(value, value_spatial_shapes, level_start_index, sampling_locations,
+               attention_weights):
+    """Independent scalar-loop statement of the operator from its math
+    (SURVEY.md Appendix A), in float64 numpy; small cases only.
+    Also returns nothing else: gradients come from autograd of msda_gridsample."""
+    v = value.detach().double().numpy()
+    loc = sampling_locations.detach().double().numpy()
+    att = attention_weights.detach().double().numpy()
+    N, _, M, D = v.shape
+    _, Q, _, L, P, _ = loc.shape
+    out = np.zeros((N, Q, M, D))
+    for n in range(N):
+        for q in range(Q):
+            for m in range(M):
+                for l in range(L):
+                    H, W = int(value_spatial_shapes[l][0]), int(value_spatial_shapes[l][1])
+                    base = int(level_start_index[l])
+                    for p in range(P):
+                        x = loc[n, q, m, l, p, 0] * W - 0.5
+                        y = loc[n, q, m, l, p, 1] * H - 0.5
+                        x0, y0 = int(np.floor(x)), int(np.floor(y))
+                        for (yy, xx) in ((y0, x0), (y0, x0 + 1), (y0 + 1, x0), (y0 + 1, x0 + 1)):
+                            if 0 <= yy < H and 0 <= xx < W:
+                                wgt = (1 - abs(y - yy)) * (1 - abs(x - xx))
+                                out[n, q, m] += att[n, q, m, l, p] * wgt * v[n, base + yy * W + xx, m]
+    return torch.from_numpy(out.reshape(N, Q, M * D))
+
+
+def msda_backward_autograd(value, value_spatial_shapes, sampling_locations,
+                           attention_weights, grad_output):
+    """Gradients of the operator w.r.t. (value, sampling_locations,
+    attention_weights) = what ``ms_deform_attn_backward`` accumulates
+    (multi_scale_deformable_attn_function.py:146-163), via autograd of the
+    CPU fallback."""
+    v = value.detach().clone().requires_grad_(True)
+    l = sampling_locations.detach().clone().requires_grad_(True)
+    a = attention_weights.detach().clone().requires_grad_(True)
+    out = msda_gridsample(v, value_spatial_shapes, l, a)
+    gv, gl, ga = torch.autograd.grad(out, (v, l, a), grad_output)
+    return gv, gl, ga
+
+
+# --------------------------------------------------------------------------
+# geometry (once per frame)
+# --------------------------------------------------------------------------
+
+def pillar_points(H, W, Z, num_z, bs, dtype=torch.float32):
+    """encoder.py:61-71 -> (bs, num_z, H*W, 3) normalised (x, y, z)."""
+    zs = torch.linspace(0.5, Z - 0.5, num_z, dtype=dtype).view(-1, 1, 1).expand(num_z, H, W) / Z
+    xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype).view(1, 1, W).expand(num_z, H, W) / W
+    ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype).view(1, H, 1).expand(num_z, H, W) / H
+    pts = torch.stack((xs, ys, zs), -1).permute(0, 3, 1, 2).flatten(2).permute(0, 2, 1)
+    return pts[None].repeat(bs, 1, 1, 1)
+
+
+def bev_grid_points(H, W, bs, dtype=torch.float32):
+    """encoder.py:74-85 -> (bs, H*W, 1, 2) normalised (x, y)."""
+    ry, rx = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=dtype),
+                            torch.linspace(0.5, W - 0.5, W, dtype=dtype), indexing="ij")
+    ref = torch.stack((rx.reshape(-1)[None] / W, ry.reshape(-1)[None] / H), -1)
+    return ref.repeat(bs, 1, 1).unsqueeze(2)
+
+
+def project_to_cameras(ref_3d, pc_range, img_metas):
+    """encoder.py:95-144 -> reference_points_cam (Nc,B,Q,Dz,2), bev_mask (Nc,B,Q,Dz)."""
+    l2i = ref_3d.new_tensor(np.asarray([m["lidar2img"] for m in img_metas]))  # (B,Nc,4,4)
+    p = ref_3d.clone()
+    p[..., 0:1] = p[..., 0:1] * (pc_range[3] - pc_range[0]) + pc_range[0]
+    p[..., 1:2] = p[..., 1:2] * (pc_range[4] - pc_range[1]) + pc_range[1]
+    p[..., 2:3] = p[..., 2:3] * (pc_range[5] - pc_range[2]) + pc_range[2]
+    p = torch.cat((p, torch.ones_like(p[..., :1])), -1).permute(1, 0, 2, 3)   # (Dz,B,Q,4)
+    Dz, B, Q = p.shape[:3]
+    Nc = l2i.size(1)
+    p = p.view(Dz, B, 1, Q, 4).repeat(1, 1, Nc, 1, 1).unsqueeze(-1)
+    mats = l2i.view(1, B, Nc, 1, 4, 4).repeat(Dz, 1, 1, Q, 1, 1)
+    cam = torch.matmul(mats.float(), p.float()).squeeze(-1)
+    eps = 1e-5
+    mask = cam[..., 2:3] > eps
+    cam = cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
+    cam[..., 0] /= img_metas[0]["img_shape"][0][1]
+    cam[..., 1] /= img_metas[0]["img_shape"][0][0]
+    mask = (mask & (cam[..., 1:2] > 0.0) & (cam[..., 1:2] < 1.0)
+            & (cam[..., 0:1] < 1.0) & (cam[..., 0:1] > 0.0))
+    mask = torch.nan_to_num(mask)
+    return cam.permute(2, 1, 3, 0, 4), mask.permute(2, 1, 3, 0, 4).squeeze(-1)
+
+
+# --------------------------------------------------------------------------
+# modules as functions over a state_dict
+# --------------------------------------------------------------------------
+
+def _lin(sd, key, x):
+    return F.linear(x, sd[key + ".weight"], sd[key + ".bias"])
+
+
+def temporal_self_attention(sd, pre, query, value, bev_pos, ref_2d, bev_h, bev_w,
+                            num_heads=8, num_points=4, msda=msda_gridsample):
+    """temporal_self_attention.py:177-272 (eval mode: dropout is identity)."""
+    bs, Q, C = query.shape
+    if value is None:
+        value = torch.stack([query, query], 1).reshape(bs * 2, Q, C)
+    identity = query
+    if bev_pos is not None:
+        query = query + bev_pos
+    shapes = torch.tensor([[bev_h, bev_w]])
+    q2 = torch.cat([value[:bs], query], -1)
+    v = _lin(sd, pre + "value_proj", value).reshape(bs * 2, value.shape[1], num_heads, -1)
+    off = _lin(sd, pre + "sampling_offsets", q2).view(bs, Q, num_heads, 2, 1, num_points, 2)
+    att = _lin(sd, pre + "attention_weights", q2).view(bs, Q, num_heads, 2, num_points)
+    att = att.softmax(-1).view(bs, Q, num_heads, 2, 1, num_points)
+    att = att.permute(0, 3, 1, 2, 4, 5).reshape(bs * 2, Q, num_heads, 1, num_points).contiguous()
+    off = off.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * 2, Q, num_heads, 1, num_points, 2)
+    norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc = ref_2d[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out = msda(v, shapes, loc, att)                                     # (bs*2,Q,C)
+    out = out.permute(1, 2, 0).view(Q, C, bs, 2).mean(-1).permute(2, 0, 1)
+    return _lin(sd, pre + "output_proj", out) + identity
+
+
+def deformable_attention_3d(sd, pre, query, value, ref_cam, shapes, num_heads=8,
+                            num_points=8, msda=msda_gridsample):
+    """spatial_cross_attention.py:318-399 with batch_first=True."""
+    bs, Q, _ = query.shape
+    L = shapes.shape[0]
+    v = _lin(sd, pre + "value_proj", value).view(bs, value.shape[1], num_heads, -1)
+    off = _lin(sd, pre + "sampling_offsets", query).view(bs, Q, num_heads, L, num_points, 2)
+    att = _lin(sd, pre + "attention_weights", query).view(bs, Q, num_heads, L * num_points)
+    att = att.softmax(-1).view(bs, Q, num_heads, L, num_points)
+    norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    Dz = ref_cam.shape[2]
+    off = off / norm[None, None, None, :, None, :]
+    off = off.view(bs, Q, num_heads, L, num_points // Dz, Dz, 2)
+    loc = (ref_cam[:, :, None, None, None, :, :] + off).view(bs, Q, num_heads, L, num_points, 2)
+    return msda(v, shapes, loc, att)
+
+
+def spatial_cross_attention(sd, pre, query, feats, ref_cam, bev_mask, shapes,
+                            msda=msda_gridsample):
+    """spatial_cross_attention.py:123-175 (eval mode), padded per-camera rebatch
+    exactly as the reference does it, visibility taken from batch element 0."""
+    bs, Q, C = query.shape
+    Nc = feats.shape[0]
+    Dz = ref_cam.size(3)
+    residual = query
+    slots = torch.zeros_like(query)
+    idx = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+    max_len = max(len(i) for i in idx)
+    q_re = query.new_zeros(bs, Nc, max_len, C)
+    r_re = ref_cam.new_zeros(bs, Nc, max_len, Dz, 2)
+    for j in range(bs):
+        for i in range(Nc):
+            q_re[j, i, :len(idx[i])] = query[j, idx[i]]
+            r_re[j, i, :len(idx[i])] = ref_cam[i][j, idx[i]]
+    S = feats.shape[1]
+    val = feats.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
+    out = deformable_attention_3d(sd, pre + "deformable_attention.", q_re.view(bs * Nc, max_len, C),
+                                  val, r_re.view(bs * Nc, max_len, Dz, 2), shapes, msda=msda)
+    out = out.view(bs, Nc, max_len, C)
+    for j in range(bs):
+        for i in range(Nc):
+            slots[j, idx[i]] += out[j, i, :len(idx[i])]
+    count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
+    slots = slots / torch.clamp(count, min=1.0)[..., None]
+    return _lin(sd, pre + "output_proj", slots) + residual
+
+
+def ffn(sd, pre, x):
+    """mmcv FFN (add_identity=True), keys layers.0.0 / layers.1."""
+    h = F.relu(_lin(sd, pre + "layers.0.0", x))
+    return x + _lin(sd, pre + "layers.1", h)
+
+
+def layer_norm(sd, pre, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
+
+
+def encoder_layer(sd, pre, query, feats, bev_pos, ref_2d, ref_cam, bev_mask, bev_h, bev_w,
+                  shapes, prev_bev, msda=msda_gridsample):
+    """encoder.py:356-406 with operation_order
+    ('self_attn','norm','cross_attn','norm','ffn','norm')."""
+    x = temporal_self_attention(sd, pre + "attentions.0.", query, prev_bev, bev_pos, ref_2d,
+                                bev_h, bev_w, msda=msda)
+    x = layer_norm(sd, pre + "norms.0", x)
+    x = spatial_cross_attention(sd, pre + "attentions.1.", x, feats, ref_cam, bev_mask, shapes,
+                                msda=msda)
+    x = layer_norm(sd, pre + "norms.1", x)
+    x = ffn(sd, pre + "ffns.0.", x)
+    return layer_norm(sd, pre + "norms.2", x)
+
+
+def encoder_forward(sd, bev_query, feats, *, bev_h, bev_w, bev_pos, spatial_shapes,
+                    level_start_index=None, prev_bev=None, shift=None, img_metas=None,
+                    num_layers=None, pc_range=None, num_points_in_pillar=4,
+                    msda=msda_gridsample, return_intermediate=False, **_):
+    """encoder.py:185-239.  ``bev_query``/``bev_pos``/``prev_bev`` are (Q,bs,C),
+    ``feats`` is (Nc,S,bs,C); returns (bs,Q,C)."""
+    if num_layers is None:
+        num_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
+    bs = bev_query.size(1)
+    ref_3d = pillar_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar, bs,
+                           bev_query.dtype)
+    ref_2d = bev_grid_points(bev_h, bev_w, bs, bev_query.dtype)
+    ref_cam, bev_mask = project_to_cameras(ref_3d, pc_range, img_metas)
+    shifted = ref_2d.clone() + shift[:, None, None, :]
+    x = bev_query.permute(1, 0, 2)
+    pos = bev_pos.permute(1, 0, 2)
+    Q = x.shape[1]
+    if prev_bev is not None:
+        prev = torch.stack([prev_bev.permute(1, 0, 2), x], 1).reshape(bs * 2, Q, -1)
+        hybrid = torch.stack([shifted, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
+    else:
+        prev = None
+        hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
+    inter = []
+    for i in range(num_layers):
+        x = encoder_layer(sd, f"layers.{i}.", x, feats, pos, hybrid, ref_cam, bev_mask,
+                          bev_h, bev_w, spatial_shapes, prev, msda=msda)
+        inter.append(x)
+    return torch.stack(inter) if return_intermediate else x

@@ -1,0 +1,304 @@
+"""TEST INFRASTRUCTURE — not part of the product path.
+
+A minimal stand-in for the parts of ``mmcv-full==1.4.0`` (reference pin:
+docs/install.md:27) that the reference's five BEV-encoder files import, plus a
+loader that executes those files *unmodified* from ``/root/reference`` on CPU
+(recipe: SURVEY.md §8c).  mmcv itself is not installed here and its source is
+not on disk, so the three third-party pieces the reference leans on are
+restated from their published behaviour:
+
+* ``multi_scale_deformable_attn_pytorch`` -> ``oracle.bevformer_cpu.msda_gridsample``
+* ``FFN``                                -> Linear-ReLU-Drop-Linear-Drop + identity
+* ``TransformerLayerSequence``           -> deep-copies the layer cfg ``num_layers`` times
+
+This module is only usable where ``/root/reference`` exists (the build
+container).  It is used by ``oracle/make_golden.py`` to produce the fixtures in
+``tests/golden/`` and by the CPU tests that cross-check the restatement in
+``oracle/bevformer_cpu.py`` against the reference's own code.  Nothing on the
+GPU box imports it.
+"""
+import copy
+import importlib
+import os
+import sys
+import types
+import warnings
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = "/root/reference"
+_MODULES_DIR = os.path.join(REFERENCE_ROOT, "projects/mmdet3d_plugin/bevformer/modules")
+
+
+def reference_available():
+    return os.path.isdir(_MODULES_DIR)
+
+
+class _Registry:
+    def __init__(self, name):
+        self.name = name
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+    def get(self, key):
+        return self.module_dict.get(key)
+
+    def build(self, cfg, **default_args):
+        return _build_from_cfg(cfg, self, default_args or None)
+
+
+class _ConfigDict(dict):
+    # missing keys must raise AttributeError or copy.deepcopy probes break
+    # (custom_base_transformer_layer.py:147-149 deep-copies a ConfigDict)
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _build_from_cfg(cfg, registry, default_args=None):
+    args = dict(cfg)
+    if default_args:
+        for k, v in default_args.items():
+            args.setdefault(k, v)
+    typ = args.pop("type")
+    cls = registry.get(typ) if isinstance(typ, str) else typ
+    if cls is None:
+        raise KeyError(f"{typ} is not in the {registry.name} registry")
+    return cls(**args)
+
+
+def _passthrough_decorator_factory(*a, **k):
+    def deco(fn):
+        return fn
+    return deco
+
+
+class _BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self._is_init = False
+        self.init_cfg = copy.deepcopy(init_cfg)
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, "init_weights"):
+                m.init_weights()
+
+
+class _ModuleList(_BaseModule, nn.ModuleList):
+    def __init__(self, modules=None, init_cfg=None):
+        _BaseModule.__init__(self, init_cfg)
+        nn.ModuleList.__init__(self, modules)
+
+
+class _Sequential(_BaseModule, nn.Sequential):
+    def __init__(self, *args, init_cfg=None):
+        _BaseModule.__init__(self, init_cfg)
+        nn.Sequential.__init__(self, *args)
+
+
+def _xavier_init(module, gain=1, bias=0, distribution="normal"):
+    if hasattr(module, "weight") and module.weight is not None:
+        if distribution == "uniform":
+            nn.init.xavier_uniform_(module.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(module.weight, gain=gain)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def _constant_init(module, val, bias=0):
+    if hasattr(module, "weight") and module.weight is not None:
+        nn.init.constant_(module.weight, val)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def _digit_version(v):
+    out = []
+    for p in str(v).split("+")[0].split(".")[:3]:
+        num = "".join(ch for ch in p if ch.isdigit())
+        out.append(int(num) if num else 0)
+    return tuple(out)
+
+
+def install(ext_module=None):
+    """Put the stub ``mmcv`` (and empty ``projects.*`` packages whose
+    ``bevformer.modules`` path points at the reference directory) into
+    ``sys.modules``.  ``ext_module`` is what ``ext_loader.load_ext`` returns —
+    pass an ``_ext``-shaped object to make the reference's autograd Function
+    call it (multi_scale_deformable_attn_function.py:10-12)."""
+    if "mmcv" in sys.modules and getattr(sys.modules["mmcv"], "__bevformer_amd_stub__", False):
+        if ext_module is not None:
+            sys.modules["mmcv"].utils.ext_loader._ext = ext_module
+        return sys.modules["mmcv"]
+    if not reference_available():
+        raise RuntimeError("the reference tree is not present on this machine")
+    from . import bevformer_cpu
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    regs = {n: _Registry(n) for n in ("ATTENTION", "TRANSFORMER_LAYER", "TRANSFORMER_LAYER_SEQUENCE",
+                                      "FEEDFORWARD_NETWORK", "POSITIONAL_ENCODING")}
+
+    def build_attention(cfg, default_args=None):
+        return _build_from_cfg(cfg, regs["ATTENTION"], default_args)
+
+    def build_feedforward_network(cfg, default_args=None):
+        return _build_from_cfg(cfg, regs["FEEDFORWARD_NETWORK"], default_args)
+
+    def build_transformer_layer(cfg, default_args=None):
+        return _build_from_cfg(cfg, regs["TRANSFORMER_LAYER"], default_args)
+
+    def build_transformer_layer_sequence(cfg, default_args=None):
+        return _build_from_cfg(cfg, regs["TRANSFORMER_LAYER_SEQUENCE"], default_args)
+
+    @regs["FEEDFORWARD_NETWORK"].register_module()
+    class FFN(_BaseModule):
+        # mmcv.cnn.bricks.transformer.FFN restated; parameter names
+        # layers.0.0.{weight,bias}, layers.1.{weight,bias}
+        def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                     act_cfg=dict(type="ReLU", inplace=True), ffn_drop=0.0,
+                     dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+            super().__init__(init_cfg)
+            assert num_fcs >= 2
+            self.embed_dims = embed_dims
+            layers, cin = [], embed_dims
+            for _ in range(num_fcs - 1):
+                layers.append(_Sequential(nn.Linear(cin, feedforward_channels),
+                                          nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+                cin = feedforward_channels
+            layers.append(nn.Linear(feedforward_channels, embed_dims))
+            layers.append(nn.Dropout(ffn_drop))
+            self.layers = _Sequential(*layers)
+            self.dropout_layer = nn.Identity()
+            self.add_identity = add_identity
+
+        def forward(self, x, identity=None):
+            out = self.layers(x)
+            if not self.add_identity:
+                return self.dropout_layer(out)
+            if identity is None:
+                identity = x
+            return identity + self.dropout_layer(out)
+
+    class TransformerLayerSequence(_BaseModule):
+        def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+            super().__init__(init_cfg)
+            if isinstance(transformerlayers, dict):
+                transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+            self.num_layers = num_layers
+            self.layers = _ModuleList()
+            for i in range(num_layers):
+                self.layers.append(build_transformer_layer(transformerlayers[i]))
+            self.embed_dims = self.layers[0].embed_dims
+            self.pre_norm = self.layers[0].pre_norm
+
+    class _ExtLoader:
+        _ext = ext_module
+
+        @classmethod
+        def load_ext(cls, name, funcs):
+            class _Proxy:
+                def __getattr__(self, item):
+                    if cls._ext is None:
+                        raise RuntimeError("no _ext module installed in the mmcv stub")
+                    return getattr(cls._ext, item)
+            return _Proxy()
+
+    def build_norm_layer(cfg, num_features, postfix=""):
+        assert cfg["type"] == "LN"
+        return "ln" + str(postfix), nn.LayerNorm(num_features, eps=cfg.get("eps", 1e-5))
+
+    def build_activation_layer(cfg):
+        assert cfg["type"] == "ReLU"
+        return nn.ReLU(inplace=cfg.get("inplace", False))
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    class MultiScaleDeformableAttention(_BaseModule):  # import target only
+        pass
+
+    mmcv = mod("mmcv", __bevformer_amd_stub__=True, ConfigDict=_ConfigDict,
+               deprecated_api_warning=_passthrough_decorator_factory, __path__=[])
+    mmcv.utils = mod("mmcv.utils", ext_loader=_ExtLoader, ConfigDict=_ConfigDict,
+                     build_from_cfg=_build_from_cfg,
+                     deprecated_api_warning=_passthrough_decorator_factory, to_2tuple=to_2tuple,
+                     TORCH_VERSION=torch.__version__, digit_version=_digit_version,
+                     Registry=_Registry)
+    mmcv.ops = mod("mmcv.ops", __path__=[])
+    mmcv.ops.multi_scale_deform_attn = mod(
+        "mmcv.ops.multi_scale_deform_attn",
+        multi_scale_deformable_attn_pytorch=bevformer_cpu.msda_gridsample,
+        MultiScaleDeformableAttention=MultiScaleDeformableAttention)
+    mmcv.cnn = mod("mmcv.cnn", xavier_init=_xavier_init, constant_init=_constant_init,
+                   Linear=nn.Linear, build_activation_layer=build_activation_layer,
+                   build_norm_layer=build_norm_layer, __path__=[])
+    mmcv.cnn.bricks = mod("mmcv.cnn.bricks", __path__=[])
+    mmcv.cnn.bricks.registry = mod("mmcv.cnn.bricks.registry", **regs)
+    mmcv.cnn.bricks.transformer = mod(
+        "mmcv.cnn.bricks.transformer", build_attention=build_attention,
+        build_feedforward_network=build_feedforward_network,
+        build_transformer_layer=build_transformer_layer,
+        build_transformer_layer_sequence=build_transformer_layer_sequence,
+        TransformerLayerSequence=TransformerLayerSequence, FFN=FFN)
+    mmcv.runner = mod("mmcv.runner", force_fp32=_passthrough_decorator_factory,
+                      auto_fp16=_passthrough_decorator_factory, __path__=[])
+    mmcv.runner.base_module = mod("mmcv.runner.base_module", BaseModule=_BaseModule,
+                                  ModuleList=_ModuleList, Sequential=_Sequential)
+
+    def run_time(name):
+        return lambda fn: fn
+
+    for pkg in ("projects", "projects.mmdet3d_plugin", "projects.mmdet3d_plugin.models",
+                "projects.mmdet3d_plugin.models.utils", "projects.mmdet3d_plugin.bevformer"):
+        mod(pkg, __path__=[])
+    mod("projects.mmdet3d_plugin.models.utils.bricks", run_time=run_time)
+    mod("projects.mmdet3d_plugin.bevformer.modules", __path__=[_MODULES_DIR])
+    return mmcv
+
+
+def load_reference(ext_module=None):
+    """Import the reference's own hot-path files (unmodified) and return a
+    namespace with its classes plus the stub's ``build_transformer_layer_sequence``."""
+    install(ext_module)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = "projects.mmdet3d_plugin.bevformer.modules."
+        fn = importlib.import_module(base + "multi_scale_deformable_attn_function")
+        sca = importlib.import_module(base + "spatial_cross_attention")
+        tsa = importlib.import_module(base + "temporal_self_attention")
+        enc = importlib.import_module(base + "encoder")
+    ns = types.SimpleNamespace(
+        function_module=fn, sca_module=sca, tsa_module=tsa, encoder_module=enc,
+        MultiScaleDeformableAttnFunction_fp32=fn.MultiScaleDeformableAttnFunction_fp32,
+        SpatialCrossAttention=sca.SpatialCrossAttention,
+        MSDeformableAttention3D=sca.MSDeformableAttention3D,
+        TemporalSelfAttention=tsa.TemporalSelfAttention,
+        BEVFormerEncoder=enc.BEVFormerEncoder, BEVFormerLayer=enc.BEVFormerLayer,
+        build_transformer_layer_sequence=sys.modules["mmcv.cnn.bricks.transformer"]
+        .build_transformer_layer_sequence)
+    return ns
+
+
+def build_reference_encoder(cfg, ext_module=None):
+    ns = load_reference(ext_module)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ns.build_transformer_layer_sequence(copy.deepcopy(cfg)).eval()

@@ -1,0 +1,196 @@
+"""GPU parity of the hand-written HIP operator (through the C ABI / the
+``_ext``-shaped module) against the CPU oracle, forward and backward.
+
+Tolerances (fp32 arithmetic, different summation order than the oracle, and
+non-deterministic atomic order in grad_value):
+  forward  fp32: rtol 1e-4, atol 1e-5
+  backward fp32: rtol 1e-3, atol 1e-4
+  bf16 storage : rtol 2e-2, atol 2e-2 against the fp32 oracle fed the same
+                 bf16-rounded value (output is rounded to bf16 once more)
+"""
+import ctypes
+
+import pytest
+import torch
+
+from bevformer_amd import _lib
+from bevformer_amd import ext
+from bevformer_amd.functions import (MultiScaleDeformableAttnFunction_bf16,
+                                     MultiScaleDeformableAttnFunction_fp32)
+from bevformer_amd.synthetic import make_msda_case, make_sca_msda_case, make_tsa_msda_case
+from oracle import bevformer_cpu as O
+from oracle import msda_c
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # N, Q, M, D, shapes, P
+    (1, 5, 2, 4, [(3, 4)], 2),                              # LPG=1
+    (2, 33, 8, 32, [(6, 9), (3, 5)], 4),                    # the encoder's head size
+    (6, 70, 8, 32, [(16, 26), (8, 13), (4, 7), (2, 4)], 8),  # SCA-like
+    (2, 120, 8, 32, [(12, 10)], 4),                         # TSA-like
+    (2, 9, 3, 8, [(5, 7), (3, 4), (2, 2), (1, 1)], 8),      # 1x1 level, M not pow2
+    (1, 17, 4, 64, [(7, 5)], 3),                            # generic P, LPG=16
+    (1, 6, 1, 256, [(4, 4)], 5),                            # LPG=64
+    (1, 4, 2, 5, [(4, 4)], 3),                              # odd D -> scalar fallback
+    (2, 11, 2, 16, [(5, 5), (2, 3)], 12),                   # P > LPG
+]
+
+
+def _gpu(*ts):
+    return [t.to(DEV) for t in ts]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("coherent", [False, True])
+def test_forward_fp32(case, coherent):
+    N, Q, M, D, shapes, P = case
+    value, sh, start, loc, attn = make_msda_case(N, Q, M, D, shapes, P, seed=1, coherent=coherent)
+    want = msda_c.forward(value, sh, start, loc, attn)
+    got = ext.ms_deform_attn_forward(*_gpu(value, sh, start, loc, attn), im2col_step=64).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    # and the grid_sample form (what the reference's CPU fallback computes)
+    torch.testing.assert_close(got, O.msda_gridsample(value, sh, loc, attn), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_fp32(case):
+    N, Q, M, D, shapes, P = case
+    value, sh, start, loc, attn = make_msda_case(N, Q, M, D, shapes, P, seed=2)
+    g = torch.randn(N, Q, M * D, generator=torch.Generator().manual_seed(9))
+    wv, wl, wa = msda_c.backward(value, sh, start, loc, attn, g)
+    v, s_, st, l, a, gg = _gpu(value, sh, start, loc, attn, g)
+    gv = torch.zeros_like(v)
+    gl = torch.full_like(l, 123.0)   # must be overwritten, not accumulated
+    ga = torch.full_like(a, 123.0)
+    ext.ms_deform_attn_backward(v, s_, st, l, a, gg, gv, gl, ga, im2col_step=64)
+    torch.testing.assert_close(gv.cpu(), wv, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(ga.cpu(), wa, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gl.cpu(), wl, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", CASES[:7])
+def test_forward_backward_bf16(case):
+    N, Q, M, D, shapes, P = case
+    value, sh, start, loc, attn = make_msda_case(N, Q, M, D, shapes, P, seed=3)
+    vb = value.to(torch.bfloat16)
+    want = msda_c.forward(vb.float(), sh, start, loc, attn)
+    got = ext.ms_deform_attn_forward(*_gpu(vb, sh, start, loc, attn)).float().cpu()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+    g = torch.randn(N, Q, M * D, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    wv, wl, wa = msda_c.backward(vb.float(), sh, start, loc, attn, g.float())
+    v, s_, st, l, a, gg = _gpu(vb, sh, start, loc, attn, g)
+    gv = torch.zeros(v.shape, device=DEV)
+    gl = torch.empty_like(l)
+    ga = torch.empty_like(a)
+    ext.ms_deform_attn_backward(v, s_, st, l, a, gg, gv, gl, ga)
+    torch.testing.assert_close(gv.cpu(), wv, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(ga.cpu(), wa, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gl.cpu(), wl, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("qtile,xcd,variant", [(1, 1, 0), (1, 2, 0), (8, 1, 0), (32, 2, 0),
+                                               (128, 2, 0), (8, 2, 2)])
+def test_launch_tunings_agree(qtile, xcd, variant):
+    value, sh, start, loc, attn = make_msda_case(3, 77, 8, 32, [(9, 11), (4, 6)], 8, seed=4)
+    want = msda_c.forward(value, sh, start, loc, attn)
+    t = _lib.Tuning(variant=variant, qtile=qtile, xcd_remap=xcd)
+    args = _gpu(value, sh, start, loc, attn)
+    got = ext.ms_deform_attn_forward(*args, tuning=ctypes.byref(t)).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    g = torch.randn(3, 77, 256, generator=torch.Generator().manual_seed(1))
+    wv, wl, wa = msda_c.backward(value, sh, start, loc, attn, g)
+    gv = torch.zeros_like(args[0]); gl = torch.empty_like(args[3]); ga = torch.empty_like(args[4])
+    ext.ms_deform_attn_backward(*args, g.to(DEV), gv, gl, ga, tuning=ctypes.byref(t))
+    torch.testing.assert_close(gv.cpu(), wv, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(ga.cpu(), wa, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gl.cpu(), wl, rtol=1e-3, atol=1e-3)
+
+
+def test_autograd_function_matches_oracle_autograd():
+    value, sh, start, loc, attn = make_msda_case(2, 40, 8, 32, [(7, 9), (4, 5)], 4, seed=5)
+    g = torch.randn(2, 40, 256, generator=torch.Generator().manual_seed(2))
+    wv, wl, wa = O.msda_backward_autograd(value, sh, loc, attn, g)
+    v, s_, st, l, a = _gpu(value, sh, start, loc, attn)
+    v.requires_grad_(True); l.requires_grad_(True); a.requires_grad_(True)
+    out = MultiScaleDeformableAttnFunction_fp32.apply(v, s_, st, l, a, 64)
+    out.backward(g.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), O.msda_gridsample(value, sh, loc, attn),
+                               rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(v.grad.cpu(), wv, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(a.grad.cpu(), wa, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(l.grad.cpu(), wl, rtol=1e-3, atol=1e-3)
+    # fp16 input is up-cast like the reference's custom_fwd(cast_inputs=float32)
+    out16 = MultiScaleDeformableAttnFunction_fp32.apply(v.detach().half(), s_, st, l.detach(),
+                                                        a.detach(), 64)
+    assert out16.dtype == torch.float32
+    outb = MultiScaleDeformableAttnFunction_bf16.apply(v.detach(), s_, st, l.detach(), a.detach(), 64)
+    assert outb.dtype == torch.bfloat16
+
+
+def test_empty_and_degenerate_inputs():
+    # zero queries
+    value, sh, start, loc, attn = make_msda_case(2, 0, 8, 32, [(4, 4)], 4, seed=1)
+    out = ext.ms_deform_attn_forward(*_gpu(value, sh, start, loc, attn))
+    assert out.shape == (2, 0, 256)
+    # every point far outside the map -> exact zeros, gradients zero
+    value, sh, start, loc, attn = make_msda_case(1, 9, 8, 32, [(4, 4)], 4, seed=1)
+    loc = loc + 5.0
+    v, s_, st, l, a = _gpu(value, sh, start, loc, attn)
+    out = ext.ms_deform_attn_forward(v, s_, st, l, a)
+    assert torch.count_nonzero(out) == 0
+    gv = torch.zeros_like(v); gl = torch.full_like(l, 7.0); ga = torch.full_like(a, 7.0)
+    ext.ms_deform_attn_backward(v, s_, st, l, a, torch.ones_like(out), gv, gl, ga)
+    assert torch.count_nonzero(gv) == 0 and torch.count_nonzero(gl) == 0 and torch.count_nonzero(ga) == 0
+    # NaN location contributes nothing (point-level range test fails)
+    loc2 = loc - 5.0
+    loc2[0, 0, 0, 0, 0, 0] = float("nan")
+    out = ext.ms_deform_attn_forward(v, s_, st, loc2.to(DEV), a)
+    assert torch.isfinite(out).all()
+
+
+def test_argument_errors_raise_runtime_error():
+    value, sh, start, loc, attn = make_msda_case(1, 4, 2, 8, [(3, 3)], 2, seed=1)
+    with pytest.raises(RuntimeError):
+        ext.ms_deform_attn_forward(value, sh, start, loc, attn)            # CPU tensors
+    v, s_, st, l, a = _gpu(value, sh, start, loc, attn)
+    with pytest.raises(RuntimeError):
+        ext.ms_deform_attn_forward(v, s_.int(), st, l, a)                  # wrong index dtype
+    with pytest.raises(RuntimeError):
+        ext.ms_deform_attn_forward(v, s_, st, l.transpose(1, 2), a)        # non-contiguous / shape
+    with pytest.raises(RuntimeError):
+        ext.ms_deform_attn_forward(v.double(), s_, st, l, a)               # unsupported dtype
+
+
+@pytest.mark.parametrize("which", ["sca", "tsa"])
+def test_base_size_properties(which):
+    """bevformer_base operator sizes: compared with the (OpenMP) C oracle on a
+    slice of queries, plus size-independent properties on the full output:
+    linearity in value and the constant-field identity."""
+    if which == "sca":
+        value, sh, start, loc, attn, _ = make_sca_msda_case("base", seed=0)
+    else:
+        value, sh, start, loc, attn = make_tsa_msda_case("base", seed=0)
+    v, s_, st, l, a = _gpu(value, sh, start, loc, attn)
+    out = ext.ms_deform_attn_forward(v, s_, st, l, a)
+    # oracle on the first and last 256 queries of every batch entry
+    for sl in (slice(0, 256), slice(loc.shape[1] - 256, loc.shape[1])):
+        want = msda_c.forward(value, sh, start, loc[:, sl].contiguous(), attn[:, sl].contiguous())
+        torch.testing.assert_close(out[:, sl].cpu(), want, rtol=1e-4, atol=1e-5)
+    # linearity: f(2 v1 - 3 v2) = 2 f(v1) - 3 f(v2)
+    v2 = torch.randn(v.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    out2 = ext.ms_deform_attn_forward(v2, s_, st, l, a)
+    mix = ext.ms_deform_attn_forward((2 * v - 3 * v2).contiguous(), s_, st, l, a)
+    torch.testing.assert_close(mix, 2 * out - 3 * out2, rtol=1e-4, atol=1e-4)
+    # constant field + all taps inside the map: out = const * sum(attn) = const
+    lc = l.clamp(0.3, 0.7)
+    ones = torch.ones_like(v)
+    outc = ext.ms_deform_attn_forward(ones, s_, st, lc, a)
+    torch.testing.assert_close(outc, torch.ones_like(outc), rtol=1e-5, atol=1e-5)
+    # backward: sum(grad_value) == sum_q g . (sum attn * in-range weights) for constant g
+    gv = torch.zeros_like(v); gl = torch.empty_like(l); ga = torch.empty_like(a)
+    ext.ms_deform_attn_backward(v, s_, st, lc, a, torch.ones_like(out), gv, gl, ga)
+    total = gv.double().sum().item()
+    expect = out.shape[0] * out.shape[1] * out.shape[2]       # each output element spreads 1.0
+    assert abs(total - expect) / expect < 1e-4

@@ -1,0 +1,91 @@
+"""Operator-level micro-benchmark on the GPU box: times the HIP forward and
+backward kernels at the bevformer_base SCA / TSA operator shapes over launch
+tunings, prints one JSON object per line and writes gpurun_out/kbench.json.
+
+    python tools/kbench.py [--iters 20] [--quick]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bevformer_amd import _lib, ext  # noqa: E402
+from bevformer_amd.synthetic import make_sca_msda_case, make_tsa_msda_case  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def alg_bytes_fwd(v, loc, attn, out):
+    return v.numel() * v.element_size() + loc.numel() * 4 + attn.numel() * 4 + out.numel() * out.element_size()
+
+
+def alg_bytes_bwd(v, loc, attn, g):
+    rd = v.numel() * v.element_size() + loc.numel() * 4 + attn.numel() * 4 + g.numel() * g.element_size()
+    wr = v.numel() * 4 + loc.numel() * 4 + attn.numel() * 4
+    return rd + wr
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2] * 1e-3, ts[0] * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--workload", default="base")
+    args = ap.parse_args()
+    results = []
+    cases = {}
+    v, sh, st, loc, attn, hits = make_sca_msda_case(args.workload, seed=0)
+    cases["sca"] = (v, sh, st, loc, attn)
+    cases["tsa"] = make_tsa_msda_case(args.workload, seed=0)
+    tunings = [(0, 0)] if args.quick else [(1, 1), (1, 2), (4, 2), (8, 1), (8, 2), (16, 2), (32, 2), (64, 2), (128, 2)]
+    for name, (v, sh, st, loc, attn) in cases.items():
+        for dtype in (torch.float32, torch.bfloat16):
+            vd, shd, std, locd, attnd = v.to(DEV, dtype), sh.to(DEV), st.to(DEV), loc.to(DEV), attn.to(DEV)
+            out = ext.ms_deform_attn_forward(vd, shd, std, locd, attnd)
+            g = torch.randn_like(out)
+            gv = torch.zeros(vd.shape, device=DEV)
+            gl = torch.empty_like(locd)
+            ga = torch.empty_like(attnd)
+            for qtile, xcd in (tunings if dtype == torch.float32 else [(0, 0)]):
+                t = _lib.Tuning(variant=0, qtile=qtile, xcd_remap=xcd)
+                tp = ctypes.byref(t) if dtype == torch.float32 else None
+                f_med, f_min = timeit(lambda: ext.ms_deform_attn_forward(vd, shd, std, locd, attnd, tuning=tp), args.iters)
+                b_med, b_min = timeit(lambda: ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga, tuning=tp), args.iters)
+                bf, bb = alg_bytes_fwd(vd, locd, attnd, out), alg_bytes_bwd(vd, locd, attnd, g)
+                r = dict(op=name, dtype=str(dtype).split(".")[-1], shape=list(locd.shape), qtile=qtile, xcd=xcd,
+                         fwd_us=f_med * 1e6, fwd_min_us=f_min * 1e6, fwd_alg_GBs=bf / f_med / 1e9,
+                         bwd_us=b_med * 1e6, bwd_min_us=b_min * 1e6, bwd_alg_GBs=bb / b_med / 1e9,
+                         fwd_alg_MB=bf / 1e6, bwd_alg_MB=bb / 1e6)
+                print(json.dumps(r), flush=True)
+                results.append(r)
+    # practical bandwidth ceiling: device copy of 1 GiB
+    a = torch.empty(256 << 20, dtype=torch.float32, device=DEV)
+    b = torch.empty_like(a)
+    c_med, _ = timeit(lambda: b.copy_(a), 10)
+    r = dict(op="copy_1GiB", us=c_med * 1e6, GBs=2 * a.numel() * 4 / c_med / 1e9)
+    print(json.dumps(r))
+    results.append(r)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/kbench.json", "w") as f:
+        json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
