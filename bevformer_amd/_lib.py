@@ -30,6 +30,10 @@ SIGNATURES = {
     "bevmsda_backward_f32": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4, _c_int),
     "bevmsda_forward_bf16": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p], _c_int),
     "bevmsda_backward_bf16": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_forward_ragged_f32": ([_c_void_p] * 6 + _DIMS + [_c_void_p, _c_void_p], _c_int),
+    "bevmsda_backward_ragged_f32": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_forward_ragged_bf16": ([_c_void_p] * 6 + _DIMS + [_c_void_p, _c_void_p], _c_int),
+    "bevmsda_backward_ragged_bf16": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
     "bevmsda_forward_f32_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                             ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4

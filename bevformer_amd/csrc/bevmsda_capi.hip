@@ -102,7 +102,16 @@ int dispatch(const KArgs &a, int variant, hipStream_t stream) {
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
                  const float *attn, int N, int S, int M, int D, int L, int Q, int P, T *out,
-                 void *stream, const bevmsda_tuning *tuning) {
+                 void *stream, const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr,
+                 int R = -1) {
+  // ragged mode: R rows in total, row r samples value[row_batch[r]]; expressed
+  // to the kernels as one batch of Q = R queries plus the row->batch table
+  const int Nv = N;
+  if (R >= 0) {
+    if (R > 0 && !row_batch) return BEVMSDA_ERR_NULL_POINTER;
+    N = 1;
+    Q = R;
+  }
   const int rc = check_common(value, shapes, lstart, loc, attn, N, S, M, D, L, Q, P);
   if (rc < 0) return rc;
   if (rc == 1) return BEVMSDA_OK;
@@ -110,7 +119,8 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, c
   if (misaligned(out)) return BEVMSDA_ERR_MISALIGNED;
   KArgs a{};
   a.value = value; a.shapes = shapes; a.lstart = lstart; a.loc = loc; a.attn = attn; a.out = out;
-  a.NQ = 1L * N * Q; a.N = N; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
+  a.row_batch = (R >= 0) ? row_batch : nullptr;
+  a.NQ = 1L * N * Q; a.N = Nv; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
   a.qtile = resolve_qtile(tuning, kDefaultQtileFwd, a.NQ);
   if (a.qtile < 0) return BEVMSDA_ERR_BAD_OPTION;
   const int xr = tuning ? tuning->xcd_remap : 0;
@@ -125,7 +135,13 @@ template <typename T>
 int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
                   const float *attn, const T *grad_out, int N, int S, int M, int D, int L, int Q,
                   int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream,
-                  const bevmsda_tuning *tuning) {
+                  const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr, int R = -1) {
+  const int Nv = N;
+  if (R >= 0) {
+    if (R > 0 && !row_batch) return BEVMSDA_ERR_NULL_POINTER;
+    N = 1;
+    Q = R;
+  }
   const int rc = check_common(value, shapes, lstart, loc, attn, N, S, M, D, L, Q, P);
   if (rc < 0) return rc;
   if (rc == 1 || L == 0 || P == 0) return BEVMSDA_OK;
@@ -135,7 +151,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   KArgs a{};
   a.value = value; a.shapes = shapes; a.lstart = lstart; a.loc = loc; a.attn = attn;
   a.grad_out = grad_out; a.grad_value = grad_value; a.grad_loc = grad_loc; a.grad_attn = grad_attn;
-  a.NQ = 1L * N * Q; a.N = N; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
+  a.row_batch = (R >= 0) ? row_batch : nullptr;
+  a.NQ = 1L * N * Q; a.N = Nv; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
   a.qtile = resolve_qtile(tuning, kDefaultQtileBwd, a.NQ);
   if (a.qtile < 0) return BEVMSDA_ERR_BAD_OPTION;
   const int xr = tuning ? tuning->xcd_remap : 0;
@@ -205,6 +222,40 @@ int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, 
                           void *stream) {
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
                                grad_value, grad_loc, grad_attn, stream, nullptr);
+}
+
+int bevmsda_forward_ragged_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *loc, const float *attn, const int32_t *row_batch, int N, int S,
+                               int M, int D, int L, int R, int P, float *out, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  return forward_impl<float>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, 0, P, out, stream,
+                             nullptr, row_batch, R);
+}
+
+int bevmsda_backward_ragged_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                const float *loc, const float *attn, const int32_t *row_batch,
+                                const float *grad_out, int N, int S, int M, int D, int L, int R, int P,
+                                float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
+                              grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R);
+}
+
+int bevmsda_forward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                const float *loc, const float *attn, const int32_t *row_batch, int N, int S,
+                                int M, int D, int L, int R, int P, uint16_t *out, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  return forward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, 0, P, out, stream,
+                              nullptr, row_batch, R);
+}
+
+int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                 const float *loc, const float *attn, const int32_t *row_batch,
+                                 const uint16_t *grad_out, int N, int S, int M, int D, int L, int R, int P,
+                                 float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
+                               grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R);
 }
 
 }  // extern "C"

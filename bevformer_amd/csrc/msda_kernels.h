@@ -40,7 +40,8 @@ struct KArgs {
   float *grad_value;
   float *grad_loc;
   float *grad_attn;
-  long NQ;  // N*Q
+  const int32_t *row_batch;  // ragged mode: value batch entry of every query row (else nq / Q)
+  long NQ;  // N*Q (ragged: total rows)
   int N, S, M, D, L, Q, P;
   int qtile;      // >=1
   int xcd_remap;  // 0/1
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) msda_fwd_kernel(const KArgs a) {
   if (nq >= a.NQ) return;
   const int P = PT ? PT : a.P;
   const int L = a.L;
-  const long n = nq / a.Q;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
   const long row = nq * a.M + m;
   const int pix_stride = a.M * D;
   const T *__restrict__ vb = static_cast<const T *>(a.value) + static_cast<size_t>(n) * a.S * pix_stride + m * D + lig * CPL;
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const KArgs a) {
   if (nq >= a.NQ) return;
   const int P = PT ? PT : a.P;
   const int L = a.L;
-  const long n = nq / a.Q;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
   const long row = nq * a.M + m;
   const int pix_stride = a.M * D;
   const size_t boff = static_cast<size_t>(n) * a.S * pix_stride + m * D + lig * CPL;
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) msda_fwd_scalar_kernel(const KArgs a) {
   const int c = static_cast<int>(tid % D);
   const long row = tid / D;
   const int m = static_cast<int>(row % a.M);
-  const long n = (row / a.M) / a.Q;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[row / a.M]) : (row / a.M) / a.Q;
   const int pix_stride = a.M * D;
   const T *vb = static_cast<const T *>(a.value) + static_cast<size_t>(n) * a.S * pix_stride + m * D + c;
   float acc[1] = {0.f};
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256) msda_bwd_scalar_kernel(const KArgs a) {
   const int c = static_cast<int>(tid % D);
   const long row = tid / D;
   const int m = static_cast<int>(row % a.M);
-  const long n = (row / a.M) / a.Q;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[row / a.M]) : (row / a.M) / a.Q;
   const int pix_stride = a.M * D;
   const size_t boff = static_cast<size_t>(n) * a.S * pix_stride + m * D + c;
   const T *vb = static_cast<const T *>(a.value) + boff;

@@ -1,0 +1,11 @@
+"""MI355X-native implementations of the reference's BEV-encoder plugin classes
+(same names as projects/mmdet3d_plugin/bevformer/modules/__init__.py:3-5)."""
+from .bricks import FFN
+from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
+from .encoder import BEVFormerEncoder, BEVFormerLayer
+from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
+from .temporal_self_attention import TemporalSelfAttention
+
+__all__ = ["BEVFormerEncoder", "BEVFormerLayer", "SpatialCrossAttention",
+           "MSDeformableAttention3D", "TemporalSelfAttention", "MyCustomBaseTransformerLayer",
+           "FFN"]

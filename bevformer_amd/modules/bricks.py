@@ -1,0 +1,62 @@
+"""Feed-forward and normalisation bricks of the encoder layer.
+
+With a real mmcv present the layer builds mmcv's own ``FFN`` through the
+``FEEDFORWARD_NETWORK`` registry (as custom_base_transformer_layer.py:157-158
+does); without it, the ``FFN`` below provides the same module with the same
+parameter names (``layers.0.0.{weight,bias}``, ``layers.1.{weight,bias}``,
+SURVEY.md §8a-K) so reference checkpoints load unchanged.
+"""
+import torch.nn as nn
+
+from ..registry import FEEDFORWARD_NETWORK, HAVE_MMCV, BaseModule, Sequential
+
+
+class FFN(BaseModule):
+    """``x + Drop(Linear(Drop(ReLU(Linear(x)))))`` — mmcv's FFN with
+    ``add_identity=True``, called as ``ffn(query, identity=None)``
+    (encoder.py:402-403)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type="ReLU", inplace=True), ffn_drop=0.0, dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        if num_fcs < 2:
+            raise ValueError(f"num_fcs should be no less than 2. got {num_fcs}.")
+        if act_cfg.get("type", "ReLU") != "ReLU":
+            raise NotImplementedError("only ReLU FFNs are used by the BEVFormer encoder")
+        self.embed_dims = embed_dims
+        self.feedforward_channels = feedforward_channels
+        self.num_fcs = num_fcs
+        layers, cin = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(Sequential(nn.Linear(cin, feedforward_channels), nn.ReLU(inplace=True),
+                                     nn.Dropout(ffn_drop)))
+            cin = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = Sequential(*layers)
+        p = (dropout_layer or {}).get("drop_prob", 0.0) if dropout_layer else 0.0
+        self.dropout_layer = nn.Dropout(p) if p else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+if not HAVE_MMCV:
+    FEEDFORWARD_NETWORK.register_module(name="FFN", module=FFN)
+
+
+def build_norm_layer(cfg, num_features):
+    """Only ``dict(type='LN')`` occurs on this path (bevformer_base.py:78-105)."""
+    if HAVE_MMCV:
+        from mmcv.cnn import build_norm_layer as _b
+        return _b(cfg, num_features)
+    if cfg.get("type") != "LN":
+        raise NotImplementedError(f"norm type {cfg.get('type')} is not used by the BEV encoder")
+    return "ln", nn.LayerNorm(num_features, eps=cfg.get("eps", 1e-5))

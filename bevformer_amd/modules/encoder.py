@@ -1,0 +1,190 @@
+"""BEVFormerEncoder / BEVFormerLayer on the MI355X kernels.
+
+Drop-in for the reference classes of the same registry names
+(projects/mmdet3d_plugin/bevformer/modules/encoder.py:24-239 and :242-406):
+same constructor arguments (built from the ``encoder=dict(...)`` block of the
+configs, bevformer_base.py:78-105), same forward keyword contract (call site
+modules/transformer.py:186-198), same ``state_dict`` keys.
+
+What is organised differently (results unchanged):
+  * all per-frame geometry — reference points, camera projection, visibility,
+    the ragged (camera, query) row list of SCA, the camera-count reciprocal and
+    the small (1,2)/(1,) BEV shape tensors the reference re-creates in every
+    layer (encoder.py:370-372) — is built once per call into a ``FramePlan``
+    and cached across calls while the camera matrices do not change;
+  * optional BEV-query tiling over the GPUs of a node (``bev_tiling.py``): each
+    rank runs the layer stack on a contiguous block of BEV rows and the grid is
+    reassembled with an RCCL all-gather.
+"""
+import copy
+import warnings
+
+import torch
+
+from ..registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, BaseModule, ModuleList,
+                        auto_fp16, build_transformer_layer, force_fp32)
+from . import geometry
+from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
+
+
+class TransformerLayerSequence(BaseModule):
+    """mmcv's ``TransformerLayerSequence`` surface: ``num_layers`` deep copies
+    of the layer config -> ``layers``; ``embed_dims`` / ``pre_norm`` mirrored
+    from the first layer (read by modules/transformer.py)."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = ModuleList()
+        for i in range(num_layers):
+            self.layers.append(build_transformer_layer(transformerlayers[i]))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module(force=True)
+class BEVFormerEncoder(TransformerLayerSequence):
+
+    def __init__(self, *args, pc_range=None, num_points_in_pillar=4, return_intermediate=False,
+                 dataset_type="nuscenes", **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.num_points_in_pillar = num_points_in_pillar
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self._plan_cache = {}
+        self.plan_cache_size = 4
+        self.bev_tiling = None          # set by bev_tiling.enable_bev_tiling()
+
+    # kept as static/instance methods with the reference's names and outputs
+    get_reference_points = staticmethod(geometry.get_reference_points)
+
+    @force_fp32(apply_to=("reference_points", "img_metas"))
+    def point_sampling(self, reference_points, pc_range, img_metas):
+        return geometry.point_sampling(reference_points, pc_range, img_metas)
+
+    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype):
+        key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
+                                img_metas, device, dtype)
+        plan = self._plan_cache.get(key)
+        if plan is None:
+            plan = geometry.build_frame_plan(bev_h, bev_w, bs, self.pc_range,
+                                             self.num_points_in_pillar, img_metas, device, dtype)
+            if len(self._plan_cache) >= self.plan_cache_size:
+                self._plan_cache.pop(next(iter(self._plan_cache)))
+            self._plan_cache[key] = plan
+        return plan
+
+    @auto_fp16()
+    def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
+                shift=0.0, **kwargs):
+        """bev_query / bev_pos / prev_bev (Q, bs, C); key = value (Nc, S, bs, C);
+        returns (bs, Q, C), or (num_layers, bs, Q, C) with return_intermediate."""
+        if self.bev_tiling is not None:
+            from .. import bev_tiling
+            return bev_tiling.tiled_forward(self, bev_query, key, value, *args, bev_h=bev_h,
+                                            bev_w=bev_w, bev_pos=bev_pos,
+                                            spatial_shapes=spatial_shapes,
+                                            level_start_index=level_start_index,
+                                            prev_bev=prev_bev, shift=shift, **kwargs)
+        bs = bev_query.size(1)
+        plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                               bev_query.dtype)
+        ref_2d = plan.ref_2d
+        shift_ref_2d = ref_2d + shift[:, None, None, :]
+
+        bev_query = bev_query.permute(1, 0, 2)
+        bev_pos = bev_pos.permute(1, 0, 2)
+        len_bev = ref_2d.shape[1]
+        if prev_bev is not None:
+            prev_bev = prev_bev.permute(1, 0, 2)
+            prev_bev = torch.stack([prev_bev, bev_query], 1).reshape(bs * 2, len_bev, -1)
+            hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
+        else:
+            hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
+
+        output = bev_query
+        intermediate = []
+        for layer in self.layers:
+            output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
+                           ref_3d=plan.ref_3d, bev_h=bev_h, bev_w=bev_w,
+                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                           reference_points_cam=plan.reference_points_cam,
+                           bev_mask=plan.bev_mask, prev_bev=prev_bev, frame_plan=plan, **kwargs)
+            bev_query = output
+            if self.return_intermediate:
+                intermediate.append(output)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output
+
+
+@TRANSFORMER_LAYER.register_module(force=True)
+class BEVFormerLayer(MyCustomBaseTransformerLayer):
+    """One encoder layer: TSA -> LN -> SCA -> LN -> FFN -> LN in the order given
+    by ``operation_order`` (encoder.py:243-406)."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN"),
+                 ffn_num_fcs=2, **kwargs):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")     # the reference config style is the deprecated one
+            super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                             ffn_dropout=ffn_dropout, operation_order=operation_order,
+                             act_cfg=act_cfg, norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs,
+                             **kwargs)
+        self.fp16_enabled = False
+        assert len(operation_order) == 6
+        assert set(operation_order) == set(["self_attn", "norm", "cross_attn", "ffn"])
+
+    def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
+                attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
+                ref_3d=None, bev_h=None, bev_w=None, reference_points_cam=None, mask=None,
+                spatial_shapes=None, level_start_index=None, prev_bev=None, frame_plan=None,
+                **kwargs):
+        norm_i = attn_i = ffn_i = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None] * self.num_attn
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+            warnings.warn(f"Use same attn_mask in all attentions in {self.__class__.__name__} ")
+        else:
+            assert len(attn_masks) == self.num_attn
+        if frame_plan is not None:
+            bev_shapes, bev_start = frame_plan.bev_shapes, frame_plan.bev_start
+        else:
+            bev_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
+            bev_start = torch.tensor([0], device=query.device)
+
+        for op in self.operation_order:
+            if op == "self_attn":
+                query = self.attentions[attn_i](
+                    query, prev_bev, prev_bev, identity if self.pre_norm else None,
+                    query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_i],
+                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
+                    spatial_shapes=bev_shapes, level_start_index=bev_start, **kwargs)
+                attn_i += 1
+                identity = query
+            elif op == "norm":
+                query = self.norms[norm_i](query)
+                norm_i += 1
+            elif op == "cross_attn":
+                query = self.attentions[attn_i](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=key_pos, reference_points=ref_3d,
+                    reference_points_cam=reference_points_cam, mask=mask,
+                    attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                    frame_plan=frame_plan, **kwargs)
+                attn_i += 1
+                identity = query
+            elif op == "ffn":
+                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                ffn_i += 1
+        return query

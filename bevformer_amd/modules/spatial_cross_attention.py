@@ -1,0 +1,209 @@
+"""SpatialCrossAttention / MSDeformableAttention3D on the MI355X kernels.
+
+Registry names, constructor arguments, parameter names and forward contracts
+follow the reference (projects/mmdet3d_plugin/bevformer/modules/
+spatial_cross_attention.py:32-175 and :179-399).  The execution differs:
+
+  * no zero-padded (bs, num_cams, max_len) rebatch and no per-layer
+    ``nonzero()`` host syncs: the visible (camera, query) pairs are a ragged row
+    list built once per frame (``modules/geometry.py``) and the sampling kernel
+    reads the value of the right camera through a row->batch table.  Padded rows
+    in the reference are computed and never read back (:165-167), so outputs
+    are identical;
+  * offsets and attention logits come from ONE GEMM over the concatenated
+    projection weights;
+  * the per-camera scatter / camera-count division is an ``index_add_`` over the
+    row list and a multiply by the precomputed reciprocal count.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..registry import ATTENTION, BaseModule, build_attention, constant_, xavier_uniform_
+from . import geometry
+from .temporal_self_attention import _direction_grid, _is_power_of_2
+
+
+@ATTENTION.register_module(force=True)
+class MSDeformableAttention3D(BaseModule):
+    """Deformable attention over the Z-anchors of a BEV pillar
+    (spatial_cross_attention.py:179-399); ``output_proj`` is ``None`` as in the
+    reference (:221) — the projection lives in SpatialCrossAttention."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=8, im2col_step=64,
+                 dropout=0.1, batch_first=True, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, "
+                             f"but got {embed_dims} and {num_heads}")
+        if not _is_power_of_2(embed_dims // num_heads):
+            warnings.warn("You'd better set embed_dims in MultiScaleDeformAttention to make the "
+                          "dimension of each attention head a power of 2 (the HIP kernel's "
+                          "16-byte lane-group path needs a multiple of 4).")
+        self.norm_cfg = norm_cfg
+        self.batch_first = batch_first
+        self.output_proj = None
+        self.fp16_enabled = False
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        constant_(self.sampling_offsets, 0.0)
+        self.sampling_offsets.bias.data = _direction_grid(self.num_heads, self.num_levels,
+                                                          self.num_points)
+        constant_(self.attention_weights, 0.0, 0.0)
+        xavier_uniform_(self.value_proj)
+        xavier_uniform_(self.output_proj)      # None: skipped, as in mmcv
+        self._is_init = True
+
+    # -- shared pieces -----------------------------------------------------
+    def _project_queries(self, query):
+        """(..., C) -> offsets (..., M, L, P, 2), softmaxed weights (..., M, L, P)
+        from one GEMM over [sampling_offsets ; attention_weights]."""
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        n_off = self.sampling_offsets.out_features
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        proj = F.linear(query, w, b)
+        lead = query.shape[:-1]
+        off = proj[..., :n_off].reshape(*lead, M, L, P, 2)
+        att = proj[..., n_off:].reshape(*lead, M, L * P).softmax(-1).view(*lead, M, L, P)
+        return off, att
+
+    def _locations(self, off, reference_points, spatial_shapes):
+        """Z-anchor sampling locations (spatial_cross_attention.py:357-372):
+        point k of a level uses anchor k mod num_Z_anchors."""
+        if reference_points.shape[-1] != 2:
+            if reference_points.shape[-1] == 4:
+                assert False
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, "
+                             f"but get {reference_points.shape[-1]} instead.")
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        lead = off.shape[:-4]
+        Dz = reference_points.shape[-2]
+        assert P % Dz == 0
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        off = off / normalizer[:, None, :]                       # (...,M,L,P,2) / (L,1,2)
+        off = off.view(*lead, M, L, P // Dz, Dz, 2)
+        ref = reference_points.view(*lead, 1, 1, 1, Dz, 2)
+        return (ref + off).view(*lead, M, L, P, 2)
+
+    # -- reference-shaped call (batch layout) --------------------------------
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        """query (bs, Q, C), value (bs, S, C), reference_points (bs, Q, Dz, 2)
+        -> (bs, Q, C).  No residual, no dropout, no output projection here."""
+        if value is None:
+            value = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, Q, _ = query.shape
+        num_value = value.shape[1]
+        v = self.value_proj(value)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        v = v.view(bs, num_value, self.num_heads, -1)
+        off, att = self._project_queries(query)
+        loc = self._locations(off, reference_points, spatial_shapes)
+        out = ops.msda(v, spatial_shapes, level_start_index, loc.contiguous(), att.contiguous(),
+                       self.im2col_step)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return out
+
+    # -- ragged call used by SpatialCrossAttention ---------------------------
+    def project_value(self, value):
+        """(N, S, C) camera features -> (N, S, M, D)."""
+        return self.value_proj(value).view(value.shape[0], value.shape[1], self.num_heads, -1)
+
+    def forward_ragged(self, query_rows, value, row_ref, row_batch, spatial_shapes,
+                       level_start_index):
+        """query_rows (R, C); value (N, S, M, D) already projected; row_ref
+        (R, Dz, 2); row_batch (R,) int32 -> (R, C)."""
+        off, att = self._project_queries(query_rows)
+        loc = self._locations(off, row_ref, spatial_shapes)
+        return ops.msda_ragged(value, spatial_shapes, level_start_index, loc.contiguous(),
+                               att.contiguous(), row_batch)
+
+
+@ATTENTION.register_module(force=True)
+class SpatialCrossAttention(BaseModule):
+    """BEV queries attend to the camera features they project into
+    (spatial_cross_attention.py:32-175)."""
+
+    def __init__(self, embed_dims=256, num_cams=6, pc_range=None, dropout=0.1, init_cfg=None,
+                 batch_first=False,
+                 deformable_attention=dict(type="MSDeformableAttention3D", embed_dims=256,
+                                           num_levels=4),
+                 **kwargs):
+        super().__init__(init_cfg)
+        self.init_cfg = init_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self.deformable_attention = build_attention(deformable_attention)
+        self.embed_dims = embed_dims
+        self.num_cams = num_cams
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.batch_first = batch_first
+        self.init_weight()
+
+    def init_weight(self):
+        xavier_uniform_(self.output_proj)
+
+    def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, reference_points_cam=None,
+                bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
+                projected_value=None, **kwargs):
+        """query (bs, Q, C); key/value (Nc, S, bs, C); reference_points_cam
+        (Nc, bs, Q, Dz, 2); bev_mask (Nc, bs, Q, Dz) -> (bs, Q, C).
+
+        ``frame_plan`` (from this package's encoder) carries the ragged row list;
+        without it the list is derived from ``bev_mask`` here (one host sync,
+        like the reference's ``nonzero()``)."""
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if residual is None:
+            inp_residual = query
+        else:  # the reference leaves `slots` undefined on this path (:128-130)
+            inp_residual = residual
+        if query_pos is not None:
+            query = query + query_pos
+        bs, Q, C = query.shape
+
+        if frame_plan is not None:
+            row_query, row_batch, row_ref, inv_count = (frame_plan.row_query, frame_plan.row_batch,
+                                                        frame_plan.row_ref, frame_plan.inv_count)
+        else:
+            row_query, row_batch, row_ref, inv_count, _ = geometry.build_sca_rows(
+                reference_points_cam, bev_mask)
+
+        if projected_value is None:
+            Nc, S, _, _ = value.shape
+            feats = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, S, self.embed_dims)
+            projected_value = self.deformable_attention.project_value(feats)
+
+        q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
+        out_rows = self.deformable_attention.forward_ragged(
+            q_rows, projected_value, row_ref, row_batch, spatial_shapes, level_start_index)
+        slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
+        slots.index_add_(0, row_query, out_rows)
+        slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
+        slots = self.output_proj(slots)
+        return self.dropout(slots) + inp_residual

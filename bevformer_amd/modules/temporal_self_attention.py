@@ -1,0 +1,160 @@
+"""TemporalSelfAttention on the MI355X deformable-attention kernels.
+
+Same registry name, constructor arguments, parameters (``sampling_offsets``,
+``attention_weights``, ``value_proj``, ``output_proj``) and forward contract as
+the reference class (projects/mmdet3d_plugin/bevformer/modules/
+temporal_self_attention.py:26-272); what differs is how the work is issued:
+
+  * the sampling-offset and attention-weight projections share their input
+    (``cat([prev_or_cur, query + pos])``), so they run as ONE GEMM over the
+    concatenated weight (same numbers, one launch, input read once);
+  * when there is no history (``value is None``) the reference stacks the query
+    twice and projects both copies (temporal_self_attention.py:177-180,198);
+    here the projection runs once and both queue entries sample the same
+    projected tensor through the ragged row->batch table of the kernel;
+  * sampling runs in the hand-written HIP kernel (no CPU fallback: on a CPU
+    tensor this raises).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..registry import ATTENTION, BaseModule, constant_, xavier_uniform_
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return (n & (n - 1) == 0) and n != 0
+
+
+def _direction_grid(num_heads, copies, num_points):
+    """Initial sampling-offset bias: one direction per head, radius i+1 for
+    point i (temporal_self_attention.py:110-122 / spatial_cross_attention.py:256-267)."""
+    thetas = torch.arange(num_heads, dtype=torch.float32) * (2.0 * math.pi / num_heads)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(num_heads, 1, 1, 2)
+    grid = grid.repeat(1, copies, num_points, 1)
+    for i in range(num_points):
+        grid[:, :, i, :] *= i + 1
+    return grid.view(-1)
+
+
+@ATTENTION.register_module(force=True)
+class TemporalSelfAttention(BaseModule):
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, num_bev_queue=2,
+                 im2col_step=64, dropout=0.1, batch_first=True, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, "
+                             f"but got {embed_dims} and {num_heads}")
+        if not _is_power_of_2(embed_dims // num_heads):
+            warnings.warn("You'd better set embed_dims in MultiScaleDeformAttention to make the "
+                          "dimension of each attention head a power of 2 (the HIP kernel's "
+                          "16-byte lane-group path needs a multiple of 4).")
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.batch_first = batch_first
+        self.fp16_enabled = False
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.num_bev_queue = num_bev_queue
+        self.sampling_offsets = nn.Linear(embed_dims * num_bev_queue,
+                                          num_bev_queue * num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims * num_bev_queue,
+                                           num_bev_queue * num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        constant_(self.sampling_offsets, 0.0)
+        self.sampling_offsets.bias.data = _direction_grid(
+            self.num_heads, self.num_levels * self.num_bev_queue, self.num_points)
+        constant_(self.attention_weights, 0.0, 0.0)
+        xavier_uniform_(self.value_proj)
+        xavier_uniform_(self.output_proj)
+        self._is_init = True
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, flag="decoder", **kwargs):
+        """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
+        b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C)."""
+        assert self.num_bev_queue == 2
+        shared_value = value is None
+        if shared_value:
+            assert self.batch_first
+        if identity is None:
+            identity = query
+        query_in = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            if value is not None:
+                value = value.permute(1, 0, 2)
+        bs, Q, C = query.shape
+        nq, M, L, P = self.num_bev_queue, self.num_heads, self.num_levels, self.num_points
+        if shared_value:
+            # the reference's stack([query, query], 1).reshape(bs*2, ...)[:bs] (:180,197):
+            # entry i of the stacked tensor is query[i // 2]
+            first = query_in if bs == 1 else query_in[torch.arange(bs, device=query.device) // 2]
+        else:
+            first = value[:bs]
+        q2 = torch.cat([first, query], -1)
+
+        src = query_in if shared_value else value
+        num_value = src.shape[1]
+        v = self.value_proj(src)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        v = v.reshape(v.shape[0], num_value, M, -1)
+
+        # one GEMM for offsets (nq*M*L*P*2 columns) and weights (nq*M*L*P columns)
+        n_off = self.sampling_offsets.out_features
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        proj = F.linear(q2, w, b)
+        off = proj[..., :n_off].reshape(bs, Q, M, nq, L, P, 2)
+        att = proj[..., n_off:].reshape(bs, Q, M, nq, L * P).softmax(-1)
+        att = att.view(bs, Q, M, nq, L, P).permute(0, 3, 1, 2, 4, 5).reshape(bs * nq, Q, M, L, P)
+        off = off.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * nq, Q, M, L, P, 2)
+
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            loc = reference_points[:, :, None, :, None, :] \
+                + off / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = reference_points[:, :, None, :, None, :2] \
+                + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, "
+                             f"but get {reference_points.shape[-1]} instead.")
+
+        if shared_value:
+            # queue entries b*2+0 and b*2+1 both sample projected batch entry b
+            row_batch = torch.arange(bs, device=query.device, dtype=torch.int32) \
+                .repeat_interleave(nq * Q)
+            out = ops.msda_ragged(v, spatial_shapes, level_start_index,
+                                  loc.reshape(bs * nq * Q, M, L, P, 2),
+                                  att.reshape(bs * nq * Q, M, L, P), row_batch)
+            out = out.view(bs * nq, Q, C)
+        else:
+            out = ops.msda(v, spatial_shapes, level_start_index, loc, att.contiguous(),
+                           self.im2col_step)
+
+        # mean over the queue entries (:257-262), then output projection
+        out = out.view(bs, nq, Q, C).mean(1)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + identity

@@ -1,0 +1,106 @@
+"""Thin functional front of the HIP operator for the modules of this package.
+
+``msda`` is the reference's operator call (``MultiScaleDeformableAttnFunction_fp32
+.apply`` at spatial_cross_attention.py:390-392 / temporal_self_attention.py:247-249);
+``msda_ragged`` is the same math over a ragged batch (row -> value-batch table),
+which is how this package runs SpatialCrossAttention without zero-padded rows.
+Neither has a CPU implementation: CPU tensors raise ``RuntimeError``.
+"""
+import torch
+from torch.autograd.function import Function, once_differentiable
+
+from . import _lib
+from .ext import _ptr, _req
+from .functions import MultiScaleDeformableAttnFunction_fp32
+
+_STORAGE = {"dtype": torch.float32}
+
+
+def set_value_storage(dtype):
+    """fp32 (reference semantics, default) or bf16 storage of the projected
+    value tensor inside the sampling kernels (fp32 arithmetic either way)."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    _STORAGE["dtype"] = dtype
+
+
+def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+         im2col_step=64):
+    if _STORAGE["dtype"] == torch.bfloat16:
+        from .functions import MultiScaleDeformableAttnFunction_bf16
+        return MultiScaleDeformableAttnFunction_bf16.apply(
+            value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+            im2col_step).to(value.dtype)
+    return MultiScaleDeformableAttnFunction_fp32.apply(
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+        im2col_step)
+
+
+def _ragged_check(value, shapes, start, loc, attn, row_batch):
+    _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
+    dev = value.device
+    for name, t in (("spatial_shapes", shapes), ("level_start_index", start),
+                    ("sampling_locations", loc), ("attention_weights", attn),
+                    ("row_batch", row_batch)):
+        _req(t.device == dev and t.is_contiguous(), f"bevmsda: {name} must be contiguous on {dev}")
+    _req(value.is_contiguous() and value.dim() == 4, "bevmsda: value must be contiguous (N,S,M,D)")
+    _req(row_batch.dtype == torch.int32, "bevmsda: row_batch must be int32")
+    _req(shapes.dtype == torch.int64 and start.dtype == torch.int64,
+         "bevmsda: spatial_shapes / level_start_index must be int64")
+    _req(loc.dtype == torch.float32 and attn.dtype == torch.float32,
+         "bevmsda: sampling_locations / attention_weights must be float32")
+    N, S, M, D = value.shape
+    _req(loc.dim() == 5 and loc.shape[-1] == 2, "bevmsda: ragged sampling_locations must be (R,M,L,P,2)")
+    R, _, L, P, _ = loc.shape
+    _req(loc.shape[1] == M and tuple(attn.shape) == (R, M, L, P) and row_batch.numel() == R
+         and tuple(shapes.shape) == (L, 2) and start.numel() == L,
+         "bevmsda: inconsistent ragged operand shapes")
+    return N, S, M, D, L, R, P
+
+
+class _RaggedFunction(Function):
+
+    @staticmethod
+    def forward(ctx, value, shapes, start, loc, attn, row_batch):
+        ctx.in_dtype = value.dtype
+        store = _STORAGE["dtype"]
+        value = value.to(store).contiguous()
+        loc = loc.float().contiguous()
+        attn = attn.float().contiguous()
+        N, S, M, D, L, R, P = _ragged_check(value, shapes, start, loc, attn, row_batch)
+        lib = _lib.load()
+        out = torch.empty((R, M * D), dtype=store, device=value.device)
+        fn = lib.bevmsda_forward_ragged_f32 if store == torch.float32 else lib.bevmsda_forward_ragged_bf16
+        with torch.cuda.device(value.device):
+            rc = fn(_ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(row_batch),
+                    N, S, M, D, L, R, P, _ptr(out), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "msda_ragged forward")
+        ctx.save_for_backward(value, shapes, start, loc, attn, row_batch)
+        return out.to(ctx.in_dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        value, shapes, start, loc, attn, row_batch = ctx.saved_tensors
+        N, S, M, D = value.shape
+        R, _, L, P, _ = loc.shape
+        grad_out = grad_out.to(value.dtype).contiguous()
+        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gl = torch.empty_like(loc)
+        ga = torch.empty_like(attn)
+        lib = _lib.load()
+        fn = lib.bevmsda_backward_ragged_f32 if value.dtype == torch.float32 \
+            else lib.bevmsda_backward_ragged_bf16
+        with torch.cuda.device(value.device):
+            rc = fn(_ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(row_batch),
+                    _ptr(grad_out), N, S, M, D, L, R, P, _ptr(gv), _ptr(gl), _ptr(ga),
+                    torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "msda_ragged backward")
+        return gv.to(ctx.in_dtype), None, None, gl, ga, None
+
+
+def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                row_batch):
+    """value (N,S,M,D); sampling_locations (R,M,L,P,2); attention_weights
+    (R,M,L,P); row_batch (R,) int32 in [0,N) -> (R, M*D)."""
+    return _RaggedFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                 attention_weights, row_batch)

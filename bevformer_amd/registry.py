@@ -1,0 +1,151 @@
+"""Registry glue for the reference's plugin API.
+
+The reference builds the encoder purely from config dicts through mmcv's
+registries (``ATTENTION`` / ``TRANSFORMER_LAYER`` / ``TRANSFORMER_LAYER_SEQUENCE``
+/ ``FEEDFORWARD_NETWORK``: spatial_cross_attention.py:14-17,31,178;
+temporal_self_attention.py:25; encoder.py:24,242; transformer.py:53).  When a
+real mmcv is importable the classes of this package register into *its*
+registries (``force=True``: they deliberately take over the plugin's names so
+that ``projects/mmdet3d_plugin`` configs resolve to the MI355X implementation);
+otherwise a minimal registry with the same ``register_module()`` / ``build()``
+surface is used, so configs written for the reference work unchanged here.
+"""
+import copy
+
+import torch.nn as nn
+
+
+class Registry:
+    """Subset of ``mmcv.utils.Registry``: name -> class, ``register_module``
+    decorator, ``build(cfg)``."""
+
+    def __init__(self, name):
+        self._name = name
+        self._module_dict = {}
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def module_dict(self):
+        return self._module_dict
+
+    def get(self, key):
+        return self._module_dict.get(key)
+
+    def __contains__(self, key):
+        return key in self._module_dict
+
+    def register_module(self, name=None, force=False, module=None):
+        def _register(cls):
+            key = name or cls.__name__
+            if not force and key in self._module_dict:
+                raise KeyError(f"{key} is already registered in {self._name}")
+            self._module_dict[key] = cls
+            return cls
+        return _register(module) if module is not None else _register
+
+    def build(self, cfg, default_args=None):
+        return build_from_cfg(cfg, self, default_args)
+
+
+def build_from_cfg(cfg, registry, default_args=None):
+    if not isinstance(cfg, dict) or "type" not in cfg:
+        raise TypeError(f"cfg must be a dict with a 'type' key, got {cfg!r}")
+    args = dict(cfg)
+    if default_args:
+        for k, v in default_args.items():
+            args.setdefault(k, v)
+    typ = args.pop("type")
+    cls = registry.get(typ) if isinstance(typ, str) else typ
+    if cls is None:
+        raise KeyError(f"{typ} is not in the {registry.name} registry")
+    return cls(**args)
+
+
+try:  # a real mmcv (not the test stub) is present: plug into it
+    import mmcv as _mmcv
+    if getattr(_mmcv, "__bevformer_amd_stub__", False):
+        raise ImportError
+    from mmcv.cnn.bricks.registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER,
+                                          TRANSFORMER_LAYER_SEQUENCE)
+    from mmcv.runner import auto_fp16, force_fp32
+    from mmcv.runner.base_module import BaseModule, ModuleList, Sequential
+    HAVE_MMCV = True
+except Exception:  # no mmcv in this environment (or only the oracle's stub)
+    HAVE_MMCV = False
+    ATTENTION = Registry("attention")
+    FEEDFORWARD_NETWORK = Registry("feed-forward Network")
+    TRANSFORMER_LAYER = Registry("transformerLayer")
+    TRANSFORMER_LAYER_SEQUENCE = Registry("transformer-layers sequence")
+
+    def _passthrough(*args, **kwargs):
+        def deco(fn):
+            return fn
+        return deco
+
+    force_fp32 = auto_fp16 = _passthrough
+
+    class BaseModule(nn.Module):
+        """``mmcv.runner.BaseModule`` surface used by this path."""
+
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self._is_init = False
+            self.init_cfg = copy.deepcopy(init_cfg)
+
+        def init_weights(self):
+            for m in self.children():
+                if hasattr(m, "init_weights"):
+                    m.init_weights()
+            self._is_init = True
+
+    class ModuleList(BaseModule, nn.ModuleList):
+        def __init__(self, modules=None, init_cfg=None):
+            BaseModule.__init__(self, init_cfg)
+            nn.ModuleList.__init__(self, modules)
+
+    class Sequential(BaseModule, nn.Sequential):
+        def __init__(self, *args, init_cfg=None):
+            BaseModule.__init__(self, init_cfg)
+            nn.Sequential.__init__(self, *args)
+
+
+def _build(cfg, registry, default_args=None):
+    if HAVE_MMCV:
+        from mmcv.utils import build_from_cfg as _bfc
+        return _bfc(cfg, registry, default_args)
+    return build_from_cfg(cfg, registry, default_args)
+
+
+def build_attention(cfg, default_args=None):
+    return _build(cfg, ATTENTION, default_args)
+
+
+def build_feedforward_network(cfg, default_args=None):
+    return _build(cfg, FEEDFORWARD_NETWORK, default_args)
+
+
+def build_transformer_layer(cfg, default_args=None):
+    return _build(cfg, TRANSFORMER_LAYER, default_args)
+
+
+def build_transformer_layer_sequence(cfg, default_args=None):
+    return _build(cfg, TRANSFORMER_LAYER_SEQUENCE, default_args)
+
+
+def xavier_uniform_(module, bias=0.0):
+    """mmcv ``xavier_init(m, distribution='uniform', bias=0.)``; a module
+    without a weight (e.g. ``None``) is skipped like mmcv does."""
+    if hasattr(module, "weight") and module.weight is not None:
+        nn.init.xavier_uniform_(module.weight)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_(module, val, bias=0.0):
+    if hasattr(module, "weight") and module.weight is not None:
+        nn.init.constant_(module.weight, val)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)

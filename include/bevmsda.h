@@ -85,6 +85,31 @@ int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                           int P, float *grad_value, float *grad_loc, float *grad_attn,
                           void *stream);
 
+/* Ragged batches: R query rows in total, row r samples value[row_batch[r]]
+ * (row_batch: int32, DEVICE memory, values in [0,N)); loc is (R, M, L, P, 2),
+ * attn (R, M, L, P), out / grad_out (R, M*D).  This is how the encoder runs
+ * SpatialCrossAttention without the reference's zero-padded per-camera
+ * rebatch (spatial_cross_attention.py:143-153: rows beyond a camera's hit
+ * count are computed and thrown away there) — same results, fewer rows. */
+int bevmsda_forward_ragged_f32(const float *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *loc, const float *attn,
+                               const int32_t *row_batch, int N, int S, int M, int D, int L,
+                               int R, int P, float *out, void *stream);
+int bevmsda_backward_ragged_f32(const float *value, const int64_t *spatial_shapes,
+                                const int64_t *level_start, const float *loc, const float *attn,
+                                const int32_t *row_batch, const float *grad_out, int N, int S,
+                                int M, int D, int L, int R, int P, float *grad_value,
+                                float *grad_loc, float *grad_attn, void *stream);
+int bevmsda_forward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                const int64_t *level_start, const float *loc, const float *attn,
+                                const int32_t *row_batch, int N, int S, int M, int D, int L,
+                                int R, int P, uint16_t *out, void *stream);
+int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                 const int64_t *level_start, const float *loc, const float *attn,
+                                 const int32_t *row_batch, const uint16_t *grad_out, int N, int S,
+                                 int M, int D, int L, int R, int P, float *grad_value,
+                                 float *grad_loc, float *grad_attn, void *stream);
+
 /* Same as above with explicit tuning. */
 int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes,
                            const int64_t *level_start, const float *loc, const float *attn,

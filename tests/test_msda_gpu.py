@@ -177,7 +177,9 @@ def test_base_size_properties(which):
     # oracle on the first and last 256 queries of every batch entry
     for sl in (slice(0, 256), slice(loc.shape[1] - 256, loc.shape[1])):
         want = msda_c.forward(value, sh, start, loc[:, sl].contiguous(), attn[:, sl].contiguous())
-        torch.testing.assert_close(out[:, sl].cpu(), want, rtol=1e-4, atol=1e-5)
+        # fp32 pixel coordinates on a 200-wide map carry ~200 * 2^-24 px of
+        # rounding (the oracle forms them in double), hence atol 1e-4 here
+        torch.testing.assert_close(out[:, sl].cpu(), want, rtol=1e-4, atol=1e-4)
     # linearity: f(2 v1 - 3 v2) = 2 f(v1) - 3 f(v2)
     v2 = torch.randn(v.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
     out2 = ext.ms_deform_attn_forward(v2, s_, st, l, a)

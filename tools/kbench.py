@@ -48,14 +48,23 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--workload", default="base")
+    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
     results = []
     cases = {}
     v, sh, st, loc, attn, hits = make_sca_msda_case(args.workload, seed=0)
     cases["sca"] = (v, sh, st, loc, attn)
     cases["tsa"] = make_tsa_msda_case(args.workload, seed=0)
-    tunings = [(0, 0)] if args.quick else [(1, 1), (1, 2), (4, 2), (8, 1), (8, 2), (16, 2), (32, 2), (64, 2), (128, 2)]
+    if args.ablate:
+        g = torch.Generator().manual_seed(1)
+        cases["sca_const"] = (v, sh, st, torch.full_like(loc, 0.5), attn)
+        cases["sca_rand"] = (v, sh, st, torch.rand(loc.shape, generator=g), attn)
+        cases["sca_oob"] = (v, sh, st, torch.full_like(loc, 3.0), attn)
+    tunings = [(0, 0, 0)] if args.quick else [(1, 2, 0), (8, 2, 0), (32, 2, 0), (1, 2, 2)]
     for name, (v, sh, st, loc, attn) in cases.items():
+        if args.only and name not in args.only.split(","):
+            continue
         for dtype in (torch.float32, torch.bfloat16):
             vd, shd, std, locd, attnd = v.to(DEV, dtype), sh.to(DEV), st.to(DEV), loc.to(DEV), attn.to(DEV)
             out = ext.ms_deform_attn_forward(vd, shd, std, locd, attnd)
@@ -63,13 +72,13 @@ def main():
             gv = torch.zeros(vd.shape, device=DEV)
             gl = torch.empty_like(locd)
             ga = torch.empty_like(attnd)
-            for qtile, xcd in (tunings if dtype == torch.float32 else [(0, 0)]):
-                t = _lib.Tuning(variant=0, qtile=qtile, xcd_remap=xcd)
+            for qtile, xcd, variant in (tunings if dtype == torch.float32 else [(0, 0, 0)]):
+                t = _lib.Tuning(variant=variant, qtile=qtile, xcd_remap=xcd)
                 tp = ctypes.byref(t) if dtype == torch.float32 else None
                 f_med, f_min = timeit(lambda: ext.ms_deform_attn_forward(vd, shd, std, locd, attnd, tuning=tp), args.iters)
                 b_med, b_min = timeit(lambda: ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga, tuning=tp), args.iters)
                 bf, bb = alg_bytes_fwd(vd, locd, attnd, out), alg_bytes_bwd(vd, locd, attnd, g)
-                r = dict(op=name, dtype=str(dtype).split(".")[-1], shape=list(locd.shape), qtile=qtile, xcd=xcd,
+                r = dict(op=name, dtype=str(dtype).split(".")[-1], shape=list(locd.shape), qtile=qtile, xcd=xcd, variant=variant,
                          fwd_us=f_med * 1e6, fwd_min_us=f_min * 1e6, fwd_alg_GBs=bf / f_med / 1e9,
                          bwd_us=b_med * 1e6, bwd_min_us=b_min * 1e6, bwd_alg_GBs=bb / b_med / 1e9,
                          fwd_alg_MB=bf / 1e6, bwd_alg_MB=bb / 1e6)
@@ -82,8 +91,9 @@ def main():
     r = dict(op="copy_1GiB", us=c_med * 1e6, GBs=2 * a.numel() * 4 / c_med / 1e9)
     print(json.dumps(r))
     results.append(r)
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/kbench.json", "w") as f:
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
+    with open(os.path.join(outdir, "kbench.json"), "w") as f:
         json.dump(results, f, indent=1)
 
 
