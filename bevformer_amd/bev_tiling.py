@@ -1,0 +1,153 @@
+"""BEV-query tiling of ONE frame over the GPUs of a node.
+
+The reference only knows data parallelism (one sample per GPU,
+bevformer/apis/mmdet_train.py:75-79).  This module adds the partition named by
+the north star: the ``bev_h x bev_w`` grid is cut into contiguous row blocks,
+rank r runs the whole layer stack on its block, and the grid is reassembled
+with an all-gather (RCCL over xGMI; ``gloo`` in the CPU tests).
+
+Why this is exact: every per-query operation of a layer (projections, softmax,
+sampling, scatter-mean, output projection, FFN, LayerNorm; encoder.py:356-404)
+is row-wise in the BEV queries.  The only cross-query reads are the sampling
+*values*:
+  * SCA samples the camera features  -> replicated input, no exchange;
+  * TSA with history samples ``[prev_bev, layer-0 bev_query]`` which the
+    reference builds ONCE before the layer loop (encoder.py:204-209,229)
+    -> replicated input, no per-layer exchange;
+  * TSA without history samples the *current* layer input
+    (temporal_self_attention.py:177-180) -> one all-gather per layer.
+One all-gather at the exit reassembles the output (it is the next frame's
+``prev_bev`` and the decoder's value).
+
+Replicated compute (Amdahl terms, measured in DESIGN.md): the value projections
+of SCA (camera features) and TSA (full BEV) run on every rank.
+"""
+from dataclasses import dataclass, replace
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class BevTiling:
+    group: Optional[object] = None
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group)
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group)
+
+
+def enable_bev_tiling(encoder, group=None):
+    """Switch ``encoder.forward`` to the tiled schedule on an initialised
+    ``torch.distributed`` process group (one process per GPU)."""
+    if not dist.is_initialized():
+        raise RuntimeError("enable_bev_tiling needs an initialised torch.distributed group")
+    encoder.bev_tiling = BevTiling(group)
+    return encoder
+
+
+def disable_bev_tiling(encoder):
+    encoder.bev_tiling = None
+    return encoder
+
+
+def row_blocks(bev_h, world):
+    """Contiguous split of the BEV rows; the first ``bev_h % world`` ranks get
+    one extra row.  -> list of (h0, h1)."""
+    base, extra = divmod(bev_h, world)
+    out, h = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((h, h + n))
+        h += n
+    return out
+
+
+def slice_plan(plan, q0, q1):
+    """The frame plan restricted to BEV queries [q0, q1) of every batch entry."""
+    Q = plan.bev_h * plan.bev_w
+    b = plan.row_query // Q
+    q = plan.row_query - b * Q
+    keep = (q >= q0) & (q < q1)
+    return replace(
+        plan, ref_3d=plan.ref_3d[:, :, q0:q1], ref_2d=plan.ref_2d[:, q0:q1],
+        reference_points_cam=plan.reference_points_cam[:, :, q0:q1],
+        bev_mask=plan.bev_mask[:, :, q0:q1],
+        row_query=(b[keep] * (q1 - q0) + (q[keep] - q0)).contiguous(),
+        row_batch=plan.row_batch[keep].contiguous(), row_ref=plan.row_ref[keep].contiguous(),
+        inv_count=plan.inv_count[:, q0:q1].contiguous(), hits=[])
+
+
+def all_gather_rows(local, blocks, bev_w, group=None):
+    """local (bs, rows_r*bev_w, C) on every rank -> (bs, Q, C).  Blocks may be
+    uneven (padded to the largest for the collective)."""
+    world = len(blocks)
+    sizes = [(h1 - h0) * bev_w for h0, h1 in blocks]
+    mx = max(sizes)
+    bs, n, C = local.shape
+    if n < mx:
+        local = torch.cat([local, local.new_zeros(bs, mx - n, C)], 1)
+    buf = local.new_empty(world, bs, mx, C)
+    dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
+    if all(s == mx for s in sizes):
+        return buf.permute(1, 0, 2, 3).reshape(bs, world * mx, C)
+    return torch.cat([buf[r, :, :sizes[r]] for r in range(world)], 1)
+
+
+def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                  spatial_shapes=None, level_start_index=None, prev_bev=None, shift=0.0,
+                  **kwargs):
+    """Same contract as ``BEVFormerEncoder.forward``; every rank returns the
+    full (bs, Q, C) grid."""
+    tiling = encoder.bev_tiling
+    group, world, rank = tiling.group, tiling.world, tiling.rank
+    bs = bev_query.size(1)
+    plan = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                              bev_query.dtype)
+    blocks = row_blocks(bev_h, world)
+    h0, h1 = blocks[rank]
+    q0, q1 = h0 * bev_w, h1 * bev_w
+    cache = getattr(plan, "_tiles", None)
+    if cache is None:
+        cache = plan._tiles = {}
+    tile = cache.get((q0, q1))
+    if tile is None:
+        tile = cache[(q0, q1)] = slice_plan(plan, q0, q1)
+
+    ref_2d = plan.ref_2d
+    shift_ref_2d = ref_2d + shift[:, None, None, :]
+    full_query = bev_query.permute(1, 0, 2)
+    pos_local = bev_pos.permute(1, 0, 2)[:, q0:q1]
+    Q = ref_2d.shape[1]
+    if prev_bev is not None:
+        tsa_value = torch.stack([prev_bev.permute(1, 0, 2), full_query], 1).reshape(bs * 2, Q, -1)
+        hybrid = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
+    else:
+        tsa_value = None
+        hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
+    hybrid = hybrid[:, q0:q1].contiguous()
+
+    x = full_query[:, q0:q1].contiguous()
+    inter = []
+    for li, layer in enumerate(encoder.layers):
+        if prev_bev is None:
+            # no history: TSA's value is the CURRENT full BEV -> exchange per layer
+            full = full_query if li == 0 else all_gather_rows(x, blocks, bev_w, group)
+            layer_value = torch.stack([full, full], 1).reshape(bs * 2, Q, -1)
+        else:
+            layer_value = tsa_value
+        x = layer(x, key, value, *args, bev_pos=pos_local, ref_2d=hybrid, ref_3d=tile.ref_3d,
+                  bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
+                  level_start_index=level_start_index,
+                  reference_points_cam=tile.reference_points_cam, bev_mask=tile.bev_mask,
+                  prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), **kwargs)
+        if encoder.return_intermediate:
+            inter.append(all_gather_rows(x, blocks, bev_w, group))
+    if encoder.return_intermediate:
+        return torch.stack(inter)
+    return all_gather_rows(x, blocks, bev_w, group)

@@ -137,7 +137,7 @@ class MSDeformableAttention3D(BaseModule):
         off, att = self._project_queries(query_rows)
         loc = self._locations(off, row_ref, spatial_shapes)
         return ops.msda_ragged(value, spatial_shapes, level_start_index, loc.contiguous(),
-                               att.contiguous(), row_batch)
+                               att.contiguous(), row_batch, tag="sca_fwd")
 
 
 @ATTENTION.register_module(force=True)

@@ -86,9 +86,12 @@ class TemporalSelfAttention(BaseModule):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, flag="decoder", **kwargs):
+                level_start_index=None, flag="decoder", bev_slice=None, **kwargs):
         """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
-        b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C)."""
+        b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C).
+
+        ``bev_slice=(q0, q1)`` (BEV tiling): ``query`` holds only queries
+        [q0, q1) while ``value`` is the full grid."""
         assert self.num_bev_queue == 2
         shared_value = value is None
         if shared_value:
@@ -110,6 +113,8 @@ class TemporalSelfAttention(BaseModule):
             first = query_in if bs == 1 else query_in[torch.arange(bs, device=query.device) // 2]
         else:
             first = value[:bs]
+            if bev_slice is not None:
+                first = first[:, bev_slice[0]:bev_slice[1]]
         q2 = torch.cat([first, query], -1)
 
         src = query_in if shared_value else value
@@ -146,11 +151,11 @@ class TemporalSelfAttention(BaseModule):
                 .repeat_interleave(nq * Q)
             out = ops.msda_ragged(v, spatial_shapes, level_start_index,
                                   loc.reshape(bs * nq * Q, M, L, P, 2),
-                                  att.reshape(bs * nq * Q, M, L, P), row_batch)
+                                  att.reshape(bs * nq * Q, M, L, P), row_batch, tag="tsa_fwd")
             out = out.view(bs * nq, Q, C)
         else:
             out = ops.msda(v, spatial_shapes, level_start_index, loc, att.contiguous(),
-                           self.im2col_step)
+                           self.im2col_step, tag="tsa_fwd")
 
         # mean over the queue entries (:257-262), then output projection
         out = out.view(bs, nq, Q, C).mean(1)

@@ -14,6 +14,31 @@ from .ext import _ptr, _req
 from .functions import MultiScaleDeformableAttnFunction_fp32
 
 _STORAGE = {"dtype": torch.float32}
+_TIMER = {"cb": None}
+
+
+def set_kernel_timer(cb):
+    """``cb(tag, algorithmic_bytes)`` must return a context manager; it brackets
+    every sampling-kernel launch (bench.py records HIP events on the launch
+    stream with it).  ``None`` removes the hook."""
+    _TIMER["cb"] = cb
+
+
+class _NoTimer:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _timed(tag, value, loc, attn, out_elems):
+    cb = _TIMER["cb"]
+    if cb is None:
+        return _NoTimer()
+    alg = value.numel() * value.element_size() + loc.numel() * 4 + attn.numel() * 4 \
+        + out_elems * value.element_size()
+    return cb(tag, alg)
 
 
 def set_value_storage(dtype):
@@ -24,7 +49,19 @@ def set_value_storage(dtype):
 
 
 def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
-         im2col_step=64):
+         im2col_step=64, tag="msda_fwd"):
+    if _TIMER["cb"] is not None and not torch.is_grad_enabled():
+        N, Q = sampling_locations.shape[:2]
+        with _timed(tag, value, sampling_locations, attention_weights,
+                    N * Q * value.shape[2] * value.shape[3]):
+            return _msda(value, spatial_shapes, level_start_index, sampling_locations,
+                         attention_weights, im2col_step)
+    return _msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                 im2col_step)
+
+
+def _msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+          im2col_step=64):
     if _STORAGE["dtype"] == torch.bfloat16:
         from .functions import MultiScaleDeformableAttnFunction_bf16
         return MultiScaleDeformableAttnFunction_bf16.apply(
@@ -60,7 +97,7 @@ def _ragged_check(value, shapes, start, loc, attn, row_batch):
 class _RaggedFunction(Function):
 
     @staticmethod
-    def forward(ctx, value, shapes, start, loc, attn, row_batch):
+    def forward(ctx, value, shapes, start, loc, attn, row_batch, tag="msda_fwd"):
         ctx.in_dtype = value.dtype
         store = _STORAGE["dtype"]
         value = value.to(store).contiguous()
@@ -70,7 +107,7 @@ class _RaggedFunction(Function):
         lib = _lib.load()
         out = torch.empty((R, M * D), dtype=store, device=value.device)
         fn = lib.bevmsda_forward_ragged_f32 if store == torch.float32 else lib.bevmsda_forward_ragged_bf16
-        with torch.cuda.device(value.device):
+        with torch.cuda.device(value.device), _timed(tag, value, loc, attn, R * M * D):
             rc = fn(_ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(row_batch),
                     N, S, M, D, L, R, P, _ptr(out), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "msda_ragged forward")
@@ -95,12 +132,12 @@ class _RaggedFunction(Function):
                     _ptr(grad_out), N, S, M, D, L, R, P, _ptr(gv), _ptr(gl), _ptr(ga),
                     torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "msda_ragged backward")
-        return gv.to(ctx.in_dtype), None, None, gl, ga, None
+        return gv.to(ctx.in_dtype), None, None, gl, ga, None, None
 
 
 def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
-                row_batch):
+                row_batch, tag="msda_fwd"):
     """value (N,S,M,D); sampling_locations (R,M,L,P,2); attention_weights
     (R,M,L,P); row_batch (R,) int32 in [0,N) -> (R, M*D)."""
     return _RaggedFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
-                                 attention_weights, row_batch)
+                                 attention_weights, row_batch, tag)

@@ -7,11 +7,11 @@ from bevformer_amd import ops
 from oracle import bevformer_cpu as O
 
 
-def _oracle_msda(value, shapes, start, loc, attn, im2col_step=64):
+def _oracle_msda(value, shapes, start, loc, attn, im2col_step=64, tag=None):
     return O.msda_gridsample(value, shapes, loc, attn)
 
 
-def _oracle_msda_ragged(value, shapes, start, loc, attn, row_batch):
+def _oracle_msda_ragged(value, shapes, start, loc, attn, row_batch, tag=None):
     """Ragged batch through the oracle: one call per value-batch entry."""
     R, M = loc.shape[:2]
     out = value.new_zeros(R, M * value.shape[-1])
