@@ -45,7 +45,19 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
   if (nb >= (1LL << 31) - 8) return BEVMSDA_ERR_TOO_LARGE;
   a.nblocks = static_cast<int>(nb);
   const unsigned grid = a.xcd_remap ? static_cast<unsigned>(((nb + 7) / 8) * 8) : static_cast<unsigned>(nb);
-  if (BWD) {
+  if (BWD && a.D == 32 && a.variant != 1) {
+    // D = 32: line-shaped atomics (8 rows per wave in float4 lane groups)
+    KArgs b = a;
+    const long g8 = tiles * a.qtile * a.M;
+    const long nb8 = (g8 + 31) / 32;
+    b.nblocks = static_cast<int>(nb8);
+    const unsigned grid8 = b.xcd_remap ? static_cast<unsigned>(((nb8 + 7) / 8) * 8) : static_cast<unsigned>(nb8);
+    switch (a.P) {
+      case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 4>), dim3(grid8), dim3(256), 0, stream, b); break;
+      case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 8>), dim3(grid8), dim3(256), 0, stream, b); break;
+      default: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 0>), dim3(grid8), dim3(256), 0, stream, b); break;
+    }
+  } else if (BWD) {
     switch (a.P) {
       case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 4>), dim3(grid), dim3(256), 0, stream, a); break;
       case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 8>), dim3(grid), dim3(256), 0, stream, a); break;
@@ -128,6 +140,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, c
   a.xcd_remap = (xr == 1) ? 0 : 1;
   const int variant = tuning ? tuning->variant : 0;
   if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  a.variant = variant;
   return dispatch<T, false>(a, variant, static_cast<hipStream_t>(stream));
 }
 
@@ -160,6 +173,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   a.xcd_remap = (xr == 1) ? 0 : 1;
   const int variant = tuning ? tuning->variant : 0;
   if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  a.variant = variant;
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
 }
 

@@ -46,6 +46,7 @@ struct KArgs {
   int qtile;      // >=1
   int xcd_remap;  // 0/1
   int nblocks;    // logical blocks
+  int variant;    // 0 default, 1 generic lane-group kernels only, 2 scalar fallback
 };
 
 typedef uint16_t bf16_t;
@@ -328,6 +329,145 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const KArgs a) {
         if (lig == j) { out_ga = ga; out_gx = gx; out_gy = gy; }
       }
       if (p0 + lig < P) {
+        gap[l * P + p0 + lig] = out_ga;
+        glp[l * P + p0 + lig] = make_float2(out_gx, out_gy);
+      }
+    }
+  }
+}
+
+
+// -------------------------------------------- backward, D = 32 (the encoder's head size)
+// Measured on MI355X (tools/probes/atomic_probe.hip): fp32 global atomics retire
+// ~10 G (instruction x 128-byte line) operations per second no matter how many
+// dwords of the line an instruction carries — 80 G atomics/s when 8 lanes touch a
+// line (the generic kernel above), 326 G/s when 32 consecutive lanes cover the
+// whole line.  This kernel therefore keeps the float4 lane-group layout for the
+// value loads and the channel reductions, and re-shapes only the scatter: the
+// bilinear coefficient and element offset of every (row, tap) are broadcast to a
+// 32-lane half-wave whose lane i owns channel i of that row's grad_out, so each
+// atomic instruction updates two complete (pixel, head) lines.
+template <>
+struct Io<bf16_t, 4> {
+  static __device__ __forceinline__ void load(const bf16_t *p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    v[0] = bf16_lo(t.x); v[1] = bf16_hi(t.x); v[2] = bf16_lo(t.y); v[3] = bf16_hi(t.y);
+  }
+};
+
+template <typename T, int PT>
+__global__ void __launch_bounds__(256) msda_bwd_d32_kernel(const KArgs a) {
+  constexpr int LPG = 8, CPL = 4, D = 32, GPB = 256 / LPG;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane & 7;
+  const int half_lane = lane & 31;            // channel owned in the scatter phase
+  const int half_base = lane & 32;            // first lane of my half-wave
+  const long G = static_cast<long>(logical_block(a)) * GPB + threadIdx.x / LPG;
+  long nq; int m;
+  map_group(G, a, nq, m);
+  const bool active = nq < a.NQ;
+  if (!active) nq = a.NQ - 1;                 // keep the lanes alive for the cross-group shuffles
+  const int P = PT ? PT : a.P;
+  const int L = a.L;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
+  const long row = nq * a.M + m;
+  const int pix_stride = a.M * D;
+  // element offset of (n, :, m, 0) — fits in 63 bits, kept as two shuffled halves
+  const long long boff = static_cast<long long>(n) * a.S * pix_stride + m * D;
+  const T *__restrict__ vb = static_cast<const T *>(a.value) + boff + lig * CPL;
+  const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * P;
+  const float *__restrict__ ap = a.attn + row * L * P;
+  float2 *__restrict__ glp = reinterpret_cast<float2 *>(a.grad_loc) + row * L * P;
+  float *__restrict__ gap = a.grad_attn + row * L * P;
+
+  float g[CPL];
+  Io<T, CPL>::load(static_cast<const T *>(a.grad_out) + row * D + lig * CPL, g);
+
+  // scatter-side state: for each of the 4 rows handled by my half-wave, my
+  // channel of its grad_out and the base of its (n, m) gradient slice
+  float gd[4];
+  long long gbase[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int src = half_base + k * 8;        // first lane of that row's group
+    const float e0 = __shfl(g[0], src + (half_lane >> 2), 64), e1 = __shfl(g[1], src + (half_lane >> 2), 64);
+    const float e2 = __shfl(g[2], src + (half_lane >> 2), 64), e3 = __shfl(g[3], src + (half_lane >> 2), 64);
+    const int c = half_lane & 3;
+    gd[k] = c == 0 ? e0 : (c == 1 ? e1 : (c == 2 ? e2 : e3));
+    const int lo = __shfl(static_cast<int>(boff & 0xffffffffLL), src, 64);
+    const int hi = __shfl(static_cast<int>(boff >> 32), src, 64);
+    const int ok = __shfl(active ? 1 : 0, src, 64);
+    gbase[k] = (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo);
+    if (!ok) gd[k] = 0.f;                     // rows past the end scatter nothing
+  }
+
+  for (int l = 0; l < L; ++l) {
+    const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+    const long long lo_off = static_cast<long long>(a.lstart[l]) * pix_stride;
+    const T *__restrict__ vl = vb + lo_off;
+#pragma unroll
+    for (int p0 = 0; p0 < P; p0 += LPG) {
+      float2 mxy = make_float2(-4.f, -4.f);
+      float ma = 0.f;
+      if (p0 + lig < P) {
+        mxy = lp[l * P + p0 + lig];
+        ma = ap[l * P + p0 + lig];
+      }
+      float out_ga = 0.f, out_gx = 0.f, out_gy = 0.f;
+      const int cnt = (P - p0) < LPG ? (P - p0) : LPG;
+#pragma unroll
+      for (int j = 0; j < cnt; ++j) {
+        const float lx = __shfl(mxy.x, j, LPG), ly = __shfl(mxy.y, j, LPG), aw = __shfl(ma, j, LPG);
+        float ga = 0.f, gx = 0.f, gy = 0.f;
+        // per-tap scatter coefficients (0 = nothing to add) and offsets of my row
+        float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+        int o00 = 0, dx = 0, dy = 0;
+        Tap t;
+        if (make_tap(lx, ly, H, W, pix_stride, t)) {
+          float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) v00[c] = v01[c] = v10[c] = v11[c] = 0.f;
+          if (t.ok00) Io<T, CPL>::load(vl + t.o00, v00);
+          if (t.ok01) Io<T, CPL>::load(vl + t.o00 + t.dx, v01);
+          if (t.ok10) Io<T, CPL>::load(vl + t.o00 + t.dy, v10);
+          if (t.ok11) Io<T, CPL>::load(vl + t.o00 + t.dy + t.dx, v11);
+          const float hx = 1.f - t.fx, hy = 1.f - t.fy;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const float gc = g[c];
+            ga = fmaf(gc, t.w00 * v00[c] + t.w01 * v01[c] + t.w10 * v10[c] + t.w11 * v11[c], ga);
+            gx = fmaf(gc, hy * (v01[c] - v00[c]) + t.fy * (v11[c] - v10[c]), gx);
+            gy = fmaf(gc, hx * (v10[c] - v00[c]) + t.fx * (v11[c] - v01[c]), gy);
+          }
+          gx *= aw * static_cast<float>(W);
+          gy *= aw * static_cast<float>(H);
+          if (t.ok00) c00 = t.w00 * aw;
+          if (t.ok01) c01 = t.w01 * aw;
+          if (t.ok10) c10 = t.w10 * aw;
+          if (t.ok11) c11 = t.w11 * aw;
+          o00 = t.o00; dx = t.dx; dy = t.dy;
+        }
+        ga = group_sum<LPG>(ga);
+        gx = group_sum<LPG>(gx);
+        gy = group_sum<LPG>(gy);
+        if (lig == j) { out_ga = ga; out_gx = gx; out_gy = gy; }
+
+        // scatter: 4 rows x 4 taps per half-wave, one full line per atomic
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int src = half_base + k * 8;
+          const float k00 = __shfl(c00, src, 64), k01 = __shfl(c01, src, 64);
+          const float k10 = __shfl(c10, src, 64), k11 = __shfl(c11, src, 64);
+          const int q00 = __shfl(o00, src, 64), qdx = __shfl(dx, src, 64), qdy = __shfl(dy, src, 64);
+          float *__restrict__ gp = a.grad_value + gbase[k] + lo_off + q00 + half_lane;
+          const float gk = gd[k];
+          if (k00 != 0.f) unsafeAtomicAdd(gp, k00 * gk);
+          if (k01 != 0.f) unsafeAtomicAdd(gp + qdx, k01 * gk);
+          if (k10 != 0.f) unsafeAtomicAdd(gp + qdy, k10 * gk);
+          if (k11 != 0.f) unsafeAtomicAdd(gp + qdy + qdx, k11 * gk);
+        }
+      }
+      if (active && p0 + lig < P) {
         gap[l * P + p0 + lig] = out_ga;
         glp[l * P + p0 + lig] = make_float2(out_gx, out_gy);
       }
