@@ -92,8 +92,11 @@ def all_gather_rows(local, blocks, bev_w, group=None):
     bs, n, C = local.shape
     if n < mx:
         local = torch.cat([local, local.new_zeros(bs, mx - n, C)], 1)
-    buf = local.new_empty(world, bs, mx, C)
-    dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
+    # output is the dim-0 concatenation of the shards (the layout both RCCL and
+    # gloo accept for all_gather_into_tensor), viewed back as (world, bs, mx, C)
+    flat = local.new_empty(world * bs, mx, C)
+    dist.all_gather_into_tensor(flat, local.contiguous(), group=group)
+    buf = flat.view(world, bs, mx, C)
     if all(s == mx for s in sizes):
         return buf.permute(1, 0, 2, 3).reshape(bs, world * mx, C)
     return torch.cat([buf[r, :, :sizes[r]] for r in range(world)], 1)
