@@ -38,6 +38,10 @@ SIGNATURES = {
                                                             ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4
                                 + [ctypes.POINTER(Tuning)], _c_int),
+    "bevmsda_forward_bf16_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
+                                                             ctypes.POINTER(Tuning)], _c_int),
+    "bevmsda_backward_bf16_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4
+                                 + [ctypes.POINTER(Tuning)], _c_int),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 // kernel selection and launches.  No torch, no allocation, no global state.
 #include "../../include/bevmsda.h"
 #include "msda_kernels.h"
+#include "msda_d32.h"
 
 namespace {
 
@@ -26,6 +27,21 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *lstart
   }
   if (1LL * S * M * D >= (1LL << 31) || 1LL * L * P * 2 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   return BEVMSDA_OK;
+}
+
+int ilog2_exact(long v) {
+  if (v <= 0 || (v & (v - 1)) != 0) return -1;
+  int s = 0;
+  while ((1L << s) < v) ++s;
+  return s;
+}
+
+// D = 32 forward through the buffer-descriptor kernel (msda_d32.h): needs P in {4, 8}
+// and the whole value tensor addressable with a 31-bit byte offset.
+template <typename T>
+bool d32_fwd_eligible(const KArgs &a) {
+  const unsigned long long bytes = 1ULL * a.N * a.S * a.M * a.D * sizeof(T);
+  return a.D == 32 && a.L >= 1 && (a.P == 4 || a.P == 8) && bytes < (1ULL << 31);
 }
 
 int resolve_qtile(const bevmsda_tuning *t, int dflt, long NQ) {
@@ -63,6 +79,25 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 8>), dim3(grid), dim3(256), 0, stream, a); break;
       default: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 0>), dim3(grid), dim3(256), 0, stream, a); break;
     }
+  } else if (!BWD && a.variant != 1 && d32_fwd_eligible<T>(a)) {
+    // variant 0 / 3: registers for 4 waves per SIMD; 4: 8 waves; 5: 2 waves (msda_d32.h)
+    const int wpe = a.variant == 4 ? 8 : (a.variant == 5 ? 2 : 4);
+    KArgs b = a;
+    const long nb8 = (tiles * a.qtile * a.M + 31) / 32;
+    b.nblocks = static_cast<int>(nb8);
+    const dim3 g8(b.xcd_remap ? static_cast<unsigned>(((nb8 + 7) / 8) * 8) : static_cast<unsigned>(nb8));
+#define BEVMSDA_D32(PT_, W_) \
+  hipLaunchKernelGGL((bevmsda::msda_fwd_d32_kernel<T, PT_, W_>), g8, dim3(256), 0, stream, b)
+    if (a.P == 8) {
+      if (wpe == 8) BEVMSDA_D32(8, 8);
+      else if (wpe == 2) BEVMSDA_D32(8, 2);
+      else BEVMSDA_D32(8, 4);
+    } else {
+      if (wpe == 8) BEVMSDA_D32(4, 8);
+      else if (wpe == 2) BEVMSDA_D32(4, 2);
+      else BEVMSDA_D32(4, 4);
+    }
+#undef BEVMSDA_D32
   } else {
     switch (a.P) {
       case 4: hipLaunchKernelGGL((bevmsda::msda_fwd_kernel<T, CPL, LPG, 4>), dim3(grid), dim3(256), 0, stream, a); break;
@@ -139,8 +174,10 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, c
   if (xr < 0 || xr > 2) return BEVMSDA_ERR_BAD_OPTION;
   a.xcd_remap = (xr == 1) ? 0 : 1;
   const int variant = tuning ? tuning->variant : 0;
-  if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  if (variant < 0 || variant > 5) return BEVMSDA_ERR_BAD_OPTION;
   a.variant = variant;
+  a.mshift = ilog2_exact(M);
+  a.qshift = ilog2_exact(a.qtile);
   return dispatch<T, false>(a, variant, static_cast<hipStream_t>(stream));
 }
 
@@ -171,9 +208,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   const int xr = tuning ? tuning->xcd_remap : 0;
   if (xr < 0 || xr > 2) return BEVMSDA_ERR_BAD_OPTION;
   a.xcd_remap = (xr == 1) ? 0 : 1;
-  const int variant = tuning ? tuning->variant : 0;
-  if (variant < 0 || variant > 2) return BEVMSDA_ERR_BAD_OPTION;
+  int variant = tuning ? tuning->variant : 0;
+  if (variant < 0 || variant > 5) return BEVMSDA_ERR_BAD_OPTION;
+  if (variant > 2) variant = 0;  // 3..5 select forward kernels only
   a.variant = variant;
+  a.mshift = ilog2_exact(M);
+  a.qshift = ilog2_exact(a.qtile);
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
 }
 
@@ -236,6 +276,20 @@ int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, 
                           void *stream) {
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
                                grad_value, grad_loc, grad_attn, stream, nullptr);
+}
+
+int bevmsda_forward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
+                            int P, uint16_t *out, void *stream, const bevmsda_tuning *tuning) {
+  return forward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, tuning);
+}
+
+int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                             const float *loc, const float *attn, const uint16_t *grad_out, int N, int S, int M,
+                             int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                             void *stream, const bevmsda_tuning *tuning) {
+  return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P,
+                               grad_value, grad_loc, grad_attn, stream, tuning);
 }
 
 int bevmsda_forward_ragged_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,

@@ -1,0 +1,195 @@
+// Multi-scale deformable attention, head size D = 32 (every BEVFormer config):
+// the forward sampling kernel of the BEV-encoder hot path for CDNA4 (gfx950).
+//
+// Same math as msda_kernels.h (operator reached by the
+// reference at bevformer/modules/multi_scale_deformable_attn_function.py:118-124).
+// What is specific to this kernel:
+//
+//   * lane group = 8 lanes x 4 channels (one 16-byte fp32 / 8-byte bf16 request per
+//     lane and bilinear tap: one tap of one head is one contiguous 128 B / 64 B line);
+//     a wavefront carries 8 (query row, head) pairs, a 256-thread block 32;
+//   * the sampling parameters of a level's points are computed ONCE, lane j of a
+//     group owning point j (floor, bilinear coefficients x attention weight,
+//     validity folded into the coefficients, byte offset of the top-left tap), and
+//     are then broadcast inside the group with ds_swizzle BROADCAST(8, j) — the
+//     LDS crossbar without an address VGPR — instead of being recomputed by all 8
+//     lanes (the generic kernel spends ~60 VALU instructions per point on that);
+//   * value is read through ONE raw buffer descriptor over the whole tensor with
+//     hardware bounds checking: a point outside the map gets the byte offset
+//     0x80000000 (beyond num_records -> the load returns 0 and touches no cache
+//     line), a tap outside the map keeps its in-range neighbour address and a
+//     coefficient of exactly 0.  The inner loop therefore has no branches: all
+//     16 requests of 4 points are issued back to back (16 x 1 KiB per wave in
+//     flight) before the first FMA waits;
+//   * blocks are dealt to XCDs in contiguous row ranges (msda_kernels.h).
+//
+// Exactness note: an out-of-map tap contributes fma(0, v, acc) with v a finite
+// neighbouring feature value instead of being skipped; identical results for
+// finite feature maps (the reference's CPU fallback, grid_sample with zero
+// padding, multiplies by the out-of-range mask the same way).
+#pragma once
+#include "msda_kernels.h"
+
+namespace bevmsda {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kOobOffset = 0x80000000u;  // > num_records of any eligible tensor
+
+template <typename T> struct TapLoad;
+template <> struct TapLoad<float> {
+  static constexpr int kBytes = 16;
+  static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, 0);
+    f32x4 o;
+    o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]);
+    o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
+    return o;
+  }
+};
+template <> struct TapLoad<bf16_t> {
+  static constexpr int kBytes = 8;
+  static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, 0);
+    f32x4 o;
+    o[0] = bf16_lo(v[0]); o[1] = bf16_hi(v[0]); o[2] = bf16_lo(v[1]); o[3] = bf16_hi(v[1]);
+    return o;
+  }
+};
+
+template <int J>
+__device__ __forceinline__ float bcast8(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (J << 5) | 0x18));
+}
+template <int J>
+__device__ __forceinline__ uint32_t bcast8(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), (J << 5) | 0x18));
+}
+
+// Sampling parameters of one point, held by the lane that owns the point.
+struct PointParams {
+  float k00, k01, k10, k11;  // bilinear coefficient x attention weight, 0 when the tap is outside
+  uint32_t off;              // byte offset of value[n, level, y0, x0, m, 0], or kOobOffset
+};
+
+__device__ __forceinline__ PointParams point_params(float lx, float ly, float aw, int H, int W,
+                                                    uint32_t level_base, uint32_t pix_bytes) {
+  PointParams p;
+  const float Wf = static_cast<float>(W), Hf = static_cast<float>(H);
+  const float x = lx * Wf - 0.5f, y = ly * Hf - 0.5f;
+  const bool inside = (x > -1.f) && (y > -1.f) && (x < Wf) && (y < Hf);
+  const float xf = floorf(x), yf = floorf(y);
+  const int x0 = static_cast<int>(xf), y0 = static_cast<int>(yf);
+  const float fx = x - xf, fy = y - yf;
+  const float gx = 1.f - fx, gy = 1.f - fy;
+  const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W, y0ok = y0 >= 0, y1ok = y0 + 1 < H;
+  const float a = inside ? aw : 0.f;
+  p.k00 = (y0ok && x0ok) ? gy * gx * a : 0.f;
+  p.k01 = (y0ok && x1ok) ? gy * fx * a : 0.f;
+  p.k10 = (y1ok && x0ok) ? fy * gx * a : 0.f;
+  p.k11 = (y1ok && x1ok) ? fy * fx * a : 0.f;
+  // y0*W + x0 >= -(W+1): two's-complement wrap keeps the sum right whenever the tap
+  // itself is in range; otherwise the coefficient is 0 or the load is out of range
+  const uint32_t o = level_base + static_cast<uint32_t>(y0 * W + x0) * pix_bytes;
+  p.off = inside ? o : kOobOffset;
+  return p;
+}
+
+// Broadcast the parameters of points J0 .. J0+CNT-1 (held by lanes J0.. of every
+// group), issue their 4*CNT tap requests back to back, then accumulate.
+template <int J0, int j, int CNT, typename T>
+struct IssuePoints {
+  static __device__ __forceinline__ void run(const PointParams &p, __amdgpu_buffer_rsrc_t r,
+                                             uint32_t lane_term, uint32_t dxb, uint32_t dyb,
+                                             f32x4 (&v)[CNT][4], float (&k)[CNT][4]) {
+    constexpr int J = J0 + j;
+    // p.off carries no lane term: every lane adds its own channel offset
+    // (kOobOffset + lane_term stays beyond num_records < 2^31)
+    const uint32_t o = bcast8<J>(p.off) + lane_term;
+    k[j][0] = bcast8<J>(p.k00); k[j][1] = bcast8<J>(p.k01);
+    k[j][2] = bcast8<J>(p.k10); k[j][3] = bcast8<J>(p.k11);
+    v[j][0] = TapLoad<T>::load(r, o);
+    v[j][1] = TapLoad<T>::load(r, o + dxb);
+    v[j][2] = TapLoad<T>::load(r, o + dyb);
+    v[j][3] = TapLoad<T>::load(r, o + dyb + dxb);
+    if constexpr (j + 1 < CNT) IssuePoints<J0, j + 1, CNT, T>::run(p, r, lane_term, dxb, dyb, v, k);
+  }
+};
+
+template <int J0, int CNT, typename T>
+__device__ __forceinline__ void sample_points(const PointParams &p, __amdgpu_buffer_rsrc_t r,
+                                              uint32_t lane_term, uint32_t dxb, uint32_t dyb,
+                                              f32x4 &acc) {
+  f32x4 v[CNT][4];
+  float k[CNT][4];
+  IssuePoints<J0, 0, CNT, T>::run(p, r, lane_term, dxb, dyb, v, k);
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[0] = fmaf(k[j][t], v[j][t][0], acc[0]);
+      acc[1] = fmaf(k[j][t], v[j][t][1], acc[1]);
+      acc[2] = fmaf(k[j][t], v[j][t][2], acc[2]);
+      acc[3] = fmaf(k[j][t], v[j][t][3], acc[3]);
+    }
+  }
+}
+
+// PT = points per level (4 or 8).  WPE = waves per SIMD the register allocation is
+// sized for: it is the knob that decides how many of a level's 4*PT tap requests hipcc
+// keeps in flight per wave (8 -> 64 VGPRs, ~8 requests; 4 -> 128 VGPRs, ~24; 2 -> all 32).
+template <typename T, int PT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fwd_d32_kernel(const KArgs a) {
+  constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
+  static_assert(PT == 4 || PT == 8, "PT");
+  const int lig = threadIdx.x & 7;
+  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  long nq; int m;
+  map_group(G, a, nq, m);
+  const bool active = nq < a.NQ;
+  if (!active) nq = a.NQ - 1;       // whole groups stay alive for the swizzles; nothing is stored
+  const int L = a.L;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
+  const long row = nq * a.M + m;
+  const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
+  // byte offset of value[n, 0, m, 0]; the tensor is < 2 GiB (checked by the host side)
+  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
+  const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  // lane j of the group owns point j of every level (lanes >= PT own nothing)
+  const bool owner = lig < PT;
+  const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * PT + (owner ? lig : 0);
+  const float *__restrict__ ap = a.attn + row * L * PT + (owner ? lig : 0);
+  const float live = (active && owner) ? 1.f : 0.f;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float2 xy = lp[0];
+  float aw = ap[0];
+  for (int l = 0; l < L; ++l) {
+    const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+    const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+    const uint32_t dyb = static_cast<uint32_t>(W) * pix_bytes;
+    const PointParams p = point_params(xy.x, xy.y, aw * live, H, W, head_base + lbytes, pix_bytes);
+    if (l + 1 < L) {                // next level's locations travel under this level's taps
+      xy = lp[(l + 1) * PT];
+      aw = ap[(l + 1) * PT];
+    }
+    sample_points<0, PT, T>(p, rsrc, lane_term, pix_bytes, dyb, acc);
+  }
+  if (active) {
+    T *op = static_cast<T *>(a.out) + row * D + lig * 4;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      uint2 t;
+      t.x = f32_to_bf16(acc[0]) | (f32_to_bf16(acc[1]) << 16);
+      t.y = f32_to_bf16(acc[2]) | (f32_to_bf16(acc[3]) << 16);
+      *reinterpret_cast<uint2 *>(op) = t;
+    }
+  }
+}
+
+}  // namespace bevmsda

@@ -47,6 +47,8 @@ struct KArgs {
   int xcd_remap;  // 0/1
   int nblocks;    // logical blocks
   int variant;    // 0 default, 1 generic lane-group kernels only, 2 scalar fallback
+  int mshift;     // log2(M) when M is a power of two, else -1
+  int qshift;     // log2(qtile) when qtile is a power of two, else -1
 };
 
 typedef uint16_t bf16_t;
@@ -120,6 +122,13 @@ __device__ __forceinline__ int logical_block(const KArgs &a) {
 
 // lane-group index -> (n*Q+q, m)
 __device__ __forceinline__ void map_group(long G, const KArgs &a, long &nq, int &m) {
+  if (a.mshift >= 0 && a.qshift >= 0) {  // shifts instead of 64-bit divisions
+    const long tile = G >> (a.mshift + a.qshift);
+    const int r = static_cast<int>(G & ((1L << (a.mshift + a.qshift)) - 1));
+    m = r >> a.qshift;
+    nq = (tile << a.qshift) + (r & ((1 << a.qshift) - 1));
+    return;
+  }
   if (a.qtile <= 1) {
     nq = G / a.M;
     m = static_cast<int>(G - nq * a.M);

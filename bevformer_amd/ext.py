@@ -75,6 +75,8 @@ def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                 rc = lib.bevmsda_forward_f32_ex(*args, tuning)
             else:
                 rc = lib.bevmsda_forward_f32(*args)
+        elif tuning is not None:
+            rc = lib.bevmsda_forward_bf16_ex(*args, tuning)
         else:
             rc = lib.bevmsda_forward_bf16(*args)
     _lib.check(rc, "ms_deform_attn_forward")
@@ -114,6 +116,8 @@ def ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index
                 rc = lib.bevmsda_backward_f32_ex(*args, tuning)
             else:
                 rc = lib.bevmsda_backward_f32(*args)
+        elif tuning is not None:
+            rc = lib.bevmsda_backward_bf16_ex(*args, tuning)
         else:
             rc = lib.bevmsda_backward_bf16(*args)
     _lib.check(rc, "ms_deform_attn_backward")

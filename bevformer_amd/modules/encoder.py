@@ -58,6 +58,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         self.fp16_enabled = False
         self._plan_cache = {}
         self.plan_cache_size = 4
+        self.sca_row_order = "raster"   # or "image": see geometry.build_sca_rows
         self.bev_tiling = None          # set by bev_tiling.enable_bev_tiling()
 
     # kept as static/instance methods with the reference's names and outputs
@@ -69,11 +70,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
 
     def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype):
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
-                                img_metas, device, dtype)
+                                img_metas, device, dtype) + (self.sca_row_order,)
         plan = self._plan_cache.get(key)
         if plan is None:
             plan = geometry.build_frame_plan(bev_h, bev_w, bs, self.pc_range,
-                                             self.num_points_in_pillar, img_metas, device, dtype)
+                                             self.num_points_in_pillar, img_metas, device, dtype,
+                                             row_order=self.sca_row_order)
             if len(self._plan_cache) >= self.plan_cache_size:
                 self._plan_cache.pop(next(iter(self._plan_cache)))
             self._plan_cache[key] = plan

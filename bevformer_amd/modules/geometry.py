@@ -93,16 +93,47 @@ class FramePlan:
     level_shapes_host: Optional[list] = None
 
 
-def build_sca_rows(reference_points_cam, bev_mask, sort_rows=False):
+def _morton_key(u, v, bits=7):
+    """Interleave the top ``bits`` bits of u, v in [0, 1) -> int64 Z-order key."""
+    n = 1 << bits
+    ui = (u.clamp(0.0, 1.0) * (n - 1)).long()
+    vi = (v.clamp(0.0, 1.0) * (n - 1)).long()
+    key = torch.zeros_like(ui)
+    for b in range(bits):
+        key |= ((ui >> b) & 1) << (2 * b)
+        key |= ((vi >> b) & 1) << (2 * b + 1)
+    return key
+
+
+ROW_ORDERS = ("raster", "image")
+
+
+def build_sca_rows(reference_points_cam, bev_mask, row_order="raster"):
     """Ragged equivalent of spatial_cross_attention.py:136-153.
 
     Literal to the reference for bs > 1: the visible set of camera i is taken
     from batch element 0 and reused for every batch element; the camera count
-    uses each element's own mask."""
+    uses each element's own mask.
+
+    ``row_order`` only permutes the rows inside a camera (results are
+    unchanged: every row is scattered back through ``row_query``):
+      * ``raster``: BEV raster order, as the reference's ``nonzero()`` yields;
+      * ``image``:  Z-order of the projected pillar in the camera image, so that
+        rows processed together sample neighbouring feature pixels."""
+    assert row_order in ROW_ORDERS
     Nc, B, Q, D = bev_mask.shape
     vis0 = bev_mask[:, 0].any(-1)                                        # (Nc,Q)
     cam, q = vis0.nonzero(as_tuple=True)                                 # sorted by cam, then q (sync)
     hits = torch.bincount(cam, minlength=Nc).tolist()
+    if row_order == "image" and cam.numel():
+        m = bev_mask[cam, 0, q].float()                                  # (R0,D)
+        uv = reference_points_cam[cam, 0, q]                             # (R0,D,2)
+        cnt = m.sum(-1).clamp(min=1.0)
+        u = (uv[..., 0] * m).sum(-1) / cnt
+        v = (uv[..., 1] * m).sum(-1) / cnt
+        key = cam.long() * (1 << 14) + _morton_key(u, v)
+        perm = torch.argsort(key, stable=True)
+        cam, q = cam[perm], q[perm]
     rows_q, rows_b, rows_ref = [], [], []
     for j in range(B):
         rows_q.append(j * Q + q)
@@ -115,7 +146,7 @@ def build_sca_rows(reference_points_cam, bev_mask, sort_rows=False):
 
 
 def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas, device,
-                     dtype=torch.float32):
+                     dtype=torch.float32, row_order="raster"):
     ref_3d = get_reference_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar,
                                   dim="3d", bs=bs, device=device, dtype=dtype)
     ref_2d = get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device=device, dtype=dtype)
@@ -125,7 +156,7 @@ def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas
                      bev_shapes=torch.tensor([[bev_h, bev_w]], device=device),
                      bev_start=torch.zeros(1, dtype=torch.long, device=device))
     (plan.row_query, plan.row_batch, plan.row_ref, plan.inv_count, plan.hits) = \
-        build_sca_rows(ref_cam, bev_mask)
+        build_sca_rows(ref_cam, bev_mask, row_order)
     return plan
 
 

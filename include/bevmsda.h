@@ -46,7 +46,8 @@ enum {
 
 /* Optional launch tuning (benchmark sweeps).  Zero-initialise for defaults. */
 typedef struct bevmsda_tuning {
-  int32_t variant;   /* 0 = library default; otherwise a kernel id, see DESIGN.md */
+  int32_t variant;   /* 0 = library default; 1 = generic lane-group kernels; 2 = one lane per
+                        channel; 3/4/5 = D=32 forward sized for 4/8/2 waves per SIMD */
   int32_t qtile;     /* 0 = default; queries of one head handled by adjacent lane groups */
   int32_t xcd_remap; /* 0 = default, 1 = off, 2 = on: contiguous row ranges per XCD */
   int32_t reserved[5];
@@ -120,6 +121,15 @@ int bevmsda_backward_f32_ex(const float *value, const int64_t *spatial_shapes,
                             const float *grad_out, int N, int S, int M, int D, int L, int Q,
                             int P, float *grad_value, float *grad_loc, float *grad_attn,
                             void *stream, const bevmsda_tuning *tuning);
+int bevmsda_forward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start, const float *loc, const float *attn,
+                            int N, int S, int M, int D, int L, int Q, int P, uint16_t *out,
+                            void *stream, const bevmsda_tuning *tuning);
+int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes,
+                             const int64_t *level_start, const float *loc, const float *attn,
+                             const uint16_t *grad_out, int N, int S, int M, int D, int L, int Q,
+                             int P, float *grad_value, float *grad_loc, float *grad_attn,
+                             void *stream, const bevmsda_tuning *tuning);
 
 #ifdef __cplusplus
 }

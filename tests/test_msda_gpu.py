@@ -91,7 +91,8 @@ def test_forward_backward_bf16(case):
 
 
 @pytest.mark.parametrize("qtile,xcd,variant", [(1, 1, 0), (1, 2, 0), (8, 1, 0), (32, 2, 0),
-                                               (128, 2, 0), (8, 2, 2)])
+                                               (128, 2, 0), (8, 2, 2), (8, 2, 1), (1, 2, 1),
+                                               (8, 2, 3), (1, 1, 4), (32, 2, 5), (3, 2, 3)])
 def test_launch_tunings_agree(qtile, xcd, variant):
     value, sh, start, loc, attn = make_msda_case(3, 77, 8, 32, [(9, 11), (4, 6)], 8, seed=4)
     want = msda_c.forward(value, sh, start, loc, attn)

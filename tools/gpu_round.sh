@@ -12,5 +12,5 @@ nproc > "$out/nproc.txt"
 timeout 900 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
 timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"
 timeout 300 python tools/kbench.py --quick > "$out/kbench.log" 2>&1
-timeout 900 tools/prof.sh "$tag" python bench.py --no-cpu-baseline --steps 5 --warmup 2 > "$out/prof_summary.txt" 2>&1
+timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 5 --warmup 2 > "$out/prof_summary.txt" 2>&1
 tail -3 "$out/pytest_gpu.log"; cat "$out/bench.json"; tail -5 "$out/kbench.log"

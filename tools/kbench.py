@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--workload", default="base")
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--sort", action="store_true", help="add the image-ordered SCA case")
+    ap.add_argument("--sweep", action="store_true", help="forward variants x qtile")
+    ap.add_argument("--no-bwd", action="store_true")
     args = ap.parse_args()
     results = []
     cases = {}
@@ -61,7 +64,26 @@ def main():
         cases["sca_const"] = (v, sh, st, torch.full_like(loc, 0.5), attn)
         cases["sca_rand"] = (v, sh, st, torch.rand(loc.shape, generator=g), attn)
         cases["sca_oob"] = (v, sh, st, torch.full_like(loc, 3.0), attn)
-    tunings = [(0, 0, 0)] if args.quick else [(1, 2, 0), (8, 2, 0), (32, 2, 0), (1, 2, 2)]
+    if args.sort:
+        # rows of every camera re-ordered along a Z-curve of the projected pillar (the
+        # encoder's sca_row_order="image"); padded rows stay at the end
+        from bevformer_amd.modules.geometry import _morton_key
+        v, sh, st, loc, attn = cases["sca"]
+        loc_s, attn_s = loc.clone(), attn.clone()
+        # pillar position ~ mean sampling location of head 0 / level 0 (offsets are small)
+        ctr = loc[:, :, :, 0].mean(dim=(2, 3))                      # (Nc, Q, 2)
+        for i, h in enumerate(hits):
+            key = _morton_key(ctr[i, :h, 0], ctr[i, :h, 1])
+            perm = torch.argsort(key, stable=True)
+            loc_s[i, :h] = loc[i, :h][perm]
+            attn_s[i, :h] = attn[i, :h][perm]
+        cases["sca_sorted"] = (v, sh, st, loc_s, attn_s)
+    if args.quick:
+        tunings = [(0, 0, 0)]
+    elif args.sweep:
+        tunings = [(q, 2, var) for var in (1, 4, 3, 5) for q in (1, 8, 32)]
+    else:
+        tunings = [(8, 2, 1), (8, 2, 4), (8, 2, 3), (8, 2, 5)]
     for name, (v, sh, st, loc, attn) in cases.items():
         if args.only and name not in args.only.split(","):
             continue
@@ -72,16 +94,18 @@ def main():
             gv = torch.zeros(vd.shape, device=DEV)
             gl = torch.empty_like(locd)
             ga = torch.empty_like(attnd)
-            for qtile, xcd, variant in (tunings if dtype == torch.float32 else [(0, 0, 0)]):
+            bwd_done = False
+            for qtile, xcd, variant in tunings:
                 t = _lib.Tuning(variant=variant, qtile=qtile, xcd_remap=xcd)
-                tp = ctypes.byref(t) if dtype == torch.float32 else None
+                tp = ctypes.byref(t)
                 f_med, f_min = timeit(lambda: ext.ms_deform_attn_forward(vd, shd, std, locd, attnd, tuning=tp), args.iters)
-                b_med, b_min = timeit(lambda: ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga, tuning=tp), args.iters)
                 bf, bb = alg_bytes_fwd(vd, locd, attnd, out), alg_bytes_bwd(vd, locd, attnd, g)
                 r = dict(op=name, dtype=str(dtype).split(".")[-1], shape=list(locd.shape), qtile=qtile, xcd=xcd, variant=variant,
-                         fwd_us=f_med * 1e6, fwd_min_us=f_min * 1e6, fwd_alg_GBs=bf / f_med / 1e9,
-                         bwd_us=b_med * 1e6, bwd_min_us=b_min * 1e6, bwd_alg_GBs=bb / b_med / 1e9,
-                         fwd_alg_MB=bf / 1e6, bwd_alg_MB=bb / 1e6)
+                         fwd_us=f_med * 1e6, fwd_min_us=f_min * 1e6, fwd_alg_GBs=bf / f_med / 1e9, fwd_alg_MB=bf / 1e6)
+                if not bwd_done and not args.no_bwd:      # backward kernels do not depend on the forward variant
+                    b_med, b_min = timeit(lambda: ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga, tuning=tp), max(3, args.iters // 4))
+                    r.update(bwd_us=b_med * 1e6, bwd_min_us=b_min * 1e6, bwd_alg_GBs=bb / b_med / 1e9, bwd_alg_MB=bb / 1e6)
+                    bwd_done = True
                 print(json.dumps(r), flush=True)
                 results.append(r)
     # practical bandwidth ceiling: device copy of 1 GiB
