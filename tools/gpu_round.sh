@@ -1,16 +1,24 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, bench line, rocprof summaries, operator sweep.
-# usage (from the repo root on the GPU box): tools/gpu_round.sh <tag>
+# One GPU-box visit: parity tests, operator sweep, probes, bench line, rocprof summaries.
+# usage (from the repo root on the GPU box): tools/gpu_round.sh <tag> [steps...]
 set -u
-tag=${1:-r1}
+tag=${1:-r1}; shift || true
+steps=${*:-"pytest kbench probe bench prof"}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd "$root"
-rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock|gfx" | head -12 > "$out/rocminfo.txt"
 nproc > "$out/nproc.txt"
-timeout 900 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
-timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"
-timeout 300 python tools/kbench.py --quick > "$out/kbench.log" 2>&1
-timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 5 --warmup 2 > "$out/prof_summary.txt" 2>&1
-tail -3 "$out/pytest_gpu.log"; cat "$out/bench.json"; tail -5 "$out/kbench.log"
+for s in $steps; do
+  case $s in
+    pytest) timeout 600 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"; tail -4 "$out/pytest_gpu.log";;
+    kbench) timeout 400 python tools/kbench.py --sweep --sort --iters 10 > "$out/kbench.log" 2>&1; cp gpurun_out/kbench.json "$out/kbench.json" 2>/dev/null; tail -3 "$out/kbench.log";;
+    kquick) timeout 300 python tools/kbench.py --iters 10 > "$out/kbench.log" 2>&1; tail -12 "$out/kbench.log";;
+    probe) (cd tools/probes && hipcc --offload-arch=gfx950 -O3 -o atomic_probe atomic_probe.hip 2>/dev/null && timeout 120 ./atomic_probe) > "$out/atomic_probe.log" 2>&1; tail -16 "$out/atomic_probe.log";;
+    bench) timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"; cat "$out/bench.json";;
+    bench_image) timeout 300 python bench.py --no-cpu-baseline --row-order image > "$out/bench_image.json" 2> "$out/bench_image.err"; cat "$out/bench_image.json";;
+    bench_raster) timeout 300 python bench.py --no-cpu-baseline --row-order raster > "$out/bench_raster.json" 2> "$out/bench_raster.err"; cat "$out/bench_raster.json";;
+    prof) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; tail -5 "$out/prof_summary.txt";;
+    trace) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -30 "$out/prof_summary.txt";;
+  esac
+done
