@@ -21,6 +21,19 @@ class Tuning(ctypes.Structure):
                 ("xcd_remap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
+class FusedDesc(ctypes.Structure):
+    """Mirror of ``struct bevmsda_fused_desc``."""
+    _fields_ = [("R", ctypes.c_int64), ("proj_row", ctypes.c_int64),
+                ("N", ctypes.c_int32), ("S", ctypes.c_int32), ("M", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("L", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("Q", ctypes.c_int32), ("K", ctypes.c_int32), ("A", ctypes.c_int32),
+                ("ref_mode", ctypes.c_int32), ("off_head", ctypes.c_int32),
+                ("off_k", ctypes.c_int32), ("lg_head", ctypes.c_int32), ("lg_k", ctypes.c_int32),
+                ("vmul", ctypes.c_int32), ("vadd", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 6)]
+
+
+ERR_UNSUPPORTED = -7
 _DIMS = [_c_int] * 7
 # name -> argtypes; every symbol the header declares is listed (tests check it)
 SIGNATURES = {
@@ -38,6 +51,10 @@ SIGNATURES = {
                                                             ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4
                                 + [ctypes.POINTER(Tuning)], _c_int),
+    "bevmsda_fused_forward_f32": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+                                  _c_int),
+    "bevmsda_fused_forward_bf16": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+                                   _c_int),
     "bevmsda_forward_bf16_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                              ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_bf16_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4

@@ -217,6 +217,51 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
 }
 
+template <typename T>
+int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
+               const float *logits, const float *ref, const int32_t *row_batch,
+               const bevmsda_fused_desc *d, T *out, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->R < 0 || d->N < 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->P < 0 || d->Q < 0 || d->K < 0 ||
+      d->A <= 0)
+    return BEVMSDA_ERR_BAD_SHAPE;
+  const unsigned long long bytes = 1ULL * d->N * d->S * d->M * d->D * sizeof(T);
+  if (d->D != 32 || !(d->P == 4 || d->P == 8) || !(d->L == 1 || d->L == 4) || !(d->K == 1 || d->K == 2) ||
+      bytes >= (1ULL << 31) || (d->proj_row & 1) || (d->off_head & 1) || (d->off_k & 1) ||
+      (d->ref_mode != 0 && d->ref_mode != 1) || (d->ref_mode == 1 && d->A != d->L))
+    return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->R == 0) return BEVMSDA_OK;
+  if (!value || !shapes || !lstart || !offs || !logits || !ref || !out) return BEVMSDA_ERR_NULL_POINTER;
+  if (!row_batch && d->Q <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(value) || misaligned(out) || (reinterpret_cast<uintptr_t>(offs) & 7u) ||
+      (reinterpret_cast<uintptr_t>(ref) & 7u) || (reinterpret_cast<uintptr_t>(logits) & 3u))
+    return BEVMSDA_ERR_MISALIGNED;
+  if (d->R * static_cast<long long>(d->M) >= (1LL << 36)) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::FusedArgs f{};
+  KArgs &a = f.k;
+  a.value = value; a.shapes = shapes; a.lstart = lstart; a.out = out; a.row_batch = row_batch;
+  a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = d->Q > 0 ? d->Q : 1; a.P = d->P;
+  a.qtile = kDefaultQtileFwd; a.xcd_remap = 1;
+  a.mshift = ilog2_exact(a.M); a.qshift = ilog2_exact(a.qtile);
+  f.offs = offs; f.logits = logits; f.ref = ref; f.proj_row = d->proj_row;
+  f.off_head = d->off_head; f.off_k = d->off_k; f.lg_head = d->lg_head; f.lg_k = d->lg_k;
+  f.K = d->K; f.A = d->A; f.ref_mode = d->ref_mode; f.vmul = d->vmul; f.vadd = d->vadd;
+  f.out_scale = 1.0f / static_cast<float>(d->K);
+  const long tiles = (a.NQ + a.qtile - 1) / a.qtile;
+  const long nb = (tiles * a.qtile * a.M + 31) / 32;
+  if (nb >= (1LL << 31) - 8) return BEVMSDA_ERR_TOO_LARGE;
+  a.nblocks = static_cast<int>(nb);
+  const dim3 grid(static_cast<unsigned>(((nb + 7) / 8) * 8));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // register budget: 4 waves/SIMD for the 4-level call (SCA), 8 for the 1-level call (TSA)
+  // (tools/kbench.py sweep, profiles/r1)
+  if (d->P == 8 && d->L == 4) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 4, 4>), grid, dim3(256), 0, st, f);
+  else if (d->P == 8) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 8>), grid, dim3(256), 0, st, f);
+  else if (d->L == 4) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 4, 4>), grid, dim3(256), 0, st, f);
+  else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 8>), grid, dim3(256), 0, st, f);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,6 +277,7 @@ const char *bevmsda_error_string(int code) {
     case BEVMSDA_ERR_MISALIGNED: return "pointer not 16-byte aligned";
     case BEVMSDA_ERR_LAUNCH: return "kernel launch failed";
     case BEVMSDA_ERR_BAD_OPTION: return "bad tuning option";
+    case BEVMSDA_ERR_UNSUPPORTED: return "shape not supported by the fused entry point";
     default: return "unknown error";
   }
 }
@@ -324,6 +370,20 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
   if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
                                grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R);
+}
+
+int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                              const float *offs, const float *logits, const float *ref,
+                              const int32_t *row_batch, const bevmsda_fused_desc *desc, float *out,
+                              void *stream) {
+  return fused_impl<float>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, desc, out, stream);
+}
+
+int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *offs, const float *logits, const float *ref,
+                               const int32_t *row_batch, const bevmsda_fused_desc *desc, uint16_t *out,
+                               void *stream) {
+  return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, desc, out, stream);
 }
 
 }  // extern "C"

@@ -83,11 +83,11 @@ __device__ __forceinline__ PointParams point_params(float lx, float ly, float aw
   const float fx = x - xf, fy = y - yf;
   const float gx = 1.f - fx, gy = 1.f - fy;
   const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W, y0ok = y0 >= 0, y1ok = y0 + 1 < H;
-  const float a = inside ? aw : 0.f;
-  p.k00 = (y0ok && x0ok) ? gy * gx * a : 0.f;
-  p.k01 = (y0ok && x1ok) ? gy * fx * a : 0.f;
-  p.k10 = (y1ok && x0ok) ? fy * gx * a : 0.f;
-  p.k11 = (y1ok && x1ok) ? fy * fx * a : 0.f;
+  // `inside` is false for NaN coordinates too: every coefficient is then an exact 0
+  p.k00 = (inside && y0ok && x0ok) ? gy * gx * aw : 0.f;
+  p.k01 = (inside && y0ok && x1ok) ? gy * fx * aw : 0.f;
+  p.k10 = (inside && y1ok && x0ok) ? fy * gx * aw : 0.f;
+  p.k11 = (inside && y1ok && x1ok) ? fy * fx * aw : 0.f;
   // y0*W + x0 >= -(W+1): two's-complement wrap keeps the sum right whenever the tap
   // itself is in range; otherwise the coefficient is 0 or the load is out of range
   const uint32_t o = level_base + static_cast<uint32_t>(y0 * W + x0) * pix_bytes;
@@ -163,7 +163,7 @@ msda_fwd_d32_kernel(const KArgs a) {
   const bool owner = lig < PT;
   const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * PT + (owner ? lig : 0);
   const float *__restrict__ ap = a.attn + row * L * PT + (owner ? lig : 0);
-  const float live = (active && owner) ? 1.f : 0.f;
+  const bool live = active && owner;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float2 xy = lp[0];
@@ -172,7 +172,7 @@ msda_fwd_d32_kernel(const KArgs a) {
     const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
     const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
     const uint32_t dyb = static_cast<uint32_t>(W) * pix_bytes;
-    const PointParams p = point_params(xy.x, xy.y, aw * live, H, W, head_base + lbytes, pix_bytes);
+    const PointParams p = point_params(xy.x, xy.y, live ? aw : 0.f, H, W, head_base + lbytes, pix_bytes);
     if (l + 1 < L) {                // next level's locations travel under this level's taps
       xy = lp[(l + 1) * PT];
       aw = ap[(l + 1) * PT];
@@ -187,6 +187,133 @@ msda_fwd_d32_kernel(const KArgs a) {
       uint2 t;
       t.x = f32_to_bf16(acc[0]) | (f32_to_bf16(acc[1]) << 16);
       t.y = f32_to_bf16(acc[2]) | (f32_to_bf16(acc[3]) << 16);
+      *reinterpret_cast<uint2 *>(op) = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fused front end
+// The modules feed the operator with softmax(attention logits) and with
+// reference point + offset / (W_l, H_l) (spatial_cross_attention.py:340-372,
+// temporal_self_attention.py:209-229).  In the reference those are separate
+// elementwise launches over (rows, M, L, P[, 2]) tensors; measured here they cost as
+// much as the sampling itself (profiles/r1).  This kernel takes the RAW projection
+// output instead (one row of the merged [offsets | logits] GEMM per query row) and does
+// the softmax (lane j owns point j: 1 exp per level, 8-lane butterflies for max / sum)
+// and the location arithmetic in its prologue; with K = 2 it also averages the two
+// BEV-queue entries of TemporalSelfAttention (temporal_self_attention.py:257-262).
+struct FusedArgs {
+  KArgs k;              // value, shapes, lstart, out, row_batch, NQ = output rows R, N, S, M, L, Q, P, launch fields
+  const float *offs;    // sampling-offset projections: offs[r*proj_row + m*off_head + q*off_k + (l*P + p)*2 + c]
+  const float *logits;  // attention logits:            logits[r*proj_row + m*lg_head + q*lg_k + l*P + p]
+  const float *ref;     // reference points (R, K, A, 2), normalised (x, y)
+  long proj_row;        // row stride (floats) of offs / logits
+  int off_head, off_k, lg_head, lg_k;
+  int K;                // queue entries averaged into one output row (1 or 2)
+  int A;                // reference points per (row, queue entry)
+  int ref_mode;         // 0: point p uses anchor p % A (pillar anchors); 1: level l uses ref l
+  int vmul, vadd;       // value batch entry of (row, q) = base * vmul + q * vadd, base = row_batch[r] or r / Q
+  float out_scale;      // 1 / K
+};
+
+template <int X>
+__device__ __forceinline__ float xor8(float v) {   // lane ^ X inside the 8-lane group
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (X << 10) | 0x1f));
+}
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, xor8<1>(v)); v = fmaxf(v, xor8<2>(v)); v = fmaxf(v, xor8<4>(v));
+  return v;
+}
+__device__ __forceinline__ float group8_sum(float v) {
+  v += xor8<1>(v); v += xor8<2>(v); v += xor8<4>(v);
+  return v;
+}
+
+template <typename T, int PT, int LT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_kernel(const FusedArgs f) {
+  constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
+  static_assert(PT == 4 || PT == 8, "PT");
+  static_assert(LT >= 1 && LT <= 4, "LT");
+  const KArgs &a = f.k;
+  const int lig = threadIdx.x & 7;
+  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  long r; int m;
+  map_group(G, a, r, m);
+  const bool active = r < a.NQ;
+  if (!active) r = a.NQ - 1;
+  const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
+  const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
+  const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  const bool owner = lig < PT;
+  const bool live = active && owner;
+  const int pj = owner ? lig : 0;
+
+  int Hs[LT], Ws[LT];
+  uint32_t lb[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    Hs[l] = static_cast<int>(a.shapes[2 * l]);
+    Ws[l] = static_cast<int>(a.shapes[2 * l + 1]);
+    lb[l] = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+  }
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < f.K; ++q) {
+    const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
+    const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
+    const float *__restrict__ lgp = f.logits + r * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
+    const float2 *__restrict__ ofp =
+        reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k) + pj;
+    const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
+
+    // this lane's logits / offsets of every level, and its reference point(s)
+    float lg[LT];
+    float2 of[LT], rf[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      lg[l] = lgp[l * PT];
+      of[l] = ofp[l * PT];
+      rf[l] = rfp[f.ref_mode == 0 ? (pj % f.A) : l];
+    }
+    // softmax over the L*P logits of (row, head, queue entry)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      if (!owner) lg[l] = -INFINITY;
+      mx = fmaxf(mx, lg[l]);
+    }
+    mx = group8_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      lg[l] = expf(lg[l] - mx);
+      sum += lg[l];
+    }
+    sum = group8_sum(sum);
+
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      const int H = Hs[l], W = Ws[l];
+      const float lx = rf[l].x + of[l].x / static_cast<float>(W);
+      const float ly = rf[l].y + of[l].y / static_cast<float>(H);
+      const float aw = lg[l] / sum;
+      const PointParams p = point_params(lx, ly, live ? aw : 0.f, H, W, head_base + lb[l], pix_bytes);
+      sample_points<0, PT, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
+    }
+  }
+  if (active) {
+    T *op = static_cast<T *>(a.out) + (r * a.M + m) * D + lig * 4;
+    const float sc = f.out_scale;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4 *>(op) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
+    } else {
+      uint2 t;
+      t.x = f32_to_bf16(acc[0] * sc) | (f32_to_bf16(acc[1] * sc) << 16);
+      t.y = f32_to_bf16(acc[2] * sc) | (f32_to_bf16(acc[3] * sc) << 16);
       *reinterpret_cast<uint2 *>(op) = t;
     }
   }

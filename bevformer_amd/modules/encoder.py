@@ -58,7 +58,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         self.fp16_enabled = False
         self._plan_cache = {}
         self.plan_cache_size = 4
-        self.sca_row_order = "raster"   # or "image": see geometry.build_sca_rows
+        self.sca_row_order = "image"    # or "raster": see geometry.build_sca_rows (measured: profiles/r1)
         self.bev_tiling = None          # set by bev_tiling.enable_bev_tiling()
 
     # kept as static/instance methods with the reference's names and outputs

@@ -74,8 +74,12 @@ class MSDeformableAttention3D(BaseModule):
         n_off = self.sampling_offsets.out_features
         w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = F.linear(query, w, b)
-        lead = query.shape[:-1]
+        return self._split_projection(F.linear(query, w, b))
+
+    def _split_projection(self, proj):
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        n_off = self.sampling_offsets.out_features
+        lead = proj.shape[:-1]
         off = proj[..., :n_off].reshape(*lead, M, L, P, 2)
         att = proj[..., n_off:].reshape(*lead, M, L * P).softmax(-1).view(*lead, M, L, P)
         return off, att
@@ -134,7 +138,21 @@ class MSDeformableAttention3D(BaseModule):
                        level_start_index):
         """query_rows (R, C); value (N, S, M, D) already projected; row_ref
         (R, Dz, 2); row_batch (R,) int32 -> (R, C)."""
-        off, att = self._project_queries(query_rows)
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        Dz = row_ref.shape[-2]
+        n_off = self.sampling_offsets.out_features
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        proj = F.linear(query_rows, w, b)
+        if P % Dz == 0 and row_ref.shape[-1] == 2 and ops.fused_wanted(proj, value):
+            # raw projection row -> softmax / locations / sampling in ONE kernel
+            out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
+                                 row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
+                                 off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
+                                 vmul=1, vadd=0, tag="sca_fwd")
+            if out is not None:
+                return out.to(query_rows.dtype)
+        off, att = self._split_projection(proj)
         loc = self._locations(off, row_ref, spatial_shapes)
         return ops.msda_ragged(value, spatial_shapes, level_start_index, loc.contiguous(),
                                att.contiguous(), row_batch, tag="sca_fwd")

@@ -84,6 +84,41 @@ class TemporalSelfAttention(BaseModule):
         xavier_uniform_(self.output_proj)
         self._is_init = True
 
+    def _sample_unfused(self, proj, n_off, v, reference_points, spatial_shapes, level_start_index,
+                        shared_value, bs, Q, C):
+        """softmax / location arithmetic as separate torch ops + the operator with
+        the reference's signature (the autograd path)."""
+        nq, M, L, P = self.num_bev_queue, self.num_heads, self.num_levels, self.num_points
+        off = proj[..., :n_off].reshape(bs, Q, M, nq, L, P, 2)
+        att = proj[..., n_off:].reshape(bs, Q, M, nq, L * P).softmax(-1)
+        att = att.view(bs, Q, M, nq, L, P).permute(0, 3, 1, 2, 4, 5).reshape(bs * nq, Q, M, L, P)
+        off = off.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * nq, Q, M, L, P, 2)
+
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            loc = reference_points[:, :, None, :, None, :] \
+                + off / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = reference_points[:, :, None, :, None, :2] \
+                + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, "
+                             f"but get {reference_points.shape[-1]} instead.")
+
+        if shared_value:
+            # queue entries b*2+0 and b*2+1 both sample projected batch entry b
+            row_batch = torch.arange(bs, device=proj.device, dtype=torch.int32) \
+                .repeat_interleave(nq * Q)
+            out = ops.msda_ragged(v, spatial_shapes, level_start_index,
+                                  loc.reshape(bs * nq * Q, M, L, P, 2),
+                                  att.reshape(bs * nq * Q, M, L, P), row_batch, tag="tsa_fwd")
+            out = out.view(bs * nq, Q, C)
+        else:
+            out = ops.msda(v, spatial_shapes, level_start_index, loc, att.contiguous(),
+                           self.im2col_step, tag="tsa_fwd")
+        # mean over the queue entries (temporal_self_attention.py:257-262)
+        return out.view(bs, nq, Q, C).mean(1)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, flag="decoder", bev_slice=None, **kwargs):
@@ -129,36 +164,22 @@ class TemporalSelfAttention(BaseModule):
         w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
         proj = F.linear(q2, w, b)
-        off = proj[..., :n_off].reshape(bs, Q, M, nq, L, P, 2)
-        att = proj[..., n_off:].reshape(bs, Q, M, nq, L * P).softmax(-1)
-        att = att.view(bs, Q, M, nq, L, P).permute(0, 3, 1, 2, 4, 5).reshape(bs * nq, Q, M, L, P)
-        off = off.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * nq, Q, M, L, P, 2)
-
-        if reference_points.shape[-1] == 2:
-            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
-            loc = reference_points[:, :, None, :, None, :] \
-                + off / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            loc = reference_points[:, :, None, :, None, :2] \
-                + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError(f"Last dim of reference_points must be 2 or 4, "
-                             f"but get {reference_points.shape[-1]} instead.")
-
-        if shared_value:
-            # queue entries b*2+0 and b*2+1 both sample projected batch entry b
-            row_batch = torch.arange(bs, device=query.device, dtype=torch.int32) \
-                .repeat_interleave(nq * Q)
-            out = ops.msda_ragged(v, spatial_shapes, level_start_index,
-                                  loc.reshape(bs * nq * Q, M, L, P, 2),
-                                  att.reshape(bs * nq * Q, M, L, P), row_batch, tag="tsa_fwd")
-            out = out.view(bs * nq, Q, C)
-        else:
-            out = ops.msda(v, spatial_shapes, level_start_index, loc, att.contiguous(),
-                           self.im2col_step, tag="tsa_fwd")
-
-        # mean over the queue entries (:257-262), then output projection
-        out = out.view(bs, nq, Q, C).mean(1)
+        out = None
+        if reference_points.shape[-1] == 2 and self.batch_first and key_padding_mask is None \
+                and ops.fused_wanted(proj, v):
+            # softmax, locations, sampling of both queue entries and their mean in ONE kernel
+            ref = reference_points.reshape(bs, nq, Q, L, 2).permute(0, 2, 1, 3, 4) \
+                .reshape(bs * Q, nq, L, 2)
+            out = ops.msda_fused(v, spatial_shapes, level_start_index, proj.view(bs * Q, -1), n_off,
+                                 ref, None, M=M, L=L, P=P, K=nq, off_head=nq * L * P * 2,
+                                 off_k=L * P * 2, lg_head=nq * L * P, lg_k=L * P, ref_mode=1,
+                                 vmul=1 if shared_value else nq, vadd=0 if shared_value else 1,
+                                 Q=Q, tag="tsa_fwd")
+            if out is not None:
+                out = out.to(query.dtype).view(bs, Q, C)
+        if out is None:
+            out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,
+                                       level_start_index, shared_value, bs, Q, C)
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)

@@ -141,3 +141,66 @@ def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, at
     (R,M,L,P); row_batch (R,) int32 in [0,N) -> (R, M*D)."""
     return _RaggedFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
                                  attention_weights, row_batch, tag)
+
+
+_FUSED = {"enabled": True}
+
+
+def set_fused_front_end(flag):
+    """Enable / disable the fused softmax + location + sampling kernel on the
+    no-grad path (on by default; the autograd path always uses the unfused
+    operator, whose backward kernels exist)."""
+    _FUSED["enabled"] = bool(flag)
+
+
+def fused_wanted(*tensors):
+    """The fused kernel is forward-only: use it when nothing asks for a gradient."""
+    return _FUSED["enabled"] and not (torch.is_grad_enabled()
+                                      and any(t is not None and t.requires_grad for t in tensors))
+
+
+def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
+               K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, tag="msda_fwd"):
+    """Sampling with the softmax / location prologue and the queue mean fused in
+    (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
+
+    value (N,S,M,32); proj (R, C_out) raw output of the merged projection GEMM
+    whose first ``n_off`` columns are sampling offsets and the rest attention
+    logits; ref (R,K,A,2); row_batch (R,) int32 or None.  Returns (R, M*32), or
+    ``None`` when the shape is not covered (caller falls back to the unfused path)."""
+    _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
+    store = _STORAGE["dtype"]
+    value = value.to(store)
+    _req(value.is_contiguous() and value.dim() == 4, "bevmsda: value must be contiguous (N,S,M,D)")
+    _req(proj.dtype == torch.float32 and proj.dim() == 2 and proj.stride(1) == 1,
+         "bevmsda: proj must be a float32 (R, C) matrix with unit column stride")
+    ref = ref.float().contiguous()
+    N, S, Mv, D = value.shape
+    R = proj.shape[0]
+    A = ref.shape[-2]
+    _req(Mv == M and ref.numel() == R * K * A * 2, "bevmsda: inconsistent fused operand shapes")
+    if row_batch is not None:
+        _req(row_batch.dtype == torch.int32 and row_batch.numel() == R and row_batch.is_contiguous(),
+             "bevmsda: row_batch must be a contiguous int32 (R,) tensor")
+    desc = _lib.FusedDesc(R=R, proj_row=proj.stride(0), N=N, S=S, M=M, D=D, L=L, P=P, Q=Q, K=K, A=A,
+                          ref_mode=ref_mode, off_head=off_head, off_k=off_k, lg_head=lg_head,
+                          lg_k=lg_k, vmul=vmul, vadd=vadd)
+    lib = _lib.load()
+    out = torch.empty((R, M * D), dtype=store, device=value.device)
+    fn = lib.bevmsda_fused_forward_f32 if store == torch.float32 else lib.bevmsda_fused_forward_bf16
+    logits = proj[:, n_off:]
+    import ctypes
+    with torch.cuda.device(value.device):
+        # algorithmic bytes: value + raw projection row (offsets 8 B + logit 4 B per point) + out
+        alg = value.numel() * value.element_size() + R * M * K * L * P * 12 \
+            + R * M * D * value.element_size()
+        cb = _TIMER["cb"]
+        ctx = cb(tag, alg) if cb is not None else _NoTimer()
+        with ctx:
+            rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
+                    logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
+                    ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "msda_fused forward")
+    return out

@@ -41,7 +41,8 @@ enum {
   BEVMSDA_ERR_TOO_LARGE = -3,    /* S*M*D or Q*M*L*P*2 does not fit int32     */
   BEVMSDA_ERR_MISALIGNED = -4,   /* pointer not 16-byte aligned               */
   BEVMSDA_ERR_LAUNCH = -5,       /* hipLaunchKernel failed (see hipGetLastError) */
-  BEVMSDA_ERR_BAD_OPTION = -6    /* unknown tuning value                      */
+  BEVMSDA_ERR_BAD_OPTION = -6,   /* unknown tuning value                      */
+  BEVMSDA_ERR_UNSUPPORTED = -7   /* shape not covered by this entry point: use the unfused one */
 };
 
 /* Optional launch tuning (benchmark sweeps).  Zero-initialise for defaults. */
@@ -130,6 +131,48 @@ int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shape
                              const uint16_t *grad_out, int N, int S, int M, int D, int L, int Q,
                              int P, float *grad_value, float *grad_loc, float *grad_attn,
                              void *stream, const bevmsda_tuning *tuning);
+
+/* Fused front end of the two attention modules (inference path).
+ *
+ * The reference computes, with separate elementwise launches per layer,
+ *     attention_weights = softmax(logits over L*P)          spatial_cross_attention.py:340-348
+ *                                                            temporal_self_attention.py:209-211
+ *     sampling_locations = reference + offsets / (W_l, H_l)  spatial_cross_attention.py:357-372
+ *                                                            temporal_self_attention.py:224-229
+ * and, in TemporalSelfAttention, the mean over the two BEV-queue entries after the
+ * operator (temporal_self_attention.py:257-262).  This entry point takes the raw
+ * projection outputs and does all of it inside the sampling kernel.
+ *
+ *   offs    sampling-offset projections, element (r, m, q, l, p, c) at
+ *           offs[r*proj_row + m*off_head + q*off_k + (l*P + p)*2 + c]
+ *   logits  attention logits, element (r, m, q, l, p) at
+ *           logits[r*proj_row + m*lg_head + q*lg_k + l*P + p]      (softmax over l, p)
+ *   ref     (R, K, A, 2) fp32 normalised reference points; ref_mode 0: point p uses
+ *           anchor p % A (the pillar anchors of MSDeformableAttention3D), ref_mode 1:
+ *           level l uses ref l (A = L)
+ *   row_batch  optional (R,) int32: value batch entry base of row r (else r / Q)
+ *   value batch entry of (row r, queue entry q) = base * vmul + q * vadd
+ *   out     (R, M*D) = (1/K) * sum_q sample(value[entry(r, q)], loc(r, q), softmax(r, q))
+ * Supported: D = 32, P in {4, 8}, L in {1, 4}, K in {1, 2}, value < 2 GiB; anything else
+ * returns BEVMSDA_ERR_UNSUPPORTED and the caller uses bevmsda_forward_*.  Forward only. */
+typedef struct bevmsda_fused_desc {
+  int64_t R;          /* output rows */
+  int64_t proj_row;   /* row stride of offs / logits, in floats (even) */
+  int32_t N, S, M, D, L, P, Q;
+  int32_t K, A, ref_mode;
+  int32_t off_head, off_k, lg_head, lg_k;
+  int32_t vmul, vadd;
+  int32_t reserved[6];
+} bevmsda_fused_desc;
+
+int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start, const float *offs, const float *logits,
+                              const float *ref, const int32_t *row_batch,
+                              const bevmsda_fused_desc *desc, float *out, void *stream);
+int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *offs,
+                               const float *logits, const float *ref, const int32_t *row_batch,
+                               const bevmsda_fused_desc *desc, uint16_t *out, void *stream);
 
 #ifdef __cplusplus
 }

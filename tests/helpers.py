@@ -22,18 +22,47 @@ def _oracle_msda_ragged(value, shapes, start, loc, attn, row_batch, tag=None):
     return out
 
 
+def _oracle_msda_fused(value, shapes, start, proj, n_off, ref, row_batch, *, M, L, P, K, off_head,
+                       off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, tag=None):
+    """CPU statement of the fused entry point's contract (include/bevmsda.h,
+    ``bevmsda_fused_forward_*``) out of torch ops + the oracle operator: what the
+    kernel must compute for a given descriptor."""
+    R = proj.shape[0]
+    D = value.shape[-1]
+    A = ref.shape[-2]
+    ref = ref.reshape(R, K, A, 2)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(proj.dtype)            # (L,2) = (W,H)
+    m = torch.arange(M)[:, None]
+    lp = torch.arange(L * P)[None, :]
+    base = row_batch.long() if row_batch is not None else torch.arange(R) // Q
+    out = value.new_zeros(R, M * D)
+    for k in range(K):
+        col_lg = n_off + m * lg_head + k * lg_k + lp                                 # (M, L*P)
+        att = proj[:, col_lg].softmax(-1).view(R, M, L, P)
+        col_off = (m * off_head + k * off_k + lp * 2)[..., None] + torch.arange(2)   # (M, L*P, 2)
+        off = proj[:, col_off].view(R, M, L, P, 2)
+        if ref_mode == 0:
+            rp = ref[:, k][:, torch.arange(P) % A]                                   # (R,P,2)
+            loc = rp[:, None, None, :, :] + off / norm[None, None, :, None, :]
+        else:
+            loc = ref[:, k][:, None, :, None, :] + off / norm[None, None, :, None, :]
+        n = (base * vmul + k * vadd).to(torch.int32)
+        out = out + _oracle_msda_ragged(value, shapes, start, loc, att, n)
+    return out / K
+
+
 @contextlib.contextmanager
 def oracle_ops():
     """Route the package's operator calls through the CPU oracle so that the
     HOST logic of the modules (ragged rows, merged GEMMs, geometry, plans,
     tiling) can be parity-tested without a GPU.  Test-only: the product path
     itself has no CPU implementation."""
-    saved = (ops.msda, ops.msda_ragged)
-    ops.msda, ops.msda_ragged = _oracle_msda, _oracle_msda_ragged
+    saved = (ops.msda, ops.msda_ragged, ops.msda_fused)
+    ops.msda, ops.msda_ragged, ops.msda_fused = _oracle_msda, _oracle_msda_ragged, _oracle_msda_fused
     try:
         yield
     finally:
-        ops.msda, ops.msda_ragged = saved
+        ops.msda, ops.msda_ragged, ops.msda_fused = saved
 
 
 def build_pair(name, seed=3, device="cpu"):

@@ -110,6 +110,7 @@ def test_image_row_order_is_a_pure_permutation(name):
     enc, _ = build_pair(name)
     q, f, kw = S.make_inputs(name, seed=0, temporal=True)
     with oracle_ops(), torch.no_grad():
+        enc.sca_row_order = "raster"
         want = enc(q, f, f, **kw)
         enc.sca_row_order = "image"
         got = enc(q, f, f, **kw)

@@ -21,6 +21,10 @@ from bevformer_amd.synthetic import make_msda_case, make_sca_msda_case, make_tsa
 from oracle import bevformer_cpu as O
 from oracle import msda_c
 
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -197,3 +201,53 @@ def test_base_size_properties(which):
     total = gv.double().sum().item()
     expect = out.shape[0] * out.shape[1] * out.shape[2]       # each output element spreads 1.0
     assert abs(total - expect) / expect < 1e-4
+
+
+# ----------------------------------------------------------------- fused front end
+def _fused_case(kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    M, D = 8, 32
+    if kind == "sca":                      # pillar anchors, ragged rows over 3 cameras
+        shapes = [(16, 26), (8, 13), (4, 7), (2, 4)]
+        L, P, K, A, N, R, Q = 4, 8, 1, 4, 3, 157, 0
+        desc = dict(off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0, vmul=1, vadd=0)
+        row_batch = torch.randint(0, N, (R,), generator=g, dtype=torch.int32).sort()[0]
+    else:                                  # two BEV-queue entries, averaged
+        shapes = [(12, 10)]
+        L, P, K, A, R, Q = 1, 4, 2, 1, 2 * 120, 120
+        shared = kind == "tsa_shared"
+        N = 2 if shared else 4
+        desc = dict(off_head=K * L * P * 2, off_k=L * P * 2, lg_head=K * L * P, lg_k=L * P,
+                    ref_mode=1, vmul=1 if shared else 2, vadd=0 if shared else 1)
+        row_batch = None
+    sh = torch.tensor(shapes, dtype=torch.long)
+    start = torch.cat([sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]])
+    S = int(sh.prod(1).sum())
+    value = torch.randn(N, S, M, D, generator=g)
+    n_off = M * K * L * P * 2
+    proj = torch.randn(R, n_off + M * K * L * P, generator=g)
+    proj[:, :n_off] *= 3.0                 # offsets of a few pixels
+    ref = torch.rand(R, K, A, 2, generator=g) * 1.2 - 0.1    # some anchors outside the image
+    return value, sh, start, proj, n_off, ref, row_batch, dict(M=M, L=L, P=P, K=K, Q=Q, **desc)
+
+
+@pytest.mark.parametrize("kind", ["sca", "tsa", "tsa_shared"])
+def test_fused_front_end_matches_unfused_oracle(kind):
+    from bevformer_amd import ops
+    from helpers import _oracle_msda_fused
+    value, sh, start, proj, n_off, ref, rb, kw = _fused_case(kind, seed=11)
+    want = _oracle_msda_fused(value, sh, start, proj, n_off, ref, rb, **kw)
+    got = ops.msda_fused(value.to(DEV), sh.to(DEV), start.to(DEV), proj.to(DEV), n_off, ref.to(DEV),
+                         rb.to(DEV) if rb is not None else None, **kw)
+    assert got is not None
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=2e-5)
+
+
+def test_fused_front_end_declines_unsupported_shapes():
+    from bevformer_amd import ops
+    value, sh, start, proj, n_off, ref, rb, kw = _fused_case("tsa", seed=3)
+    kw = dict(kw, P=2, off_head=2 * 1 * 2 * 2, off_k=1 * 2 * 2, lg_head=2 * 1 * 2, lg_k=1 * 2)
+    n_off2 = 8 * 2 * 1 * 2 * 2
+    got = ops.msda_fused(value.to(DEV), sh.to(DEV), start.to(DEV), proj.to(DEV), n_off2, ref.to(DEV),
+                         None, **kw)
+    assert got is None      # P = 2 is not covered: the caller must use the unfused operator
