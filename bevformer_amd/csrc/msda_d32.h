@@ -229,12 +229,11 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
-template <typename T, int PT, int LT, int WPE>
+template <typename T, int PT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_kernel(const FusedArgs f) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
   static_assert(PT == 4 || PT == 8, "PT");
-  static_assert(LT >= 1 && LT <= 4, "LT");
   const KArgs &a = f.k;
   const int lig = threadIdx.x & 7;
   const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
@@ -242,6 +241,7 @@ msda_fused_d32_kernel(const FusedArgs f) {
   map_group(G, a, r, m);
   const bool active = r < a.NQ;
   if (!active) r = a.NQ - 1;
+  const int L = a.L;
   const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
   const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
   const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
@@ -251,15 +251,7 @@ msda_fused_d32_kernel(const FusedArgs f) {
   const bool owner = lig < PT;
   const bool live = active && owner;
   const int pj = owner ? lig : 0;
-
-  int Hs[LT], Ws[LT];
-  uint32_t lb[LT];
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    Hs[l] = static_cast<int>(a.shapes[2 * l]);
-    Ws[l] = static_cast<int>(a.shapes[2 * l + 1]);
-    lb[l] = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
-  }
+  const int anchor = f.ref_mode == 0 ? pj % f.A : 0;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int q = 0; q < f.K; ++q) {
@@ -270,38 +262,32 @@ msda_fused_d32_kernel(const FusedArgs f) {
         reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k) + pj;
     const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
 
-    // this lane's logits / offsets of every level, and its reference point(s)
-    float lg[LT];
-    float2 of[LT], rf[LT];
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      lg[l] = lgp[l * PT];
-      of[l] = ofp[l * PT];
-      rf[l] = rfp[f.ref_mode == 0 ? (pj % f.A) : l];
-    }
-    // softmax over the L*P logits of (row, head, queue entry)
+    // softmax statistics over the L*P logits of (row, head, queue entry): lane j holds
+    // point j of every level, the group reduces with xor butterflies
     float mx = -INFINITY;
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      if (!owner) lg[l] = -INFINITY;
-      mx = fmaxf(mx, lg[l]);
-    }
+    for (int l = 0; l < L; ++l) mx = fmaxf(mx, owner ? lgp[l * PT] : -INFINITY);
     mx = group8_max(mx);
     float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      lg[l] = expf(lg[l] - mx);
-      sum += lg[l];
-    }
+    for (int l = 0; l < L; ++l) sum += owner ? expf(lgp[l * PT] - mx) : 0.f;
     sum = group8_sum(sum);
 
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      const int H = Hs[l], W = Ws[l];
-      const float lx = rf[l].x + of[l].x / static_cast<float>(W);
-      const float ly = rf[l].y + of[l].y / static_cast<float>(H);
-      const float aw = lg[l] / sum;
-      const PointParams p = point_params(lx, ly, live ? aw : 0.f, H, W, head_base + lb[l], pix_bytes);
+    // level loop, next level's record travelling under this level's taps (the logits
+    // are re-read from L1 instead of being kept in a register array)
+    float lg = lgp[0];
+    float2 of = ofp[0];
+    float2 rf = rfp[anchor];
+    for (int l = 0; l < L; ++l) {
+      const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+      const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+      const float lx = rf.x + of.x / static_cast<float>(W);
+      const float ly = rf.y + of.y / static_cast<float>(H);
+      const float aw = live ? expf(lg - mx) / sum : 0.f;
+      const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
+      if (l + 1 < L) {
+        lg = lgp[(l + 1) * PT];
+        of = ofp[(l + 1) * PT];
+        if (f.ref_mode == 1) rf = rfp[l + 1];
+      }
       sample_points<0, PT, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
     }
   }
