@@ -226,7 +226,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
       d->A <= 0)
     return BEVMSDA_ERR_BAD_SHAPE;
   const unsigned long long bytes = 1ULL * d->N * d->S * d->M * d->D * sizeof(T);
-  if (d->D != 32 || !(d->P == 4 || d->P == 8) || d->L < 1 || !(d->K == 1 || d->K == 2) ||
+  if (d->D != 32 || !(d->P == 4 || d->P == 8) || d->L < 1 || d->L > 4 || d->P * d->K > 8 || !(d->K == 1 || d->K == 2) ||
       bytes >= (1ULL << 31) || (d->proj_row & 1) || (d->off_head & 1) || (d->off_k & 1) ||
       (d->ref_mode != 0 && d->ref_mode != 1) || (d->ref_mode == 1 && d->A != d->L))
     return BEVMSDA_ERR_UNSUPPORTED;
@@ -255,10 +255,16 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   // register budget: 4 waves/SIMD for multi-level calls (SCA), 8 for the 1-level call (TSA)
   // (tools/kbench.py sweep, profiles/r1)
-  if (d->P == 8 && d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 4>), grid, dim3(256), 0, st, f);
-  else if (d->P == 8) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 8>), grid, dim3(256), 0, st, f);
-  else if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 4>), grid, dim3(256), 0, st, f);
-  else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 8>), grid, dim3(256), 0, st, f);
+  if (d->P == 8) {
+    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 8>), grid, dim3(256), 0, st, f);
+  } else if (d->K == 2) {
+    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 8>), grid, dim3(256), 0, st, f);
+  } else {
+    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 4>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 8>), grid, dim3(256), 0, st, f);
+  }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -217,23 +217,32 @@ struct FusedArgs {
 };
 
 template <int X>
-__device__ __forceinline__ float xor8(float v) {   // lane ^ X inside the 8-lane group
+__device__ __forceinline__ float xor8(float v) {   // value of lane ^ X (X < 8)
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (X << 10) | 0x1f));
 }
-__device__ __forceinline__ float group8_max(float v) {
-  v = fmaxf(v, xor8<1>(v)); v = fmaxf(v, xor8<2>(v)); v = fmaxf(v, xor8<4>(v));
+// reductions over the W (4 or 8) consecutive lanes that hold the points of one softmax
+template <int W>
+__device__ __forceinline__ float lanes_max(float v) {
+  v = fmaxf(v, xor8<1>(v)); v = fmaxf(v, xor8<2>(v));
+  if constexpr (W == 8) v = fmaxf(v, xor8<4>(v));
   return v;
 }
-__device__ __forceinline__ float group8_sum(float v) {
-  v += xor8<1>(v); v += xor8<2>(v); v += xor8<4>(v);
+template <int W>
+__device__ __forceinline__ float lanes_sum(float v) {
+  v += xor8<1>(v); v += xor8<2>(v);
+  if constexpr (W == 8) v += xor8<4>(v);
   return v;
 }
 
-template <typename T, int PT, int WPE>
+// PT points per level, KT queue entries; the PT*KT (<= 8) "virtual points" of a level are
+// owned by the lanes of the group: lane j -> queue entry j / PT, point j % PT.  With
+// KT = 2 (TemporalSelfAttention: PT = 4) both queue entries are sampled in the same
+// round and summed into the same accumulator (their mean is the output).
+template <typename T, int PT, int KT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_kernel(const FusedArgs f) {
-  constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
-  static_assert(PT == 4 || PT == 8, "PT");
+  constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
+  static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
   const int lig = threadIdx.x & 7;
   const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
@@ -241,55 +250,50 @@ msda_fused_d32_kernel(const FusedArgs f) {
   map_group(G, a, r, m);
   const bool active = r < a.NQ;
   if (!active) r = a.NQ - 1;
-  const int L = a.L;
+  const int L = a.L;                                    // 1..4 (host-checked)
   const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
   const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
   const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
   const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
                                                                   static_cast<int>(total_bytes), 0x00020000);
-  const bool owner = lig < PT;
+  const bool owner = lig < NP;
   const bool live = active && owner;
-  const int pj = owner ? lig : 0;
-  const int anchor = f.ref_mode == 0 ? pj % f.A : 0;
+  const int q = owner ? lig / PT : 0;                    // my queue entry
+  const int pj = owner ? lig % PT : 0;                   // my point
+  const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
+  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
+  const float *__restrict__ lgp = f.logits + r * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
+  const float2 *__restrict__ ofp =
+      reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k) + pj;
+  const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
+
+  // softmax over the L*PT logits of my (row, head, queue entry): ONE batch of loads (my
+  // point's logit of every level), one exp per level, butterflies over the PT lanes
+  float e0 = lgp[0];
+  float e1 = L > 1 ? lgp[PT] : -INFINITY;
+  float e2 = L > 2 ? lgp[2 * PT] : -INFINITY;
+  float e3 = L > 3 ? lgp[3 * PT] : -INFINITY;
+  float2 of = ofp[0];
+  float2 rf = rfp[f.ref_mode == 0 ? pj % f.A : 0];
+  const float mx = lanes_max<PT>(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
+  e0 = expf(e0 - mx); e1 = expf(e1 - mx); e2 = expf(e2 - mx); e3 = expf(e3 - mx);   // exp(-inf) = 0
+  const float sum = lanes_sum<PT>((e0 + e1) + (e2 + e3));
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int q = 0; q < f.K; ++q) {
-    const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
-    const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
-    const float *__restrict__ lgp = f.logits + r * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
-    const float2 *__restrict__ ofp =
-        reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k) + pj;
-    const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
-
-    // softmax statistics over the L*P logits of (row, head, queue entry): lane j holds
-    // point j of every level, the group reduces with xor butterflies
-    float mx = -INFINITY;
-    for (int l = 0; l < L; ++l) mx = fmaxf(mx, owner ? lgp[l * PT] : -INFINITY);
-    mx = group8_max(mx);
-    float sum = 0.f;
-    for (int l = 0; l < L; ++l) sum += owner ? expf(lgp[l * PT] - mx) : 0.f;
-    sum = group8_sum(sum);
-
-    // level loop, next level's record travelling under this level's taps (the logits
-    // are re-read from L1 instead of being kept in a register array)
-    float lg = lgp[0];
-    float2 of = ofp[0];
-    float2 rf = rfp[anchor];
-    for (int l = 0; l < L; ++l) {
-      const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
-      const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
-      const float lx = rf.x + of.x / static_cast<float>(W);
-      const float ly = rf.y + of.y / static_cast<float>(H);
-      const float aw = live ? expf(lg - mx) / sum : 0.f;
-      const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
-      if (l + 1 < L) {
-        lg = lgp[(l + 1) * PT];
-        of = ofp[(l + 1) * PT];
-        if (f.ref_mode == 1) rf = rfp[l + 1];
-      }
-      sample_points<0, PT, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
+  for (int l = 0; l < L; ++l) {
+    const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+    const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+    const float lx = rf.x + of.x / static_cast<float>(W);
+    const float ly = rf.y + of.y / static_cast<float>(H);
+    const float e = l == 0 ? e0 : (l == 1 ? e1 : (l == 2 ? e2 : e3));
+    const float aw = live ? e / sum : 0.f;
+    const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
+    if (l + 1 < L) {                // next level's record travels under this level's taps
+      of = ofp[(l + 1) * PT];
+      if (f.ref_mode == 1) rf = rfp[l + 1];
     }
+    sample_points<0, NP, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
   }
   if (active) {
     T *op = static_cast<T *>(a.out) + (r * a.M + m) * D + lig * 4;

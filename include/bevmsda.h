@@ -153,7 +153,7 @@ int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shape
  *   row_batch  optional (R,) int32: value batch entry base of row r (else r / Q)
  *   value batch entry of (row r, queue entry q) = base * vmul + q * vadd
  *   out     (R, M*D) = (1/K) * sum_q sample(value[entry(r, q)], loc(r, q), softmax(r, q))
- * Supported: D = 32, P in {4, 8}, L >= 1, K in {1, 2}, value < 2 GiB; anything else
+ * Supported: D = 32, P in {4, 8}, 1 <= L <= 4, K in {1, 2} with P*K <= 8, value < 2 GiB; anything else
  * returns BEVMSDA_ERR_UNSUPPORTED and the caller uses bevmsda_forward_*.  Forward only. */
 typedef struct bevmsda_fused_desc {
   int64_t R;          /* output rows */
