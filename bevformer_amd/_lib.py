@@ -51,10 +51,14 @@ SIGNATURES = {
                                                             ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4
                                 + [ctypes.POINTER(Tuning)], _c_int),
-    "bevmsda_fused_forward_f32": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+    "bevmsda_fused_forward_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                   _c_int),
-    "bevmsda_fused_forward_bf16": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+    "bevmsda_fused_forward_bf16": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                    _c_int),
+    "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,
+                                                     _c_void_p, _c_void_p], _c_int),
+    "bevmsda_gather_mean_f32": ([_c_void_p] * 3 + [ctypes.c_int64, _c_int, _c_int,
+                                                   _c_void_p, _c_void_p], _c_int),
     "bevmsda_forward_bf16_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                              ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_bf16_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4

@@ -3,6 +3,7 @@
 #include "../../include/bevmsda.h"
 #include "msda_kernels.h"
 #include "msda_d32.h"
+#include "rowops.h"
 
 namespace {
 
@@ -219,7 +220,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
 
 template <typename T>
 int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
-               const float *logits, const float *ref, const int32_t *row_batch,
+               const float *logits, const float *ref, const int32_t *row_batch, const int32_t *row_src,
                const bevmsda_fused_desc *d, T *out, void *stream) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->R < 0 || d->N < 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->P < 0 || d->Q < 0 || d->K < 0 ||
@@ -243,7 +244,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = d->Q > 0 ? d->Q : 1; a.P = d->P;
   a.qtile = kDefaultQtileFwd; a.xcd_remap = 1;
   a.mshift = ilog2_exact(a.M); a.qshift = ilog2_exact(a.qtile);
-  f.offs = offs; f.logits = logits; f.ref = ref; f.proj_row = d->proj_row;
+  f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
   f.off_head = d->off_head; f.off_k = d->off_k; f.lg_head = d->lg_head; f.lg_k = d->lg_k;
   f.K = d->K; f.A = d->A; f.ref_mode = d->ref_mode; f.vmul = d->vmul; f.vadd = d->vadd;
   f.out_scale = 1.0f / static_cast<float>(d->K);
@@ -380,16 +381,51 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *offs, const float *logits, const float *ref,
-                              const int32_t *row_batch, const bevmsda_fused_desc *desc, float *out,
-                              void *stream) {
-  return fused_impl<float>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, desc, out, stream);
+                              const int32_t *row_batch, const int32_t *row_src,
+                              const bevmsda_fused_desc *desc, float *out, void *stream) {
+  return fused_impl<float>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out,
+                           stream);
 }
 
 int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *offs, const float *logits, const float *ref,
-                               const int32_t *row_batch, const bevmsda_fused_desc *desc, uint16_t *out,
-                               void *stream) {
-  return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, desc, out, stream);
+                               const int32_t *row_batch, const int32_t *row_src,
+                               const bevmsda_fused_desc *desc, uint16_t *out, void *stream) {
+  return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out,
+                            stream);
+}
+
+int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,
+                              float eps, int64_t rows, int C, float *out, void *stream) {
+  if (rows < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C != 256 && C != 512 && C != 1024) return BEVMSDA_ERR_UNSUPPORTED;
+  if (rows == 0) return BEVMSDA_OK;
+  if (!x || !gamma || !beta || !out) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(x) || misaligned(out) || misaligned(gamma) || misaligned(beta) || (res && misaligned(res)))
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = (rows + 3) / 4;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const dim3 grid(static_cast<unsigned>(nb));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 256) hipLaunchKernelGGL((bevmsda::add_layernorm_kernel<1>), grid, dim3(256), 0, st, x, res, gamma, beta, eps, static_cast<long>(rows), out);
+  else if (C == 512) hipLaunchKernelGGL((bevmsda::add_layernorm_kernel<2>), grid, dim3(256), 0, st, x, res, gamma, beta, eps, static_cast<long>(rows), out);
+  else hipLaunchKernelGGL((bevmsda::add_layernorm_kernel<4>), grid, dim3(256), 0, st, x, res, gamma, beta, eps, static_cast<long>(rows), out);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *scale, int64_t Q, int J, int C,
+                            float *out, void *stream) {
+  if (Q < 0 || J < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (Q == 0) return BEVMSDA_OK;
+  if (!scale || !out || (J > 0 && (!rows || !idx))) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(out) || (rows && misaligned(rows))) return BEVMSDA_ERR_MISALIGNED;
+  const long long total = Q * static_cast<long long>(C / 4);
+  const long long nb = (total + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::gather_mean_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rows, idx, scale, static_cast<long>(Q), J, C, out);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
 }  // extern "C"

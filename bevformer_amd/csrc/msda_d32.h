@@ -207,6 +207,8 @@ struct FusedArgs {
   const float *offs;    // sampling-offset projections: offs[r*proj_row + m*off_head + q*off_k + (l*P + p)*2 + c]
   const float *logits;  // attention logits:            logits[r*proj_row + m*lg_head + q*lg_k + l*P + p]
   const float *ref;     // reference points (R, K, A, 2), normalised (x, y)
+  const int32_t *row_src;  // optional: projection row of output row r (else r) — SCA projects each
+                           // BEV query once and every camera that sees it reads the same row
   long proj_row;        // row stride (floats) of offs / logits
   int off_head, off_k, lg_head, lg_k;
   int K;                // queue entries averaged into one output row (1 or 2)
@@ -263,9 +265,10 @@ msda_fused_d32_kernel(const FusedArgs f) {
   const int pj = owner ? lig % PT : 0;                   // my point
   const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
   const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
-  const float *__restrict__ lgp = f.logits + r * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
+  const long rs = f.row_src ? static_cast<long>(f.row_src[r]) : r;
+  const float *__restrict__ lgp = f.logits + rs * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
   const float2 *__restrict__ ofp =
-      reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k) + pj;
+      reinterpret_cast<const float2 *>(f.offs + rs * f.proj_row + m * f.off_head + q * f.off_k) + pj;
   const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
 
   // softmax over the L*PT logits of my (row, head, queue entry): ONE batch of loads (my

@@ -1,0 +1,95 @@
+// Row-wise HBM-bound helpers of the encoder layer for CDNA4 (gfx950).
+//
+//   add_layernorm:  y = LayerNorm(x + res) * gamma + beta      the "attention/FFN output
+//       + identity, then norm" pair of every BEVFormerLayer step (encoder.py:360-404 run
+//       'self_attn','norm','cross_attn','norm','ffn','norm'); in the reference two
+//       launches that each stream the (Q, C) grid — here one pass: 2 reads + 1 write.
+//   gather_mean:    out[q] = scale[q] * sum_j rows[idx[q, j]]  the per-camera
+//       scatter-add + division of SpatialCrossAttention (spatial_cross_attention.py:165-172)
+//       turned into a gather over the <= J cameras that see query q (no atomics, no
+//       zero-fill of the slots tensor).
+//
+// One wavefront per row, 16-byte accesses, reductions with DPP-free xor swizzles /
+// bpermute across the 64 lanes; 4 rows per 256-thread block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bevmsda {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+// C = 4 * 64 * VPL floats per row (VPL float4 per lane); rows handled by waves.
+template <int VPL>
+__global__ void __launch_bounds__(256) add_layernorm_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ res,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps,
+                                                           long rows, float *__restrict__ out) {
+  constexpr int C = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4 *xp = reinterpret_cast<const float4 *>(x + row * C);
+  const float4 *rp = res ? reinterpret_cast<const float4 *>(res + row * C) : nullptr;
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = xp[lane + 64 * i];
+    if (rp) {
+      const float4 t = rp[lane + 64 * i];
+      v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+    }
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    ss += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
+  const float4 *gp = reinterpret_cast<const float4 *>(gamma);
+  const float4 *bp = reinterpret_cast<const float4 *>(beta);
+  float4 *op = reinterpret_cast<float4 *>(out + row * C);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float4 g = gp[lane + 64 * i], b = bp[lane + 64 * i];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x + b.x;
+    o.y = (v[i].y - mean) * rstd * g.y + b.y;
+    o.z = (v[i].z - mean) * rstd * g.z + b.z;
+    o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    op[lane + 64 * i] = o;
+  }
+}
+
+// rows (R, C); idx (Q, J) int32 row ids, -1 = empty; scale (Q,); out (Q, C); C % 4 == 0.
+__global__ void __launch_bounds__(256) gather_mean_kernel(const float *__restrict__ rows,
+                                                         const int32_t *__restrict__ idx,
+                                                         const float *__restrict__ scale, long Q, int J,
+                                                         int C, float *__restrict__ out) {
+  const int c4 = C >> 2;                               // float4 per row
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= Q * c4) return;
+  const long q = t / c4;
+  const int c = static_cast<int>(t - q * c4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < J; ++j) {
+    const int r = idx[q * J + j];
+    if (r >= 0) {
+      const float4 v = reinterpret_cast<const float4 *>(rows + static_cast<long>(r) * C)[c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  const float s = scale[q];
+  reinterpret_cast<float4 *>(out + q * C)[c] = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+}
+
+}  // namespace bevmsda

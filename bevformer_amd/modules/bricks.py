@@ -6,6 +6,7 @@ does); without it, the ``FFN`` below provides the same module with the same
 parameter names (``layers.0.0.{weight,bias}``, ``layers.1.{weight,bias}``,
 SURVEY.md §8a-K) so reference checkpoints load unchanged.
 """
+import torch
 import torch.nn as nn
 
 from ..registry import FEEDFORWARD_NETWORK, HAVE_MMCV, BaseModule, Sequential
@@ -39,12 +40,30 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Dropout(p) if p else nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
-        out = self.layers(x)
+    def _layers_inference(self, x):
+        """Same math as ``self.layers`` with dropout inactive: the hidden
+        Linear+ReLU pairs go through hipBLASLt's bias+ReLU epilogue
+        (``torch._addmm_activation``) instead of a GEMM and a clamp launch."""
+        lead = x.shape[:-1]
+        h = x.reshape(-1, x.shape[-1])
+        for blk in list(self.layers)[:-2]:
+            fc = blk[0]
+            h = torch._addmm_activation(fc.bias, h, fc.weight.t(), use_gelu=False)
+        fc = self.layers[-2]
+        return torch.addmm(fc.bias, h, fc.weight.t()).view(*lead, fc.out_features)
+
+    def forward(self, x, identity=None, defer_residual=False):
+        if not self.training and not torch.is_grad_enabled():
+            out = self._layers_inference(x)
+        else:
+            out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:
             identity = x
+        if defer_residual and not (self.training and isinstance(self.dropout_layer, nn.Dropout)
+                                   and self.dropout_layer.p > 0):
+            return out, identity                # the layer fuses "+ identity" into its LayerNorm
         return identity + self.dropout_layer(out)
 
 

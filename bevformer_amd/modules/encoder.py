@@ -24,6 +24,8 @@ import torch
 from ..registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, BaseModule, ModuleList,
                         auto_fp16, build_transformer_layer, force_fp32)
 from . import geometry
+from .. import ops
+from .bricks import FFN
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 
 
@@ -164,17 +166,39 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             bev_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
             bev_start = torch.tensor([0], device=query.device)
 
-        for op in self.operation_order:
+        # inference fast path: "+ identity" of an attention / FFN step is folded into the
+        # LayerNorm that follows it (one pass over the grid instead of two launches)
+        order = self.operation_order
+        fuse_norm = (not self.training) and (not torch.is_grad_enabled())
+        pending = None                          # (branch output, identity) awaiting its norm
+
+        def _defer(i):
+            return fuse_norm and i + 1 < len(order) and order[i + 1] == "norm" \
+                and isinstance(self.norms[norm_i], torch.nn.LayerNorm)
+
+        for i, op in enumerate(order):
             if op == "self_attn":
                 query = self.attentions[attn_i](
                     query, prev_bev, prev_bev, identity if self.pre_norm else None,
                     query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_i],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=bev_shapes, level_start_index=bev_start, **kwargs)
+                    spatial_shapes=bev_shapes, level_start_index=bev_start,
+                    defer_residual=_defer(i), **kwargs)
                 attn_i += 1
-                identity = query
+                if isinstance(query, tuple):
+                    pending, query = query, None
+                else:
+                    identity = query
             elif op == "norm":
-                query = self.norms[norm_i](query)
+                norm = self.norms[norm_i]
+                if pending is not None:
+                    branch, res = pending
+                    pending = None
+                    query = ops.add_layernorm(branch, res, norm.weight, norm.bias, norm.eps)
+                    if query is None:
+                        query = norm(branch + res)
+                else:
+                    query = norm(query)
                 norm_i += 1
             elif op == "cross_attn":
                 query = self.attentions[attn_i](
@@ -183,10 +207,19 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     reference_points_cam=reference_points_cam, mask=mask,
                     attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
                     spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                    frame_plan=frame_plan, **kwargs)
+                    frame_plan=frame_plan, defer_residual=_defer(i), **kwargs)
                 attn_i += 1
-                identity = query
+                if isinstance(query, tuple):
+                    pending, query = query, None
+                else:
+                    identity = query
             elif op == "ffn":
-                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                ffn = self.ffns[ffn_i]
+                if _defer(i) and isinstance(ffn, FFN):
+                    query = ffn(query, identity if self.pre_norm else None, defer_residual=True)
+                else:
+                    query = ffn(query, identity if self.pre_norm else None)
                 ffn_i += 1
+                if isinstance(query, tuple):
+                    pending, query = query, None
         return query

@@ -89,6 +89,8 @@ class FramePlan:
     row_batch: Optional[torch.Tensor] = None   # (R,) int32: j*Nc + cam (value batch entry)
     row_ref: Optional[torch.Tensor] = None     # (R,D,2) projected anchors of the row
     inv_count: Optional[torch.Tensor] = None   # (bs,Q,1)
+    row_query32: Optional[torch.Tensor] = None  # (R,) int32 copy of row_query (kernel-side index)
+    q_rows: Optional[torch.Tensor] = None       # (bs*Q, J) int32: rows of every slot, -1 = none
     hits: List[int] = field(default_factory=list)
     level_shapes_host: Optional[list] = None
 
@@ -145,6 +147,22 @@ def build_sca_rows(reference_points_cam, bev_mask, row_order="raster"):
             inv_count[..., None], hits)
 
 
+def build_q_rows(row_query, num_slots):
+    """Inverse of ``row_query``: for every slot (j*Q + q) the ids of the rows that
+    scatter into it, in increasing row order, padded with -1 -> (num_slots, J) int32."""
+    R = row_query.numel()
+    counts = torch.bincount(row_query, minlength=num_slots)
+    J = max(int(counts.max().item()) if R else 0, 1)
+    table = torch.full((num_slots, J), -1, dtype=torch.int32, device=row_query.device)
+    if R:
+        order = torch.argsort(row_query, stable=True)
+        sq = row_query[order]
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(R, device=row_query.device) - start[sq]
+        table[sq, pos] = order.to(torch.int32)
+    return table
+
+
 def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas, device,
                      dtype=torch.float32, row_order="raster"):
     ref_3d = get_reference_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar,
@@ -157,6 +175,8 @@ def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas
                      bev_start=torch.zeros(1, dtype=torch.long, device=device))
     (plan.row_query, plan.row_batch, plan.row_ref, plan.inv_count, plan.hits) = \
         build_sca_rows(ref_cam, bev_mask, row_order)
+    plan.row_query32 = plan.row_query.to(torch.int32)
+    plan.q_rows = build_q_rows(plan.row_query, bs * bev_h * bev_w)
     return plan
 
 

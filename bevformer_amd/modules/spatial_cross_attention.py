@@ -134,6 +134,25 @@ class MSDeformableAttention3D(BaseModule):
         """(N, S, C) camera features -> (N, S, M, D)."""
         return self.value_proj(value).view(value.shape[0], value.shape[1], self.num_heads, -1)
 
+    def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
+                                       spatial_shapes, level_start_index):
+        """queries (Q, C) projected once; row r samples with the projection row
+        ``row_src[r]`` and its own anchors ``row_ref[r]`` -> (R, C), or None when
+        the fused kernel does not cover the shape."""
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        Dz = row_ref.shape[-2]
+        if P % Dz != 0 or row_ref.shape[-1] != 2:
+            return None
+        n_off = self.sampling_offsets.out_features
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        proj = F.linear(queries, w, b)
+        out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
+                             row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
+                             off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
+                             vmul=1, vadd=0, row_src=row_src, tag="sca_fwd")
+        return None if out is None else out.to(queries.dtype)
+
     def forward_ragged(self, query_rows, value, row_ref, row_batch, spatial_shapes,
                        level_start_index):
         """query_rows (R, C); value (N, S, M, D) already projected; row_ref
@@ -186,7 +205,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
-                projected_value=None, **kwargs):
+                projected_value=None, defer_residual=False, **kwargs):
         """query (bs, Q, C); key/value (Nc, S, bs, C); reference_points_cam
         (Nc, bs, Q, Dz, 2); bev_mask (Nc, bs, Q, Dz) -> (bs, Q, C).
 
@@ -217,11 +236,26 @@ class SpatialCrossAttention(BaseModule):
             feats = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, S, self.embed_dims)
             projected_value = self.deformable_attention.project_value(feats)
 
-        q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
-        out_rows = self.deformable_attention.forward_ragged(
-            q_rows, projected_value, row_ref, row_batch, spatial_shapes, level_start_index)
-        slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
-        slots.index_add_(0, row_query, out_rows)
-        slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
+        da = self.deformable_attention
+        slots = None
+        if frame_plan is not None and frame_plan.q_rows is not None \
+                and ops.fused_wanted(query, projected_value):
+            # inference path: every BEV query is projected ONCE (the reference projects a
+            # copy per camera, spatial_cross_attention.py:149-153); each (camera, query) row
+            # reads its query's projection row through row_src; the camera mean is a gather
+            out_rows = da.forward_rows_shared_projection(
+                query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
+                frame_plan.row_query32, spatial_shapes, level_start_index)
+            if out_rows is not None:
+                slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
+        if slots is None:
+            q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
+            out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
+                                         spatial_shapes, level_start_index)
+            slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
+            slots.index_add_(0, row_query, out_rows)
+            slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
         slots = self.output_proj(slots)
+        if defer_residual and not (self.training and self.dropout.p > 0):
+            return slots, inp_residual          # the layer fuses "+ residual" into its LayerNorm
         return self.dropout(slots) + inp_residual

@@ -121,7 +121,8 @@ class TemporalSelfAttention(BaseModule):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, flag="decoder", bev_slice=None, **kwargs):
+                level_start_index=None, flag="decoder", bev_slice=None, defer_residual=False,
+                **kwargs):
         """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
         b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C).
 
@@ -183,4 +184,6 @@ class TemporalSelfAttention(BaseModule):
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
+        if defer_residual and not (self.training and self.dropout.p > 0):
+            return out, identity                # the layer fuses "+ identity" into its LayerNorm
         return self.dropout(out) + identity

@@ -160,14 +160,17 @@ def fused_wanted(*tensors):
 
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
-               K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, tag="msda_fwd"):
+               K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
+               tag="msda_fwd"):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
     value (N,S,M,32); proj (R, C_out) raw output of the merged projection GEMM
     whose first ``n_off`` columns are sampling offsets and the rest attention
-    logits; ref (R,K,A,2); row_batch (R,) int32 or None.  Returns (R, M*32), or
-    ``None`` when the shape is not covered (caller falls back to the unfused path)."""
+    logits; ref (R,K,A,2); row_batch (R,) int32 or None; row_src (R,) int32 or
+    None: projection row read by output row r (proj then has one row per BEV
+    query instead of one per output row).  Returns (R, M*32), or ``None`` when
+    the shape is not covered (caller falls back to the unfused path)."""
     _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
     store = _STORAGE["dtype"]
     value = value.to(store)
@@ -176,9 +179,12 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
          "bevmsda: proj must be a float32 (R, C) matrix with unit column stride")
     ref = ref.float().contiguous()
     N, S, Mv, D = value.shape
-    R = proj.shape[0]
+    R = proj.shape[0] if row_src is None else row_src.numel()
     A = ref.shape[-2]
     _req(Mv == M and ref.numel() == R * K * A * 2, "bevmsda: inconsistent fused operand shapes")
+    if row_src is not None:
+        _req(row_src.dtype == torch.int32 and row_src.is_contiguous() and row_src.device == proj.device,
+             "bevmsda: row_src must be a contiguous int32 (R,) tensor")
     if row_batch is not None:
         _req(row_batch.dtype == torch.int32 and row_batch.numel() == R and row_batch.is_contiguous(),
              "bevmsda: row_batch must be a contiguous int32 (R,) tensor")
@@ -199,8 +205,52 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
         with ctx:
             rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
                     logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
-                    ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
+                    _ptr(row_src) if row_src is not None else None, ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "msda_fused forward")
+    return out
+
+
+def add_layernorm(x, res, weight, bias, eps):
+    """LayerNorm(x + res) over the last dim in one pass (C ABI:
+    ``bevmsda_add_layernorm_f32``); returns ``None`` when the shape / dtype is
+    not covered so that the caller runs the separate torch ops."""
+    C = x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and C in (256, 512, 1024)
+            and weight is not None and bias is not None and weight.dtype == torch.float32):
+        return None
+    x = x.contiguous()
+    res = res.contiguous() if res is not None else None
+    if res is not None and (res.shape != x.shape or res.dtype != x.dtype):
+        return None
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.bevmsda_add_layernorm_f32(_ptr(x), _ptr(res) if res is not None else None,
+                                           _ptr(weight), _ptr(bias), float(eps), x.numel() // C, C,
+                                           _ptr(out), torch.cuda.current_stream().cuda_stream)
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "add_layernorm")
+    return out
+
+
+def gather_mean(rows, idx, scale):
+    """out[q] = scale[q] * sum_j rows[idx[q, j]] (idx int32, -1 = empty): the SCA
+    scatter-add + camera-count division as a gather (``bevmsda_gather_mean_f32``)."""
+    _req(rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous(),
+         "bevmsda: rows must be a contiguous float32 (R, C) GPU tensor")
+    _req(idx.dtype == torch.int32 and idx.dim() == 2 and idx.is_contiguous(),
+         "bevmsda: idx must be a contiguous int32 (Q, J) tensor")
+    Qn, J = idx.shape
+    scale = scale.reshape(-1).float().contiguous()
+    _req(scale.numel() == Qn, "bevmsda: scale must have one entry per output row")
+    C = rows.shape[1]
+    out = torch.empty((Qn, C), dtype=torch.float32, device=rows.device)
+    lib = _lib.load()
+    with torch.cuda.device(rows.device):
+        rc = lib.bevmsda_gather_mean_f32(_ptr(rows), _ptr(idx), _ptr(scale), Qn, J, C, _ptr(out),
+                                         torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gather_mean")
     return out

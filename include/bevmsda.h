@@ -151,6 +151,9 @@ int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shape
  *           anchor p % A (the pillar anchors of MSDeformableAttention3D), ref_mode 1:
  *           level l uses ref l (A = L)
  *   row_batch  optional (R,) int32: value batch entry base of row r (else r / Q)
+ *   row_src    optional (R,) int32: row of offs / logits used by output row r (else r) —
+ *              SpatialCrossAttention projects every BEV query once and each camera that
+ *              sees the query reads the same projection row
  *   value batch entry of (row r, queue entry q) = base * vmul + q * vadd
  *   out     (R, M*D) = (1/K) * sum_q sample(value[entry(r, q)], loc(r, q), softmax(r, q))
  * Supported: D = 32, P in {4, 8}, 1 <= L <= 4, K in {1, 2} with P*K <= 8, value < 2 GiB; anything else
@@ -167,12 +170,28 @@ typedef struct bevmsda_fused_desc {
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const float *offs, const float *logits,
-                              const float *ref, const int32_t *row_batch,
+                              const float *ref, const int32_t *row_batch, const int32_t *row_src,
                               const bevmsda_fused_desc *desc, float *out, void *stream);
 int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                                const int64_t *level_start, const float *offs,
                                const float *logits, const float *ref, const int32_t *row_batch,
-                               const bevmsda_fused_desc *desc, uint16_t *out, void *stream);
+                               const int32_t *row_src, const bevmsda_fused_desc *desc,
+                               uint16_t *out, void *stream);
+
+/* Row-wise helpers of the encoder layer (csrc/rowops.h), fp32, forward only.
+ *
+ * out = LayerNorm(x + res) * gamma + beta over the last dimension C (res may be NULL):
+ * the "+ identity" of every attention / FFN step followed by the layer's norm
+ * (encoder.py:360-404; torch.nn.LayerNorm semantics: biased variance, eps inside the
+ * square root).  C must be 256, 512 or 1024. */
+int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gamma,
+                              const float *beta, float eps, int64_t rows, int C, float *out,
+                              void *stream);
+/* out[q, :] = scale[q] * sum_{j<J, idx[q,j]>=0} rows[idx[q,j], :] — the per-camera
+ * scatter-add and division by the camera count of SpatialCrossAttention
+ * (spatial_cross_attention.py:165-172) as a gather.  idx: (Q, J) int32, -1 = empty. */
+int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *scale, int64_t Q,
+                            int J, int C, float *out, void *stream);
 
 #ifdef __cplusplus
 }

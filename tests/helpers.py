@@ -23,10 +23,12 @@ def _oracle_msda_ragged(value, shapes, start, loc, attn, row_batch, tag=None):
 
 
 def _oracle_msda_fused(value, shapes, start, proj, n_off, ref, row_batch, *, M, L, P, K, off_head,
-                       off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, tag=None):
+                       off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None, tag=None):
     """CPU statement of the fused entry point's contract (include/bevmsda.h,
     ``bevmsda_fused_forward_*``) out of torch ops + the oracle operator: what the
     kernel must compute for a given descriptor."""
+    if row_src is not None:                 # one projection row per BEV query, shared by its rows
+        proj = proj[row_src.long()]
     R = proj.shape[0]
     D = value.shape[-1]
     A = ref.shape[-2]
@@ -51,18 +53,30 @@ def _oracle_msda_fused(value, shapes, start, proj, n_off, ref, row_batch, *, M, 
     return out / K
 
 
+def _oracle_gather_mean(rows, idx, scale):
+    """Contract of ``bevmsda_gather_mean_f32`` in torch ops."""
+    Qn, J = idx.shape
+    out = rows.new_zeros(Qn, rows.shape[1])
+    for j in range(J):
+        sel = idx[:, j].long()
+        ok = sel >= 0
+        out[ok] += rows[sel[ok]]
+    return out * scale.reshape(-1, 1)
+
+
 @contextlib.contextmanager
 def oracle_ops():
     """Route the package's operator calls through the CPU oracle so that the
     HOST logic of the modules (ragged rows, merged GEMMs, geometry, plans,
     tiling) can be parity-tested without a GPU.  Test-only: the product path
     itself has no CPU implementation."""
-    saved = (ops.msda, ops.msda_ragged, ops.msda_fused)
-    ops.msda, ops.msda_ragged, ops.msda_fused = _oracle_msda, _oracle_msda_ragged, _oracle_msda_fused
+    saved = (ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean)
+    ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean = \
+        _oracle_msda, _oracle_msda_ragged, _oracle_msda_fused, _oracle_gather_mean
     try:
         yield
     finally:
-        ops.msda, ops.msda_ragged, ops.msda_fused = saved
+        ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean = saved
 
 
 def build_pair(name, seed=3, device="cpu"):
