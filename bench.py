@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured HIP graph in the timed region "
+                         "(auto: only with --gpus > 1, where eager launches would be host-bound)")
+    ap.add_argument("--force-tiling", action="store_true",
+                    help="run the multi-GPU schedule (row blocks + RCCL all-gather) even on 1 rank")
     ap.add_argument("--row-order", default=None, choices=["raster", "image"],
                     help="order of the ragged SCA rows inside a camera (default: the encoder's)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -147,6 +152,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif args.force_tiling:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     import bevformer_amd
     from bevformer_amd import bev_tiling, ops
@@ -159,7 +168,7 @@ def main():
     enc = enc.to(dev)
     if args.row_order:
         enc.sca_row_order = args.row_order
-    if world > 1:
+    if world > 1 or args.force_tiling:
         bev_tiling.enable_bev_tiling(enc)
     q, f, kw = S.make_inputs(args.workload, seed=0, temporal=not args.first_frame, device=dev)
     w = S.WORKLOADS[args.workload]
@@ -174,17 +183,55 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.force_tiling:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    timer.enabled = True
+
+    # Timed region.  Eager launches (N = 1: the step is GPU-bound and every sampling-kernel
+    # launch is bracketed by HIP events on its stream), or replays of ONE captured HIP graph
+    # of the whole step (N > 1: ~200 launches per step would be host-bound once the per-rank
+    # work shrinks; the collective is captured too).  Capture failures fall back to eager.
+    graph = None
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    graph_note = "eager"
+    if use_graph:
+        timer.enabled = True            # kernel durations from an eager pass (events cannot
+        for _ in range(2):              # bracket nodes inside a graph replay)
+            step()
+        fence()
+        timer.enabled = False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                  # allocator warm-up on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            fence()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_out = step()
+            graph.replay()
+            fence()
+            graph_note = "hip graph replay"
+        except Exception as e:          # noqa: BLE001 — any capture problem: measure eagerly
+            graph = None
+            graph_note = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
+            torch.cuda.synchronize()
+    if graph is None:
+        timer.enabled = not timer.events
+    fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+        out = g_out
+    else:
+        for _ in range(args.steps):
+            out = step()
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -220,14 +267,18 @@ def main():
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_us": dom["avg_us"], "alg_bytes": dom["alg_bytes"],
-                         "launches_timed": dom["launches"]},
+                         "launches_timed": dom["launches"],
+                         "timing": "HIP events on the launch stream, " +
+                                   ("every launch of the timed region" if graph is None and use_graph is False
+                                    else "eager pass right before the timed region")},
+            "launch_mode": graph_note,
             "kernels": ks,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.first_frame)
             line["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_tiling:
         dist.destroy_process_group()
 
 

@@ -18,6 +18,10 @@ for s in $steps; do
     bench) timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"; cat "$out/bench.json";;
     bench_image) timeout 300 python bench.py --no-cpu-baseline --row-order image > "$out/bench_image.json" 2> "$out/bench_image.err"; cat "$out/bench_image.json";;
     bench_raster) timeout 300 python bench.py --no-cpu-baseline --row-order raster > "$out/bench_raster.json" 2> "$out/bench_raster.err"; cat "$out/bench_raster.json";;
+    bench_graph) timeout 300 python bench.py --no-cpu-baseline --graph on > "$out/bench_graph.json" 2> "$out/bench_graph.err"; cat "$out/bench_graph.json"; tail -2 "$out/bench_graph.err";;
+    bench_tile1) timeout 300 python bench.py --no-cpu-baseline --graph on --force-tiling > "$out/bench_tile1.json" 2> "$out/bench_tile1.err"; cat "$out/bench_tile1.json"; tail -3 "$out/bench_tile1.err";;
+    bench_tile1_ff) timeout 300 python bench.py --no-cpu-baseline --graph on --force-tiling --first-frame > "$out/bench_tile1_ff.json" 2> "$out/bench_tile1_ff.err"; cat "$out/bench_tile1_ff.json"; tail -3 "$out/bench_tile1_ff.err";;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -3 "$out/smoke.log";;
     prof) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; tail -5 "$out/prof_summary.txt";;
     trace) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -30 "$out/prof_summary.txt";;
   esac
