@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="base")
     ap.add_argument("--dtype", default="fp32", choices=["fp32"])
+    ap.add_argument("--gemm", default=None, choices=["split", "bf16", "native"],
+                    help="how the Linear layers run (bevformer_amd.ops.set_gemm_mode); default: the "
+                         "package default / BEVMSDA_GEMM")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -78,15 +81,40 @@ class KernelTimer:
                 return False
         return _Ctx()
 
+    def gemm(self, tag, flops, nbytes):
+        """Same bracket for the projection GEMM launches (ops.set_gemm_timer)."""
+        return self("gemm:" + tag, (flops, nbytes))
+
     def summary(self):
         agg = {}
         for tag, s, e, b in self.events:
+            if tag.startswith("gemm:"):
+                continue
             a = agg.setdefault(tag, [0.0, 0, 0])
             a[0] += s.elapsed_time(e) * 1e-3
             a[1] += 1
             a[2] += b
         return {t: dict(avg_us=a[0] / a[1] * 1e6, launches=a[1], alg_bytes=a[2] / a[1],
                         GBs=a[2] / a[0] / 1e9) for t, a in agg.items()}
+
+    def gemm_summary(self):
+        agg = {}
+        for tag, s, e, b in self.events:
+            if not tag.startswith("gemm:"):
+                continue
+            a = agg.setdefault(tag[5:], [0.0, 0, 0.0, 0.0])
+            a[0] += s.elapsed_time(e) * 1e-3
+            a[1] += 1
+            a[2] += b[0]
+            a[3] += b[1]
+        per = {t: dict(avg_us=a[0] / a[1] * 1e6, launches=a[1], TFLOPs=a[2] / a[0] / 1e12,
+                       alg_GBs=a[3] / a[0] / 1e9) for t, a in agg.items()}
+        if not agg:
+            return None
+        tot_t = sum(a[0] for a in agg.values())
+        return dict(per_tag=per, total_us_per_step=None, TFLOPs=sum(a[2] for a in agg.values()) / tot_t / 1e12,
+                    alg_GBs=sum(a[3] for a in agg.values()) / tot_t / 1e9, seconds=tot_t,
+                    launches=sum(a[1] for a in agg.values()))
 
 
 def _pick_cpu_threads(cores):
@@ -174,8 +202,11 @@ def main():
     w = S.WORKLOADS[args.workload]
     Q = w["bev_h"] * w["bev_w"]
 
+    if args.gemm:
+        ops.set_gemm_mode(args.gemm)
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
+    ops.set_gemm_timer(timer.gemm)
 
     def step():
         with torch.no_grad():
@@ -243,6 +274,15 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
+        gs = timer.gemm_summary()
+        if gs is not None:
+            steps_timed = max(1, ks.get("sca_fwd", {"launches": w["layers"]})["launches"] // w["layers"])
+            gs["total_us_per_step"] = gs.pop("seconds") / steps_timed * 1e6
+            # fractions of the two MFMA peaks (MI355X_MICROARCH.md): the split kernel issues 3 bf16
+            # products per algorithmic product -> its matrix-core utilisation is 3 * TFLOPs / bf16 peak
+            gs["frac_of_f32_mfma_peak_157"] = gs["TFLOPs"] / 157.3
+            if ops.gemm_mode() != "native":
+                gs["frac_of_bf16_mfma_peak_2500"] = gs["TFLOPs"] * (3 if ops.gemm_mode() == "split" else 1) / 2500.0
         dom = ks.get("sca_fwd") or next(iter(ks.values()))
         traffic = None
         if os.path.exists(args.traffic_json):
@@ -261,6 +301,10 @@ def main():
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
                        "sca_row_order": enc.sca_row_order,
+                       "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
+                                         "3 bf16 MFMA products per fp32 product, fp32 accumulate",
+                                "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",
+                                "native": "hipBLASLt fp32 (torch.nn.functional.linear)"}[ops.gemm_mode()],
                        "global_batch": 1, "parallelism": f"bev-row-tiles x{world}" if world > 1 else "single GPU",
                        "sca_rows_per_frame": int(sum(enc.frame_plan(w['bev_h'], w['bev_w'], 1, kw['img_metas'], dev, torch.float32).hits))},
             "roofline": {"kernel": "msda_fwd (SCA sampling, ragged rows)", "bound": "hbm",
@@ -273,6 +317,7 @@ def main():
                                     else "eager pass right before the timed region")},
             "launch_mode": graph_note,
             "kernels": ks,
+            "gemms": gs,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.first_frame)

@@ -33,7 +33,17 @@ class FusedDesc(ctypes.Structure):
                 ("reserved", ctypes.c_int32 * 6)]
 
 
+class LinearDesc(ctypes.Structure):
+    """Mirror of ``struct bevmsda_linear_desc``."""
+    _fields_ = [("M", ctypes.c_int64), ("ldx0", ctypes.c_int64), ("lda0", ctypes.c_int64),
+                ("ldx1", ctypes.c_int64), ("lda1", ctypes.c_int64), ("ldw", ctypes.c_int64),
+                ("ldy", ctypes.c_int64), ("N", ctypes.c_int32), ("K0", ctypes.c_int32),
+                ("K1", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 7)]
+
+
 ERR_UNSUPPORTED = -7
+ERR_MISALIGNED = -4
 _DIMS = [_c_int] * 7
 # name -> argtypes; every symbol the header declares is listed (tests check it)
 SIGNATURES = {
@@ -59,6 +69,7 @@ SIGNATURES = {
                                                      _c_void_p, _c_void_p], _c_int),
     "bevmsda_gather_mean_f32": ([_c_void_p] * 3 + [ctypes.c_int64, _c_int, _c_int,
                                                    _c_void_p, _c_void_p], _c_int),
+    "bevmsda_linear_f32": ([_c_void_p] * 6 + [ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_forward_bf16_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                              ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_bf16_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4

@@ -4,6 +4,7 @@
 #include "msda_kernels.h"
 #include "msda_d32.h"
 #include "rowops.h"
+#include "linear_mfma.h"
 
 namespace {
 
@@ -425,6 +426,46 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipLaunchKernelGGL(bevmsda::gather_mean_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), rows, idx, scale, static_cast<long>(Q), J, C, out);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
+                       const float *bias, const bevmsda_linear_desc *d, float *y, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->M == 0 || d->N == 0) return BEVMSDA_OK;
+  if (d->K0 == 0 || d->K0 % bevmsda::kLinBK != 0 || d->K1 % bevmsda::kLinBK != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (!x0 || !w || !y || (d->K1 > 0 && !x1)) return BEVMSDA_ERR_NULL_POINTER;
+  if ((d->ldx0 | d->ldw | d->ldy) % 4 != 0 || (a0 && d->lda0 % 4 != 0) ||
+      (d->K1 > 0 && (d->ldx1 % 4 != 0 || (a1 && d->lda1 % 4 != 0))))
+    return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->ldx0 < d->K0 || d->ldw < d->K0 + d->K1 || d->ldy < d->N || (d->K1 > 0 && d->ldx1 < d->K1))
+    return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(x0) || misaligned(w) || misaligned(y) || (a0 && misaligned(a0)) ||
+      (d->K1 > 0 && (misaligned(x1) || (a1 && misaligned(a1)))))
+    return BEVMSDA_ERR_MISALIGNED;
+  bevmsda::LinArgs a;
+  a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
+  a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
+  a.w = w; a.ldw = d->ldw; a.bias = bias; a.y = y; a.ldy = d->ldy;
+  a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
+  const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
+  const long long nbn = (d->N + bevmsda::kLinBN - 1) / bevmsda::kLinBN;
+  const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+  if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+  a.nblk_m = static_cast<int>(nbm);
+  a.nblk_n = static_cast<int>(nbn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 g(static_cast<unsigned>(grid)), b(256);
+  const bool add = a.a0 != nullptr || a.a1 != nullptr;
+  if (d->precision == 0) {
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, false>), g, b, 0, st, a);
+  } else {
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, false>), g, b, 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

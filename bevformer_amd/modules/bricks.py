@@ -9,6 +9,7 @@ SURVEY.md §8a-K) so reference checkpoints load unchanged.
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..registry import FEEDFORWARD_NETWORK, HAVE_MMCV, BaseModule, Sequential
 
 
@@ -42,15 +43,21 @@ class FFN(BaseModule):
 
     def _layers_inference(self, x):
         """Same math as ``self.layers`` with dropout inactive: the hidden
-        Linear+ReLU pairs go through hipBLASLt's bias+ReLU epilogue
-        (``torch._addmm_activation``) instead of a GEMM and a clamp launch."""
+        Linear+ReLU pairs run with the bias+ReLU epilogue of the MFMA kernel
+        (``ops.linear``; hipBLASLt's ``torch._addmm_activation`` in ``native`` GEMM mode)
+        instead of a GEMM and a clamp launch."""
         lead = x.shape[:-1]
         h = x.reshape(-1, x.shape[-1])
         for blk in list(self.layers)[:-2]:
             fc = blk[0]
-            h = torch._addmm_activation(fc.bias, h, fc.weight.t(), use_gelu=False)
+            y = ops.linear(h, fc.weight, fc.bias, relu=True, tag="ffn_fc1")
+            h = y if y is not None else \
+                torch._addmm_activation(fc.bias, h, fc.weight.t(), use_gelu=False)
         fc = self.layers[-2]
-        return torch.addmm(fc.bias, h, fc.weight.t()).view(*lead, fc.out_features)
+        y = ops.linear(h, fc.weight, fc.bias, tag="ffn_fc2")
+        if y is None:
+            y = torch.addmm(fc.bias, h, fc.weight.t())
+        return y.view(*lead, fc.out_features)
 
     def forward(self, x, identity=None, defer_residual=False):
         if not self.training and not torch.is_grad_enabled():

@@ -71,10 +71,8 @@ class MSDeformableAttention3D(BaseModule):
         """(..., C) -> offsets (..., M, L, P, 2), softmaxed weights (..., M, L, P)
         from one GEMM over [sampling_offsets ; attention_weights]."""
         M, L, P = self.num_heads, self.num_levels, self.num_points
-        n_off = self.sampling_offsets.out_features
-        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        return self._split_projection(F.linear(query, w, b))
+        w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
+        return self._split_projection(ops.linear_or_torch(query, w, b, tag="sca_offs_attn"))
 
     def _split_projection(self, proj):
         M, L, P = self.num_heads, self.num_levels, self.num_points
@@ -117,7 +115,8 @@ class MSDeformableAttention3D(BaseModule):
             value = value.permute(1, 0, 2)
         bs, Q, _ = query.shape
         num_value = value.shape[1]
-        v = self.value_proj(value)
+        v = ops.linear_or_torch(value, self.value_proj.weight, self.value_proj.bias,
+                                tag="sca_value_proj")
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
         v = v.view(bs, num_value, self.num_heads, -1)
@@ -132,7 +131,9 @@ class MSDeformableAttention3D(BaseModule):
     # -- ragged call used by SpatialCrossAttention ---------------------------
     def project_value(self, value):
         """(N, S, C) camera features -> (N, S, M, D)."""
-        return self.value_proj(value).view(value.shape[0], value.shape[1], self.num_heads, -1)
+        v = ops.linear_or_torch(value, self.value_proj.weight, self.value_proj.bias,
+                                tag="sca_value_proj")
+        return v.view(value.shape[0], value.shape[1], self.num_heads, -1)
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
                                        spatial_shapes, level_start_index):
@@ -144,9 +145,8 @@ class MSDeformableAttention3D(BaseModule):
         if P % Dz != 0 or row_ref.shape[-1] != 2:
             return None
         n_off = self.sampling_offsets.out_features
-        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = F.linear(queries, w, b)
+        w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
+        proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
         out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
                              row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
                              off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
@@ -160,9 +160,8 @@ class MSDeformableAttention3D(BaseModule):
         M, L, P = self.num_heads, self.num_levels, self.num_points
         Dz = row_ref.shape[-2]
         n_off = self.sampling_offsets.out_features
-        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = F.linear(query_rows, w, b)
+        w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
+        proj = ops.linear_or_torch(query_rows, w, b, tag="sca_offs_attn")
         if P % Dz == 0 and row_ref.shape[-1] == 2 and ops.fused_wanted(proj, value):
             # raw projection row -> softmax / locations / sampling in ONE kernel
             out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
@@ -255,7 +254,8 @@ class SpatialCrossAttention(BaseModule):
             slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
             slots.index_add_(0, row_query, out_rows)
             slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
-        slots = self.output_proj(slots)
+        slots = ops.linear_or_torch(slots, self.output_proj.weight, self.output_proj.bias,
+                                    tag="sca_output_proj")
         if defer_residual and not (self.training and self.dropout.p > 0):
             return slots, inp_residual          # the layer fuses "+ residual" into its LayerNorm
         return self.dropout(slots) + inp_residual

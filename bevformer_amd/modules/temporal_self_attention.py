@@ -135,10 +135,9 @@ class TemporalSelfAttention(BaseModule):
         if identity is None:
             identity = query
         query_in = query
-        if query_pos is not None:
-            query = query + query_pos
         if not self.batch_first:
-            query = query.permute(1, 0, 2)
+            # (the reference adds query_pos before the permute; same numbers)
+            query = (query + query_pos if query_pos is not None else query).permute(1, 0, 2)
             if value is not None:
                 value = value.permute(1, 0, 2)
         bs, Q, C = query.shape
@@ -151,20 +150,24 @@ class TemporalSelfAttention(BaseModule):
             first = value[:bs]
             if bev_slice is not None:
                 first = first[:, bev_slice[0]:bev_slice[1]]
-        q2 = torch.cat([first, query], -1)
-
         src = query_in if shared_value else value
         num_value = src.shape[1]
-        v = self.value_proj(src)
+        v = ops.linear_or_torch(src, self.value_proj.weight, self.value_proj.bias, tag="tsa_value_proj")
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
         v = v.reshape(v.shape[0], num_value, M, -1)
 
-        # one GEMM for offsets (nq*M*L*P*2 columns) and weights (nq*M*L*P columns)
+        # one GEMM for offsets (nq*M*L*P*2 columns) and weights (nq*M*L*P columns); on the
+        # MFMA kernel the cat([first, query + pos]) input is read in place from its two sources
         n_off = self.sampling_offsets.out_features
-        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = F.linear(q2, w, b)
+        w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
+        proj = None
+        if self.batch_first:
+            proj = ops.linear(first, w, b, x2=query_in, x2_add=query_pos, tag="tsa_offs_attn")
+        if proj is None:
+            if self.batch_first and query_pos is not None:
+                query = query + query_pos
+            proj = F.linear(torch.cat([first, query], -1), w, b)
         out = None
         if reference_points.shape[-1] == 2 and self.batch_first and key_padding_mask is None \
                 and ops.fused_wanted(proj, v):
@@ -181,7 +184,8 @@ class TemporalSelfAttention(BaseModule):
         if out is None:
             out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,
                                        level_start_index, shared_value, bs, Q, C)
-        out = self.output_proj(out)
+        out = ops.linear_or_torch(out, self.output_proj.weight, self.output_proj.bias,
+                                  tag="tsa_output_proj")
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         if defer_residual and not (self.training and self.dropout.p > 0):

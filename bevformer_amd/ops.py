@@ -6,6 +6,9 @@
 which is how this package runs SpatialCrossAttention without zero-padded rows.
 Neither has a CPU implementation: CPU tensors raise ``RuntimeError``.
 """
+import ctypes
+import os
+
 import torch
 from torch.autograd.function import Function, once_differentiable
 
@@ -195,7 +198,6 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     out = torch.empty((R, M * D), dtype=store, device=value.device)
     fn = lib.bevmsda_fused_forward_f32 if store == torch.float32 else lib.bevmsda_fused_forward_bf16
     logits = proj[:, n_off:]
-    import ctypes
     with torch.cuda.device(value.device):
         # algorithmic bytes: value + raw projection row (offsets 8 B + logit 4 B per point) + out
         alg = value.numel() * value.element_size() + R * M * K * L * P * 12 \
@@ -254,3 +256,134 @@ def gather_mean(rows, idx, scale):
                                          torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "gather_mean")
     return out
+
+
+# ---------------------------------------------------------------------------
+# Dense projections on the matrix cores (csrc/linear_mfma.h)
+# ---------------------------------------------------------------------------
+GEMM_MODES = ("split", "bf16", "native")
+_GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "native")}
+assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
+_GEMM_TIMER = {"cb": None}
+
+
+def set_gemm_mode(mode):
+    """How the no-grad path runs its nn.Linear layers:
+    ``split``  hand-written MFMA kernel, every fp32 operand split into two bf16 terms and
+               each product accumulated in fp32 from three bf16 MFMAs (fp32-class result);
+    ``bf16``   same kernel, operands rounded to bf16 (one MFMA), fp32 accumulate / output;
+    ``native`` torch.nn.functional.linear (hipBLASLt fp32 MFMA at the fp32 vector rate).
+    The autograd path always uses ``native``."""
+    assert mode in GEMM_MODES
+    _GEMM["mode"] = mode
+
+
+def gemm_mode():
+    return _GEMM["mode"]
+
+
+def set_gemm_timer(cb):
+    """``cb(tag, flops, bytes)`` -> context manager around every ``linear`` launch."""
+    _GEMM_TIMER["cb"] = cb
+
+
+def _rows2d(t, K):
+    """View ``t`` (..., K) as (rows, K) with unit column stride and one row stride, without
+    copying when the leading dims collapse; returns (2-D view, row stride)."""
+    if t.dim() != 2:
+        t = t.reshape(-1, K)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else K)
+
+
+def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, tag="linear"):
+    """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
+    ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
+    covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
+    32) and the caller then runs the torch ops."""
+    mode = _GEMM["mode"]
+    if mode == "native" or not x.is_cuda or x.dtype != torch.float32 \
+            or weight.dtype != torch.float32 or not fused_wanted(x, weight, bias, x_add, x2, x2_add):
+        return None
+    K0 = x.shape[-1]
+    K1 = x2.shape[-1] if x2 is not None else 0
+    N = weight.shape[0]
+    if K0 % 32 or K1 % 32 or weight.shape[1] != K0 + K1 or weight.dim() != 2:
+        return None
+    lead = x.shape[:-1]
+    x0, ldx0 = _rows2d(x, K0)
+    M = x0.shape[0]
+    a0 = a1 = x1 = None
+    lda0 = lda1 = ldx1 = 0
+    if x_add is not None:
+        if x_add.shape != x.shape or x_add.dtype != torch.float32:
+            return None
+        a0, lda0 = _rows2d(x_add, K0)
+    if x2 is not None:
+        if x2.shape[:-1] != lead or x2.dtype != torch.float32:
+            return None
+        x1, ldx1 = _rows2d(x2, K1)
+        if x2_add is not None:
+            if x2_add.shape != x2.shape or x2_add.dtype != torch.float32:
+                return None
+            a1, lda1 = _rows2d(x2_add, K1)
+    w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0
+                   and weight.data_ptr() % 16 == 0) else weight.contiguous()
+    b = None
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != N:
+            return None
+        b = bias.contiguous()
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if M == 0 or N == 0:
+        return y.view(*lead, N)
+    desc = _lib.LinearDesc(M=M, ldx0=ldx0, lda0=lda0, ldx1=ldx1, lda1=lda1, ldw=w.stride(0),
+                           ldy=y.stride(0), N=N, K0=K0, K1=K1, relu=int(bool(relu)),
+                           precision=0 if mode == "split" else 1)
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    if cb is not None:
+        nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
+        ctx = cb(tag, 2.0 * M * N * (K0 + K1), nbytes)
+    else:
+        ctx = _NoTimer()
+    with torch.cuda.device(x.device), ctx:
+        rc = lib.bevmsda_linear_f32(_ptr(x0), _ptr(a0) if a0 is not None else None,
+                                    _ptr(x1) if x1 is not None else None,
+                                    _ptr(a1) if a1 is not None else None, _ptr(w),
+                                    _ptr(b) if b is not None else None, ctypes.byref(desc), _ptr(y),
+                                    torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear")
+    return y.view(*lead, N)
+
+
+def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
+    """``linear`` with the torch statement as the not-covered path (single-source form)."""
+    y = linear(x, weight, bias, relu=relu, tag=tag)
+    if y is None:
+        y = torch.nn.functional.linear(x, weight, bias)
+        if relu:
+            y = torch.relu_(y)
+    return y
+
+
+def merged_linear_params(owner, first, second):
+    """``cat`` of the weights / biases of two ``nn.Linear`` that share their input (the
+    sampling-offset and attention-weight projections), cached on ``owner`` while nothing
+    needs a gradient and the parameters have not been written to."""
+    if torch.is_grad_enabled() and (first.weight.requires_grad or second.weight.requires_grad):
+        return (torch.cat([first.weight, second.weight], 0), torch.cat([first.bias, second.bias], 0))
+    key = (first.weight._version, second.weight._version, first.bias._version, second.bias._version,
+           first.weight.data_ptr(), second.weight.data_ptr(), first.bias.data_ptr(),
+           second.bias.data_ptr())
+    hit = owner.__dict__.get("_merged_linear")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        w = torch.cat([first.weight, second.weight], 0)
+        b = torch.cat([first.bias, second.bias], 0)
+    owner.__dict__["_merged_linear"] = (key, w, b)
+    return w, b

@@ -193,6 +193,35 @@ int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gam
 int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *scale, int64_t Q,
                             int J, int C, float *out, void *stream);
 
+/* Dense projection on the matrix cores (csrc/linear_mfma.h), fp32 in / fp32 out, forward only:
+ *
+ *     y[m, n] = act( sum_k A[m, k] * w[n, k] + bias[n] ),   A = [ x0 (+ a0) | x1 (+ a1) ]
+ *
+ * = torch.nn.functional.linear, the value / sampling_offsets / attention_weights /
+ * output_proj Linear layers and the FFN of the encoder layer
+ * (temporal_self_attention.py:198,206-211,267; spatial_cross_attention.py:173,334-348;
+ * custom_base_transformer_layer.py:157-158).  The optional second source x1 concatenates
+ * along K in place (TemporalSelfAttention's cat([value[:bs], query + query_pos], -1),
+ * temporal_self_attention.py:186-197); a0 / a1 are optional element-wise addends (query_pos).
+ * precision 0: every fp32 operand is split into two bf16 terms and each product is
+ * accumulated in fp32 from three bf16 MFMAs (>= 16 mantissa bits per product); precision 1:
+ * operands rounded to bf16 (one MFMA), fp32 accumulation.
+ * Requirements: K0, K1 multiples of 32 (K1 may be 0 with x1 NULL), all row strides multiples
+ * of 4 floats, pointers 16-byte aligned; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and
+ * the caller uses the library GEMM. */
+typedef struct bevmsda_linear_desc {
+  int64_t M;                                  /* rows of A and y */
+  int64_t ldx0, lda0, ldx1, lda1, ldw, ldy;   /* row strides in floats */
+  int32_t N, K0, K1;
+  int32_t relu;                               /* 1: y = max(y, 0) after the bias */
+  int32_t precision;                          /* 0 = split-fp32 (3 products), 1 = bf16 inputs */
+  int32_t reserved[7];
+} bevmsda_linear_desc;
+
+int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                       const float *w, const float *bias, const bevmsda_linear_desc *desc,
+                       float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

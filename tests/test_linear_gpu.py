@@ -1,0 +1,110 @@
+"""GPU: the MFMA projection kernel (``bevmsda_linear_f32``, csrc/linear_mfma.h) against an
+fp64 statement of ``torch.nn.functional.linear``.
+
+Tolerances are error BOUNDS relative to ``|x| @ |w|.T`` (the scale every rounding error of a
+dot product is proportional to):
+  split (3 bf16 products per fp32 product): 2.5e-5  — per-product error <= 3 * 2^-18 = 1.1e-5
+        plus fp32 accumulation; the same bound is asserted for hipBLASLt's fp32 result so the
+        test shows both are fp32-class;
+  bf16  (operands rounded to bf16):          8e-3   — 2 * 2^-9 per product."""
+import pytest
+import torch
+
+from bevformer_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+BOUND = {"split": 2.5e-5, "bf16": 8e-3}
+
+
+@pytest.fixture
+def gemm_mode():
+    saved = ops.gemm_mode()
+    yield ops.set_gemm_mode
+    ops.set_gemm_mode(saved)
+
+
+def _ref64(x, w, b, relu=False):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    return torch.relu(y) if relu else y
+
+
+def _scale(x, w):
+    return x.abs().double() @ w.abs().double().t() + 1e-30
+
+
+def _rand(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 256), (1, 5, 32), (129, 131, 64),
+                                   (1000, 192, 512), (4099, 768, 256), (257, 64, 96)])
+def test_linear_matches_fp64(gemm_mode, mode, M, N, K):
+    gemm_mode(mode)
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2) * 0.1, _rand(N, seed=3)
+    with torch.no_grad():
+        y = ops.linear(x, w, b)
+    assert y is not None and y.shape == (M, N)
+    err = ((y.double() - _ref64(x, w, b)).abs() / _scale(x, w)).max().item()
+    assert err < BOUND[mode], f"{mode} {M}x{N}x{K}: scaled error {err:.3e}"
+    if mode == "split":      # hipBLASLt fp32 is in the same class
+        lib = ((torch.nn.functional.linear(x, w, b).double() - _ref64(x, w, b)).abs()
+               / _scale(x, w)).max().item()
+        assert lib < BOUND[mode]
+
+
+def test_linear_identity_with_asymmetric_weight(gemm_mode):
+    """A = I picks single weights: catches a transposed / permuted accumulator map, and shows
+    that an fp32 weight survives the hi + lo split to 2^-17."""
+    gemm_mode("split")
+    K = 128
+    x = torch.eye(K, device=DEV)
+    w = torch.arange(200 * K, device=DEV, dtype=torch.float32).reshape(200, K) * 1.0009765625 + 0.3
+    with torch.no_grad():
+        y = ops.linear(x, w)
+    torch.testing.assert_close(y, w.t().contiguous(), rtol=2 ** -16, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_two_sources_addends_relu_strides(gemm_mode, mode):
+    gemm_mode(mode)
+    M, K0, K1, N = 777, 256, 256, 192
+    big = _rand(M, K0 + 64, seed=4)
+    x0 = big[:, 32:32 + K0]                       # row stride K0 + 64, 16-byte aligned offset
+    x1, a1 = _rand(1, M, K1, seed=5), _rand(1, M, K1, seed=6)
+    a0 = _rand(M, K0, seed=7)
+    w, b = _rand(N, K0 + K1, seed=8) * 0.05, _rand(N, seed=9)
+    with torch.no_grad():
+        y = ops.linear(x0.view(1, M, K0), w, b, relu=True, x_add=a0.view(1, M, K0), x2=x1, x2_add=a1)
+    assert y.shape == (1, M, N)
+    xa = torch.cat([x0 + a0, (x1 + a1)[0]], -1)
+    want = _ref64(xa, w, b, relu=True)
+    err = ((y[0].double() - want).abs() / _scale(xa, w)).max().item()
+    assert err < BOUND[mode], f"scaled error {err:.3e}"
+    assert (y >= 0).all()
+
+
+def test_linear_not_covered_returns_none(gemm_mode):
+    x, w = _rand(10, 48, seed=1), _rand(7, 48, seed=2)        # K not a multiple of 32
+    gemm_mode("split")
+    with torch.no_grad():
+        assert ops.linear(x, w) is None
+        torch.testing.assert_close(ops.linear_or_torch(x, w), torch.nn.functional.linear(x, w))
+    xg = _rand(10, 64, seed=1).requires_grad_(True)           # autograd -> library GEMM
+    assert ops.linear(xg, _rand(7, 64, seed=2)) is None
+    gemm_mode("native")
+    with torch.no_grad():
+        assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
+
+
+def test_linear_propagates_nan_rows_only(gemm_mode):
+    gemm_mode("split")
+    x, w = _rand(256, 64, seed=1), _rand(128, 64, seed=2)
+    x[17, 5] = float("nan")
+    with torch.no_grad():
+        y = ops.linear(x, w, relu=True)
+    assert torch.isnan(y[17]).all()
+    assert torch.isfinite(torch.cat([y[:17], y[18:]])).all()

@@ -1,0 +1,116 @@
+"""Lane-level model of csrc/linear_mfma.h (CPU, numpy): the staging map, the LDS image,
+the fragment reads and the accumulator -> output map of one 128 x 128 block tile are
+replayed with an MFMA emulated from the documented gfx950 operand layout
+(v_mfma_f32_32x32x16_bf16: lane l holds A[i = l & 31][k = 8 (l >> 5) .. + 7], B[k][j = l & 31];
+D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]) and must reproduce x @ w.T.
+Guards the index arithmetic of the kernel against edits; the kernel itself is checked
+against torch on the GPU (tests/test_linear_gpu.py)."""
+import numpy as np
+
+BM = BN = 128
+BK = 32
+ROW = 40            # bf16 elements per LDS row (kLinRow)
+PLANE = 128 * ROW
+
+
+def _mfma_32x32x16(a_frag, b_frag, acc):
+    """a_frag, b_frag: (64, 8) per-lane operands; acc: (64, 16) per-lane accumulators."""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    for l in range(64):
+        A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a_frag[l]
+        B[8 * (l >> 5):8 * (l >> 5) + 8, l & 31] = b_frag[l]
+    D = A @ B
+    out = acc.copy()
+    for l in range(64):
+        for r in range(16):
+            out[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+def _block_tile(x, w, m0, n0):
+    M, K = x.shape
+    N = w.shape[0]
+    y = np.full((M, N), np.nan)
+    acc = np.zeros((4, 2, 2, 64, 16))
+    for kc in range(0, K, BK):
+        lds = np.zeros(2 * PLANE)            # planes: A, W (hi only: the model checks indices)
+        for tid in range(256):
+            srow, skq = tid >> 2, (tid & 3) * 8
+            for p in range(2):
+                gm = min(m0 + p * 64 + srow, M - 1)
+                gn = min(n0 + p * 64 + srow, N - 1)
+                off = (p * 64 + srow) * ROW + skq
+                lds[off:off + 8] = x[gm, kc + skq:kc + skq + 8]
+                lds[PLANE + off:PLANE + off + 8] = w[gn, kc + skq:kc + skq + 8]
+        for wave in range(4):
+            wm, wn = wave >> 1, wave & 1
+            for ks in range(2):
+                af = np.zeros((2, 64, 8))
+                bf = np.zeros((2, 64, 8))
+                for lane in range(64):
+                    frow, fk = lane & 31, (lane >> 5) * 8
+                    for t in range(2):
+                        ao = (wm * 64 + frow) * ROW + fk + t * 32 * ROW + ks * 16
+                        bo = (wn * 64 + frow) * ROW + fk + t * 32 * ROW + ks * 16
+                        af[t, lane] = lds[ao:ao + 8]
+                        bf[t, lane] = lds[PLANE + bo:PLANE + bo + 8]
+                for i in range(2):
+                    for j in range(2):
+                        acc[wave, i, j] = _mfma_32x32x16(af[i], bf[j], acc[wave, i, j])
+    for wave in range(4):
+        wm, wn = wave >> 1, wave & 1
+        for lane in range(64):
+            for j in range(2):
+                n = n0 + wn * 64 + j * 32 + (lane & 31)
+                for i in range(2):
+                    mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5)
+                    for r in range(16):
+                        m = mb + (r & 3) + 8 * (r >> 2)
+                        if n < N and m < M:
+                            y[m, n] = acc[wave, i, j, lane, r]
+    return y
+
+
+def test_block_tile_indexing_reproduces_gemm():
+    rng = np.random.default_rng(0)
+    M, N, K = 150, 200, 64            # ragged in both directions: 2 x 2 tiles with tails
+    x = rng.standard_normal((M, K))
+    w = rng.standard_normal((N, K))
+    want = x @ w.T
+    got = np.full((M, N), np.nan)
+    for m0 in range(0, M, BM):
+        for n0 in range(0, N, BN):
+            t = _block_tile(x, w, m0, n0)
+            mask = ~np.isnan(t)
+            assert not (mask & ~np.isnan(got)).any(), "two tiles wrote the same element"
+            got[mask] = t[mask]
+    assert not np.isnan(got).any(), "an output element was never written"
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_xcd_tile_map_covers_every_tile_once():
+    for nbm, nbn in ((1, 1), (7, 2), (8, 3), (313, 2), (1445, 6)):
+        grid = ((nbm + 7) // 8) * 8 * nbn
+        seen = set()
+        for b in range(grid):
+            xcd, seq = b & 7, b >> 3
+            mt, nt = (seq // nbn) * 8 + xcd, seq % nbn
+            if mt < nbm:
+                assert (mt, nt) not in seen
+                seen.add((mt, nt))
+        assert len(seen) == nbm * nbn
+
+
+def test_lds_image_is_conflict_free_for_b128_fragment_reads():
+    # ds_read_b128 service groups (MI355X_MICROARCH.md, LDS): 16 lanes each, 64 banks of 4 bytes
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for g in groups:
+        banks = set()
+        for lane in g:
+            byte = ((lane & 31) * ROW + (lane >> 5) * 8) * 2
+            for d in range(4):
+                banks.add((byte // 4 + d) % 64)
+        assert len(banks) == 64

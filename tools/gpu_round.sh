@@ -21,6 +21,13 @@ for s in $steps; do
     bench_graph) timeout 300 python bench.py --no-cpu-baseline --graph on > "$out/bench_graph.json" 2> "$out/bench_graph.err"; cat "$out/bench_graph.json"; tail -2 "$out/bench_graph.err";;
     bench_tile1) timeout 300 python bench.py --no-cpu-baseline --graph on --force-tiling > "$out/bench_tile1.json" 2> "$out/bench_tile1.err"; cat "$out/bench_tile1.json"; tail -3 "$out/bench_tile1.err";;
     bench_tile1_ff) timeout 300 python bench.py --no-cpu-baseline --graph on --force-tiling --first-frame > "$out/bench_tile1_ff.json" 2> "$out/bench_tile1_ff.err"; cat "$out/bench_tile1_ff.json"; tail -3 "$out/bench_tile1_ff.err";;
+    gbench) timeout 300 python tools/gbench.py --iters 20 > "$out/gbench.log" 2>&1; cp gpurun_out/gbench.json "$out/gbench.json" 2>/dev/null; cat "$out/gbench.log" | cut -c1-200;;
+    bench_native) timeout 300 python bench.py --no-cpu-baseline --gemm native > "$out/bench_native.json" 2> "$out/bench_native.err"; cut -c1-400 "$out/bench_native.json"; tail -2 "$out/bench_native.err";;
+    bench_split) timeout 300 python bench.py --no-cpu-baseline --gemm split > "$out/bench_split.json" 2> "$out/bench_split.err"; cut -c1-400 "$out/bench_split.json"; tail -2 "$out/bench_split.err";;
+    bench_split_graph) timeout 300 python bench.py --no-cpu-baseline --gemm split --graph on > "$out/bench_split_graph.json" 2> "$out/bench_split_graph.err"; cut -c1-400 "$out/bench_split_graph.json"; tail -2 "$out/bench_split_graph.err";;
+    bench_bf16) timeout 300 python bench.py --no-cpu-baseline --gemm bf16 > "$out/bench_bf16.json" 2> "$out/bench_bf16.err"; cut -c1-400 "$out/bench_bf16.json"; tail -2 "$out/bench_bf16.err";;
+    trace_split) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --gemm split --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -24 "$out/prof_summary.txt" | cut -c1-160;;
+    prof_split) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --gemm split --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -24 "$out/prof_summary.txt" | cut -c1-160;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -3 "$out/smoke.log";;
     prof) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; tail -5 "$out/prof_summary.txt";;
     trace) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -30 "$out/prof_summary.txt";;

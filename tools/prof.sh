@@ -16,7 +16,7 @@ if [ "${PMC:-1}" = "1" ]; then
               "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
               "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
     name=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
-    timeout -k 5 $PASS_TIMEOUT rocprofv3 --pmc $pass --kernel-include-regex "msda|bevsca|bevtsa" --output-format csv \
+    timeout -k 5 $PASS_TIMEOUT rocprofv3 --pmc $pass --kernel-include-regex "msda|bevsca|bevtsa|linear_splitbf16" --output-format csv \
         -d "$out/pmc_$name" -- "$@" > "$out/pmc_$name.log" 2>&1 || echo "pass '$pass' failed/timed out" >> "$out/failed_passes.txt"
   done
 fi
