@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph in the timed region "
-                         "(auto: only with --gpus > 1, where eager launches would be host-bound)")
+                         "(auto = on, falling back to eager launches if the capture fails; the "
+                         "per-kernel HIP-event timings come from an eager pass right before)")
     ap.add_argument("--force-tiling", action="store_true",
                     help="run the multi-GPU schedule (row blocks + RCCL all-gather) even on 1 rank")
     ap.add_argument("--row-order", default=None, choices=["raster", "image"],
@@ -222,12 +223,12 @@ def main():
         step()
     fence()
 
-    # Timed region.  Eager launches (N = 1: the step is GPU-bound and every sampling-kernel
-    # launch is bracketed by HIP events on its stream), or replays of ONE captured HIP graph
-    # of the whole step (N > 1: ~200 launches per step would be host-bound once the per-rank
-    # work shrinks; the collective is captured too).  Capture failures fall back to eager.
+    # Timed region: replays of ONE captured HIP graph of the whole step (~100 launches per
+    # step; with N > 1 the collective is captured too), per-kernel durations from HIP events
+    # around every sampling / GEMM launch of two eager steps right before; or (--graph off, or
+    # a failed capture) eager launches with the events recorded inside the timed region.
     graph = None
-    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    use_graph = args.graph in ("on", "auto")
     graph_note = "eager"
     if use_graph:
         timer.enabled = True            # kernel durations from an eager pass (events cannot

@@ -14,6 +14,9 @@ using bevmsda::bf16_t;
 // library defaults (chosen from the sweeps recorded in DESIGN.md)
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
+// projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
+constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
+constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
 
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -429,26 +432,28 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
-int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
-                       const float *bias, const bevmsda_linear_desc *d, float *y, void *stream) {
+static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
+                         const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
+                         void *stream) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (d->M == 0 || d->N == 0) return BEVMSDA_OK;
-  if (d->K0 == 0 || d->K0 % bevmsda::kLinBK != 0 || d->K1 % bevmsda::kLinBK != 0) return BEVMSDA_ERR_UNSUPPORTED;
-  if (!x0 || !w || !y || (d->K1 > 0 && !x1)) return BEVMSDA_ERR_NULL_POINTER;
-  if ((d->ldx0 | d->ldw | d->ldy) % 4 != 0 || (a0 && d->lda0 % 4 != 0) ||
+  if (d->K0 == 0 || d->K0 % bevmsda::kLinKGran != 0 || d->K1 % bevmsda::kLinKGran != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (!x0 || (!w && !wpack) || !y || (d->K1 > 0 && !x1)) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->ldx0 % 4 != 0 || (w && d->ldw % 4 != 0) || (a0 && d->lda0 % 4 != 0) ||
       (d->K1 > 0 && (d->ldx1 % 4 != 0 || (a1 && d->lda1 % 4 != 0))))
     return BEVMSDA_ERR_UNSUPPORTED;
-  if (d->ldx0 < d->K0 || d->ldw < d->K0 + d->K1 || d->ldy < d->N || (d->K1 > 0 && d->ldx1 < d->K1))
+  if (d->ldx0 < d->K0 || (w && d->ldw < d->K0 + d->K1) || d->ldy < d->N || (d->K1 > 0 && d->ldx1 < d->K1))
     return BEVMSDA_ERR_BAD_SHAPE;
-  if (misaligned(x0) || misaligned(w) || misaligned(y) || (a0 && misaligned(a0)) ||
+  if (misaligned(x0) || (w && misaligned(w)) || (wpack && misaligned(wpack)) ||
+      (reinterpret_cast<uintptr_t>(y) & 3u) != 0 || (a0 && misaligned(a0)) ||
       (d->K1 > 0 && (misaligned(x1) || (a1 && misaligned(a1)))))
     return BEVMSDA_ERR_MISALIGNED;
   bevmsda::LinArgs a;
   a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
-  a.w = w; a.ldw = d->ldw; a.bias = bias; a.y = y; a.ldy = d->ldy;
+  a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
   const long long nbn = (d->N + bevmsda::kLinBN - 1) / bevmsda::kLinBN;
@@ -459,13 +464,70 @@ int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 g(static_cast<unsigned>(grid)), b(256);
   const bool add = a.a0 != nullptr || a.a1 != nullptr;
-  if (d->precision == 0) {
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, false>), g, b, 0, st, a);
-  } else {
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, false>), g, b, 0, st, a);
+  // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
+  //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
+  //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
+  //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
+  int v = d->reserved[0] > 0 ? d->reserved[0] - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
+  if (v < 0 || v > 15) return BEVMSDA_ERR_BAD_OPTION;
+  const int wmode = v >> 2;
+  if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;
+  if (wmode > 0 && (v & 1)) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 1) && ((d->K0 + d->K1) % 64 != 0 || (d->K1 > 0 && d->K0 % 64 != 0))) v &= ~1;
+#define BEVMSDA_LIN2(NP_, BK_, SW_, WM_)                                                                     \
+  do {                                                                                                       \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_>), g, b, 0, st, a);     \
+  } while (0)
+#define BEVMSDA_LIN1(NP_)                                                       \
+  switch (v) {                                                                  \
+    case 0: BEVMSDA_LIN2(NP_, 32, true, 0); break;                              \
+    case 1: BEVMSDA_LIN2(NP_, 64, true, 0); break;                              \
+    case 2: BEVMSDA_LIN2(NP_, 32, false, 0); break;                             \
+    case 3: BEVMSDA_LIN2(NP_, 64, false, 0); break;                             \
+    case 4: BEVMSDA_LIN2(NP_, 32, true, 1); break;                              \
+    case 6: BEVMSDA_LIN2(NP_, 32, false, 1); break;                             \
+    case 8: BEVMSDA_LIN2(NP_, 32, true, 2); break;                              \
+    case 10: BEVMSDA_LIN2(NP_, 32, false, 2); break;                            \
+    case 12: BEVMSDA_LIN2(NP_, 32, true, 3); break;                             \
+    case 14: BEVMSDA_LIN2(NP_, 32, false, 3); break;                            \
+    default: return BEVMSDA_ERR_BAD_OPTION;                                     \
   }
+  if (d->precision == 0) { BEVMSDA_LIN1(3) } else { BEVMSDA_LIN1(1) }
+#undef BEVMSDA_LIN1
+#undef BEVMSDA_LIN2
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
+                       const float *bias, const bevmsda_linear_desc *d, float *y, void *stream) {
+  if (!w) return BEVMSDA_ERR_NULL_POINTER;
+  return linear_launch(x0, a0, x1, a1, w, nullptr, bias, d, y, stream);
+}
+
+int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                              const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
+                              void *stream) {
+  if (!wpack) return BEVMSDA_ERR_NULL_POINTER;
+  return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream);
+}
+
+int64_t bevmsda_linear_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return static_cast<int64_t>((N + 127) / 128) * (K / 32) * 2 * 128 * 40 * 2;
+}
+
+int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream) {
+  if (N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (K % 32 != 0 || ldw % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldw < K) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!w || !blob) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(w) || misaligned(blob)) return BEVMSDA_ERR_MISALIGNED;
+  const long long threads = static_cast<long long>((N + 127) / 128) * 128 * (K / 8);
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, blob);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

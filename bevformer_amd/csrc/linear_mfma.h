@@ -46,8 +46,9 @@ typedef float lin_f32x16 __attribute__((ext_vector_type(16)));
 struct LinArgs {
   const float *x0, *a0, *x1, *a1;  // A sources (a* optional addends); x1 == nullptr when K1 == 0
   long ldx0, lda0, ldx1, lda1;     // row strides in floats
-  const float *w;                  // (N, K0 + K1) row-major
+  const float *w;                  // (N, K0 + K1) row-major (WMODE 0)
   long ldw;
+  const uint16_t *wpack;           // pre-split weight image (WMODE > 0), see lin_pack_weight_kernel
   const float *bias;               // (N) or nullptr
   float *y;
   long ldy;
@@ -57,9 +58,8 @@ struct LinArgs {
   int nblk_m, nblk_n;
 };
 
-constexpr int kLinBM = 128, kLinBN = 128, kLinBK = 32;
-constexpr int kLinRow = 40;                 // bf16 elements per LDS row: 32 + 8 pad (80 bytes)
-constexpr int kLinPlane = 128 * kLinRow;    // one operand plane (128 rows)
+constexpr int kLinBM = 128, kLinBN = 128;
+constexpr int kLinKGran = 32;               // K0 and K1 must be multiples of this
 
 __device__ __forceinline__ uint32_t lin_pack2(float a, float b) {
   lin_f32x2 v = {a, b};
@@ -86,13 +86,42 @@ __device__ __forceinline__ float4 lin_add4(const float4 &a, const float4 &b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
-template <int NPROD, bool ADD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// NPROD: 3 = split-f32, 1 = bf16 inputs.  ADD: an addend pointer may be present.
+// BK: K elements staged per barrier pair (32: 40 KB LDS, 3 blocks / CU; 64: 72 KB, 2 blocks / CU
+// with twice the bytes in flight per thread and half the barriers).
+// WMODE: where the W operand comes from.  0 = the fp32 weight matrix, split in registers like
+// the activations; 1..3 = the pre-split bf16 image written once per weight version by
+// lin_pack_weight_kernel (per 128-row x 32-k chunk: [hi plane | lo plane] already in the padded
+// LDS row format, 20 KB contiguous), copied 1 = through registers, 2 = by LDS-DMA
+// (global_load_lds_dwordx4) into a double-buffered W area, 3 = by LDS-DMA into a single W area
+// (issued after the chunk's last fragment read).  WMODE > 0 requires BK = 32.
+// SWAP: the MFMA computes the transposed tile (W rows as the A operand), which leaves 4
+// consecutive output columns in 4 consecutive accumulator registers of a lane -> 16-byte
+// stores (4x fewer store instructions); SWAP = false stores dwords in 128-byte row segments.
+constexpr int lin_waves_per_eu(int bk, int wmode, bool add) {
+  return bk == 64 || wmode == 2 ? 2 : (wmode == 3 && !add ? 4 : 3);   // by LDS bytes and VGPR need
+}
+
+template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE>
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(lin_waves_per_eu(BK, WMODE, ADD), lin_waves_per_eu(BK, WMODE, ADD))))
 linear_splitbf16_kernel(const LinArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD: 1 = bf16 inputs, 3 = split-f32");
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE == 0 || BK == 32), "WMODE");
   constexpr bool LO = NPROD == 3;
-  // planes: [0] A hi, [1] W hi, [2] A lo, [3] W lo
-  __shared__ __attribute__((aligned(16))) uint16_t lds[(LO ? 4 : 2) * kLinPlane];
+  constexpr int ROW = BK + 8;               // bf16 elements per LDS row (16-byte pad: the 16 lanes
+                                            // of a ds_read_b128 group hit 16 distinct 4-bank slots)
+  constexpr int PLANE = 128 * ROW;
+  constexpr int TPR = BK / 8;               // staging threads per row
+  constexpr int RPP = 256 / TPR;            // rows per staging pass
+  constexpr int NP = 128 / RPP;             // staging passes
+  constexpr int NPL = LO ? 2 : 1;           // planes per operand: hi (, lo)
+  constexpr int WBUFS = WMODE == 2 ? 2 : 1;
+  // [A hi | A lo] then WBUFS x [W hi | W lo]
+  __shared__ __attribute__((aligned(16))) uint16_t lds[(1 + WBUFS) * NPL * PLANE];
+  uint16_t *const lds_a = lds;
+  uint16_t *const lds_w = lds + NPL * PLANE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -108,23 +137,30 @@ linear_splitbf16_kernel(const LinArgs a) {
   const long m0 = static_cast<long>(mt) * kLinBM;
   const int n0 = nt * kLinBN;
 
-  // staging assignment: row srow (+64 on the second pass), k offset skq inside the chunk
-  const int srow = tid >> 2;
-  const int skq = (tid & 3) * 8;
-  long gm[2];
-  const float *wp[2];
+  // staging assignment: row srow (+RPP per pass), k offset skq inside the chunk
+  const int srow = tid / TPR;
+  const int skq = (tid % TPR) * 8;
+  long gm[NP];
+  const float *wp[NP];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const long m = m0 + p * 64 + srow;
+  for (int p = 0; p < NP; ++p) {
+    const long m = m0 + p * RPP + srow;
     gm[p] = m < a.M ? m : a.M - 1;          // clamped rows are computed and never stored
-    const int n = n0 + p * 64 + srow;
-    wp[p] = a.w + static_cast<long>(n < a.N ? n : a.N - 1) * a.ldw + skq;
+    const int n = n0 + p * RPP + srow;
+    wp[p] = WMODE == 0 ? a.w + static_cast<long>(n < a.N ? n : a.N - 1) * a.ldw + skq : nullptr;
   }
+  // packed weight image: chunk (nt, kc / 32) is NPLANES_PACKED x PLANE bf16 = 20 KB contiguous
+  constexpr int WCH16 = NPL * PLANE / 8;     // 16-byte pieces of a chunk that this NPROD uses
+  constexpr int WPIECES = (WCH16 + 255) / 256;
+  const uint4 *wchunk = WMODE > 0
+      ? reinterpret_cast<const uint4 *>(a.wpack) + static_cast<long>(nt) * ((a.K0 + a.K1) / 32) * (2 * PLANE / 8)
+      : nullptr;
   const int K = a.K0 + a.K1;
 
   // running source pointers of the current A segment (re-based once, where the K axis
-  // switches from x0 to x1)
-  const float *xp[2], *ap[2];
+  // switches from x0 to x1); a chunk never straddles the switch (K0 % BK == 0 is checked
+  // by the launcher for the BK in use)
+  const float *xp[NP], *ap[NP];
   bool has_add = false;
   auto set_segment = [&](bool second) {
     const float *xs = second ? a.x1 : a.x0;
@@ -133,33 +169,55 @@ linear_splitbf16_kernel(const LinArgs a) {
     const long lda = second ? a.lda1 : a.lda0;
     has_add = ADD && as != nullptr;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       xp[p] = xs + gm[p] * ldx + skq;
       ap[p] = has_add ? as + gm[p] * lda + skq : xp[p];
     }
   };
 
-  float4 xr[2][2], wr[2][2], ar[2][2];
+  float4 xr[NP][2], wr[NP][2], ar[NP][2];
+  uint4 wq[WPIECES];                         // WMODE 1: packed W pieces in flight
   bool staged_add = false;                   // the chunk held in xr has an addend in ar
   auto load_chunk = [&]() {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       xr[p][0] = reinterpret_cast<const float4 *>(xp[p])[0];
       xr[p][1] = reinterpret_cast<const float4 *>(xp[p])[1];
-      xp[p] += kLinBK;
+      xp[p] += BK;
       if (ADD && has_add) {
         ar[p][0] = reinterpret_cast<const float4 *>(ap[p])[0];
         ar[p][1] = reinterpret_cast<const float4 *>(ap[p])[1];
-        ap[p] += kLinBK;
+        ap[p] += BK;
       }
-      wr[p][0] = reinterpret_cast<const float4 *>(wp[p])[0];
-      wr[p][1] = reinterpret_cast<const float4 *>(wp[p])[1];
-      wp[p] += kLinBK;
+      if (WMODE == 0) {
+        wr[p][0] = reinterpret_cast<const float4 *>(wp[p])[0];
+        wr[p][1] = reinterpret_cast<const float4 *>(wp[p])[1];
+        wp[p] += BK;
+      }
     }
     staged_add = has_add;
   };
+  // packed W chunk `c` -> registers (WMODE 1) or straight into W buffer `buf` (WMODE 2, 3:
+  // LDS-DMA; destination = wave-uniform base + lane * 16, which is exactly the chunk image)
+  auto load_w = [&](int c, int buf) {
+    const uint4 *src = wchunk + static_cast<long>(c) * (2 * PLANE / 8);
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+      const int idx = i * 256 + tid;
+      if (WCH16 % 256 == 0 || (i * 256 + (tid & ~63)) < WCH16) {     // wave-uniform tail guard
+        if (WMODE == 1) {
+          wq[i] = src[idx];
+        } else {
+          uint16_t *dst = lds_w + buf * NPL * PLANE + (i * 256 + (tid & ~63)) * 8;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(src + idx),
+              (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+        }
+      }
+    }
+  };
 
-  lin_f32x16 acc[2][2];
+  lin_f32x16 acc[2][2];                      // [m tile][n tile] of the 64 x 64 wavefront tile
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,80 +228,181 @@ linear_splitbf16_kernel(const LinArgs a) {
   // fragment addresses (bf16 element offsets inside a plane)
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 8;
-  const int a_off = (wm * 64 + frow) * kLinRow + fk;
-  const int b_off = (wn * 64 + frow) * kLinRow + fk;
+  const int a_off = (wm * 64 + frow) * ROW + fk;
+  const int b_off = (wn * 64 + frow) * ROW + fk;
 
   set_segment(false);
   load_chunk();
-  for (int kc = 0; kc < K; kc += kLinBK) {
+  if (WMODE > 0) load_w(0, 0);
+  for (int kc = 0, c = 0; kc < K; kc += BK, ++c) {
     // registers -> (+ addend) -> split -> LDS
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       uint4 hi, lo;
-      const int off = (p * 64 + srow) * kLinRow + skq;
+      const int off = (p * RPP + srow) * ROW + skq;
       if (ADD && staged_add) {
         xr[p][0] = lin_add4(xr[p][0], ar[p][0]);
         xr[p][1] = lin_add4(xr[p][1], ar[p][1]);
       }
       lin_split8<LO>(xr[p][0], xr[p][1], hi, lo);
-      *reinterpret_cast<uint4 *>(&lds[0 * kLinPlane + off]) = hi;
-      if (LO) *reinterpret_cast<uint4 *>(&lds[2 * kLinPlane + off]) = lo;
-      lin_split8<LO>(wr[p][0], wr[p][1], hi, lo);
-      *reinterpret_cast<uint4 *>(&lds[1 * kLinPlane + off]) = hi;
-      if (LO) *reinterpret_cast<uint4 *>(&lds[3 * kLinPlane + off]) = lo;
+      *reinterpret_cast<uint4 *>(&lds_a[off]) = hi;
+      if (LO) *reinterpret_cast<uint4 *>(&lds_a[PLANE + off]) = lo;
+      if (WMODE == 0) {
+        lin_split8<LO>(wr[p][0], wr[p][1], hi, lo);
+        *reinterpret_cast<uint4 *>(&lds_w[off]) = hi;
+        if (LO) *reinterpret_cast<uint4 *>(&lds_w[PLANE + off]) = lo;
+      }
     }
-    __syncthreads();
-    if (kc + kLinBK < K) {                          // in flight under the MFMAs below
-      if (kc + kLinBK == a.K0) set_segment(true);
+    if (WMODE == 1) {
+#pragma unroll
+      for (int i = 0; i < WPIECES; ++i)
+        if (WCH16 % 256 == 0 || i * 256 + tid < WCH16)
+          *reinterpret_cast<uint4 *>(&lds_w[(i * 256 + tid) * 8]) = wq[i];
+    }
+    __syncthreads();          // staged chunk visible (an LDS-DMA in flight is drained here too)
+    const uint16_t *wcur = lds_w + (WMODE == 2 ? (c & 1) * NPL * PLANE : 0);
+    if (kc + BK < K) {                              // in flight under the MFMAs below
+      if (kc + BK == a.K0) set_segment(true);
       load_chunk();
+      if (WMODE == 1) load_w(c + 1, 0);
+      if (WMODE == 2) load_w(c + 1, (c + 1) & 1);
     }
 
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       lin_bf16x8 ah[2], bh[2], al[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int ao = a_off + t * 32 * kLinRow + ks * 16;
-        const int bo = b_off + t * 32 * kLinRow + ks * 16;
-        ah[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds[0 * kLinPlane + ao]);
-        bh[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds[1 * kLinPlane + bo]);
+        const int ao = a_off + t * 32 * ROW + ks * 16;
+        const int bo = b_off + t * 32 * ROW + ks * 16;
+        ah[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[ao]);
+        bh[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[bo]);
         if (LO) {
-          al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds[2 * kLinPlane + ao]);
-          bl[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds[3 * kLinPlane + bo]);
+          al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
+          bl[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
         }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (LO) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (SWAP) {     // D[n][m]: W fragment as the A operand
+            if (LO) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          } else {        // D[m][n]
+            if (LO) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();
+    __syncthreads();          // every fragment of this chunk has been read
+    if (WMODE == 3 && kc + BK < K) load_w(c + 1, 0);
   }
 
-  // epilogue: D tile element (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31);
-  // for a fixed r the 32 lanes of a half-wave store one contiguous 128-byte row segment
+  // Epilogue.  MFMA D tile: lane holds (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31).
+  if (SWAP) {
+    // D rows are output columns: registers 4g .. 4g+3 of a lane are n = nb + 8g .. +3 of output
+    // row m = lane & 31 -> one float4 store per g (16-byte path needs N, ldy multiples of 4 and
+    // a 16-byte aligned y / bias: checked once, uniform)
+    const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 &&
+                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0);
+    if (vec) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    const bool nok = n < a.N;
-    const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + (lane & 31);
+        float *yrow = a.y + (m < a.M ? m : 0) * a.ldy;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < 2; ++j) {
+          const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = mb + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
-        if (a.relu) v = v < 0.f ? 0.f : v;      // NaN stays NaN, as torch.relu
-        if (nok && m < a.M) a.y[m * a.ldy + n] = v;
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb + 8 * g;
+            if (m < a.M && n < a.N) {         // N % 4 == 0: n < N covers n .. n+3
+              float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
+                                     acc[i][j][4 * g + 3]);
+              if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+              if (a.relu) {                   // NaN stays NaN, as torch.relu
+                v.x = v.x < 0.f ? 0.f : v.x;
+                v.y = v.y < 0.f ? 0.f : v.y;
+                v.z = v.z < 0.f ? 0.f : v.z;
+                v.w = v.w < 0.f ? 0.f : v.w;
+              }
+              *reinterpret_cast<float4 *>(yrow + n) = v;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nb + 8 * (r >> 2) + (r & 3);
+            if (m < a.M && n < a.N) {
+              float t = acc[i][j][r] + (a.bias ? a.bias[n] : 0.f);
+              if (a.relu) t = t < 0.f ? 0.f : t;
+              a.y[m * a.ldy + n] = t;
+            }
+          }
+        }
       }
     }
+  } else {
+    // for a fixed r the 32 lanes of a half-wave store one contiguous 128-byte row segment
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      const bool nok = n < a.N;
+      const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = mb + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bv;
+          if (a.relu) v = v < 0.f ? 0.f : v;      // NaN stays NaN, as torch.relu
+          if (nok && m < a.M) a.y[m * a.ldy + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// Weight image for WMODE > 0: for every (128-row tile nt, 32-deep chunk kc) a contiguous
+// [plane hi | plane lo][128 rows][32 + 8 pad] bf16 block (rows >= N and the pad are zero), i.e.
+// exactly the LDS image the kernel reads its B fragments from.  One thread per 8 k of a row.
+__global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__restrict__ w, long ldw, int N,
+                                                             int K, uint16_t *__restrict__ blob) {
+  constexpr int ROW = 40, PLANE = 128 * ROW;
+  const int kch = K / 32;
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  const long rows = static_cast<long>((N + 127) / 128) * 128;
+  if (t >= rows * (K / 8)) return;
+  const int n = static_cast<int>(t / (K / 8));
+  const int k = static_cast<int>(t % (K / 8)) * 8;
+  uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
+  if (n < N) {
+    const float4 *src = reinterpret_cast<const float4 *>(w + static_cast<long>(n) * ldw + k);
+    lin_split8<true>(src[0], src[1], hi, lo);
+  }
+  uint16_t *chunk = blob + (static_cast<long>(n / 128) * kch + k / 32) * (2 * PLANE);
+  const int off = (n % 128) * ROW + (k % 32);
+  *reinterpret_cast<uint4 *>(chunk + off) = hi;
+  *reinterpret_cast<uint4 *>(chunk + PLANE + off) = lo;
+  if (k % 32 == 24) {       // the 16-byte row pad
+    *reinterpret_cast<uint4 *>(chunk + off + 8) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4 *>(chunk + PLANE + off + 8) = make_uint4(0, 0, 0, 0);
   }
 }
 

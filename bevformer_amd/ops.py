@@ -262,7 +262,12 @@ def gather_mean(rows, idx, scale):
 # Dense projections on the matrix cores (csrc/linear_mfma.h)
 # ---------------------------------------------------------------------------
 GEMM_MODES = ("split", "bf16", "native")
-_GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "native")}
+_GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
+         # launch variant of the MFMA kernel: None = library default; an int v selects variant v
+         # (include/bevmsda.h, bevmsda_linear_desc.reserved[0]); v >= 4 uses the pre-split weight image
+         "variant": (int(os.environ["BEVMSDA_GEMM_VARIANT"]) if os.environ.get("BEVMSDA_GEMM_VARIANT")
+                     else None),
+         "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1"}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -280,6 +285,42 @@ def set_gemm_mode(mode):
 
 def gemm_mode():
     return _GEMM["mode"]
+
+
+def set_gemm_variant(variant=None, pack=None):
+    """Benchmark hook: force a launch variant of the MFMA kernel (None = library default);
+    ``pack`` selects the pre-split weight image for the default variant."""
+    _GEMM["variant"] = variant
+    if pack is not None:
+        _GEMM["pack"] = bool(pack)
+    elif variant is not None:
+        _GEMM["pack"] = variant >= 4
+
+
+def packed_weight(weight):
+    """Pre-split bf16 image of an (N, K) fp32 weight (``bevmsda_linear_pack_weight_f32``),
+    cached on the tensor object until it is written to or moved."""
+    key = (weight._version, weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    hit = getattr(weight, "_bevmsda_pack", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = _lib.load()
+    N, K = weight.shape
+    nbytes = lib.bevmsda_linear_packed_bytes(N, K)
+    if nbytes == 0:
+        return None
+    blob = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.bevmsda_linear_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
+                                                torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear_pack_weight")
+    try:
+        weight._bevmsda_pack = (key, blob)
+    except AttributeError:
+        pass
+    return blob
 
 
 def set_gemm_timer(cb):
@@ -341,7 +382,12 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     desc = _lib.LinearDesc(M=M, ldx0=ldx0, lda0=lda0, ldx1=ldx1, lda1=lda1, ldw=w.stride(0),
                            ldy=y.stride(0), N=N, K0=K0, K1=K1, relu=int(bool(relu)),
                            precision=0 if mode == "split" else 1)
+    variant = _GEMM["variant"]
+    blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
+    if variant is not None and (variant >= 4) == (blob is not None):
+        desc.reserved[0] = 1 + variant
     lib = _lib.load()
+    fn = lib.bevmsda_linear_f32 if blob is None else lib.bevmsda_linear_packed_f32
     cb = _GEMM_TIMER["cb"]
     if cb is not None:
         nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
@@ -349,11 +395,10 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     else:
         ctx = _NoTimer()
     with torch.cuda.device(x.device), ctx:
-        rc = lib.bevmsda_linear_f32(_ptr(x0), _ptr(a0) if a0 is not None else None,
-                                    _ptr(x1) if x1 is not None else None,
-                                    _ptr(a1) if a1 is not None else None, _ptr(w),
-                                    _ptr(b) if b is not None else None, ctypes.byref(desc), _ptr(y),
-                                    torch.cuda.current_stream().cuda_stream)
+        rc = fn(_ptr(x0), _ptr(a0) if a0 is not None else None,
+                _ptr(x1) if x1 is not None else None, _ptr(a1) if a1 is not None else None,
+                _ptr(w) if blob is None else _ptr(blob), _ptr(b) if b is not None else None,
+                ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return None
     _lib.check(rc, "linear")

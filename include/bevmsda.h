@@ -206,8 +206,9 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
  * precision 0: every fp32 operand is split into two bf16 terms and each product is
  * accumulated in fp32 from three bf16 MFMAs (>= 16 mantissa bits per product); precision 1:
  * operands rounded to bf16 (one MFMA), fp32 accumulation.
- * Requirements: K0, K1 multiples of 32 (K1 may be 0 with x1 NULL), all row strides multiples
- * of 4 floats, pointers 16-byte aligned; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and
+ * Requirements: K0, K1 multiples of 32 (K1 may be 0 with x1 NULL), input row strides
+ * multiples of 4 floats, input pointers 16-byte aligned (y: any float pointer / stride);
+ * otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and
  * the caller uses the library GEMM. */
 typedef struct bevmsda_linear_desc {
   int64_t M;                                  /* rows of A and y */
@@ -215,12 +216,29 @@ typedef struct bevmsda_linear_desc {
   int32_t N, K0, K1;
   int32_t relu;                               /* 1: y = max(y, 0) after the bias */
   int32_t precision;                          /* 0 = split-fp32 (3 products), 1 = bf16 inputs */
-  int32_t reserved[7];
+  int32_t reserved[7];                        /* reserved[0]: 0 = default launch variant, 1 + v
+                                                 selects variant v (benchmark sweeps): bit 0 of v =
+                                                 64-deep K chunks, bit 1 = dword-row epilogue,
+                                                 bits 2-3 = packed-weight copy mode (1 registers,
+                                                 2 LDS-DMA double-buffered, 3 LDS-DMA single) */
 } bevmsda_linear_desc;
 
 int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1,
                        const float *w, const float *bias, const bevmsda_linear_desc *desc,
                        float *y, void *stream);
+
+/* The same projection with the weight pre-split once per weight version (inference: the
+ * weights are constants): bevmsda_linear_pack_weight_f32 writes, for every 128-row tile and
+ * 32-deep K chunk of w (N, K), the [hi | lo] bf16 planes in the padded row format the kernel
+ * keeps in LDS, bevmsda_linear_packed_bytes(N, K) bytes in all (0 when K % 32 != 0); the kernel
+ * then copies 20 KB chunks instead of loading and splitting fp32 weights in every block.
+ * Caller-owned blob, 16-byte aligned.  desc->ldw is ignored. */
+int64_t bevmsda_linear_packed_bytes(int N, int K);
+int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob,
+                                   void *stream);
+int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                              const uint16_t *wpack, const float *bias,
+                              const bevmsda_linear_desc *desc, float *y, void *stream);
 
 #ifdef __cplusplus
 }

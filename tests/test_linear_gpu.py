@@ -22,6 +22,12 @@ def gemm_mode():
     saved = ops.gemm_mode()
     yield ops.set_gemm_mode
     ops.set_gemm_mode(saved)
+    ops.set_gemm_variant(None, pack=True)
+
+
+# launch variants of the kernel (include/bevmsda.h): 64-deep chunks, both epilogues, and the
+# three copy modes of the pre-split weight image
+VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14]
 
 
 def _ref64(x, w, b, relu=False):
@@ -37,6 +43,26 @@ def _scale(x, w):
 
 def _rand(*shape, seed):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+
+
+@pytest.mark.parametrize("variant", VARIANTS[1:])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_variants(gemm_mode, mode, variant):
+    """Every launch variant: ragged tile tails in M and N, two sources with an addend, ReLU."""
+    gemm_mode(mode)
+    ops.set_gemm_variant(variant)
+    M, K0, K1, N = 391, 128, 64, 332
+    x0, x1, a1 = _rand(M, K0, seed=11), _rand(M, K1, seed=12), _rand(M, K1, seed=13)
+    w, b = _rand(N, K0 + K1, seed=14) * 0.1, _rand(N, seed=15)
+    with torch.no_grad():
+        y = ops.linear(x0, w, b, relu=True, x2=x1, x2_add=a1)
+        y2 = ops.linear(x0, w[:, :K0].contiguous(), b)
+    xa = torch.cat([x0, x1 + a1], -1)
+    err = ((y.double() - _ref64(xa, w, b, relu=True)).abs() / _scale(xa, w)).max().item()
+    assert err < BOUND[mode], f"variant {variant}: scaled error {err:.3e}"
+    wk = w[:, :K0]
+    err2 = ((y2.double() - _ref64(x0, wk, b)).abs() / _scale(x0, wk)).max().item()
+    assert err2 < BOUND[mode], f"variant {variant} (single source): scaled error {err2:.3e}"
 
 
 @pytest.mark.parametrize("mode", ["split", "bf16"])
@@ -56,10 +82,12 @@ def test_linear_matches_fp64(gemm_mode, mode, M, N, K):
         assert lib < BOUND[mode]
 
 
-def test_linear_identity_with_asymmetric_weight(gemm_mode):
+@pytest.mark.parametrize("variant", [None, 0, 12])
+def test_linear_identity_with_asymmetric_weight(gemm_mode, variant):
     """A = I picks single weights: catches a transposed / permuted accumulator map, and shows
     that an fp32 weight survives the hi + lo split to 2^-17."""
     gemm_mode("split")
+    ops.set_gemm_variant(variant)
     K = 128
     x = torch.eye(K, device=DEV)
     w = torch.arange(200 * K, device=DEV, dtype=torch.float32).reshape(200, K) * 1.0009765625 + 0.3
@@ -98,6 +126,21 @@ def test_linear_not_covered_returns_none(gemm_mode):
     gemm_mode("native")
     with torch.no_grad():
         assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
+
+
+def test_packed_weight_is_cached_until_written(gemm_mode):
+    gemm_mode("split")
+    ops.set_gemm_variant(12)
+    x, w = _rand(64, 64, seed=1), _rand(40, 64, seed=2)
+    with torch.no_grad():
+        y1 = ops.linear(x, w)
+        blob = w._bevmsda_pack[1]
+        ops.linear(x, w)
+        assert w._bevmsda_pack[1] is blob
+        w.mul_(2.0)                                   # in-place write bumps the version
+        y2 = ops.linear(x, w)
+        assert w._bevmsda_pack[1] is not blob
+    torch.testing.assert_close(y2, 2 * y1, rtol=1e-5, atol=1e-5)
 
 
 def test_linear_propagates_nan_rows_only(gemm_mode):

@@ -45,10 +45,16 @@ def timeit(fn, iters, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="comma-separated op tags")
+    ap.add_argument("--modes", default="native,split,bf16")
+    ap.add_argument("--variants", default="", help="comma-separated launch variants of the MFMA kernel "
+                    "(include/bevmsda.h); empty = library default")
     args = ap.parse_args()
     g = torch.Generator().manual_seed(0)
     results = []
     for tag, M, K0, K1, N, relu, add in SHAPES:
+        if args.only and tag not in args.only.split(","):
+            continue
         x0 = torch.randn(M, K0, generator=g).to(DEV)
         x1 = torch.randn(M, K1, generator=g).to(DEV) if K1 else None
         a1 = torch.randn(M, K1, generator=g).to(DEV) if add else None
@@ -56,29 +62,39 @@ def main():
         b = torch.randn(N, generator=g).to(DEV)
         flops = 2.0 * M * N * (K0 + K1)
         nbytes = 4.0 * (M * (K0 + K1) + (M * K1 if add else 0) + N * (K0 + K1) + M * N)
-        want = None
-        for mode in ("native", "split", "bf16"):
-            ops.set_gemm_mode(mode)
+        state = {"want": None}
 
-            def run():
-                with torch.no_grad():
-                    if mode == "native":
-                        xa = x0 if x1 is None else torch.cat([x0, x1 + a1 if add else x1], -1)
-                        y = torch.nn.functional.linear(xa, w, b)
-                        return torch.relu_(y) if relu else y
-                    return ops.linear(x0, w, b, relu=relu, x2=x1, x2_add=a1)
-            y = run()
-            if mode == "native":
-                want = y
-                err = 0.0
-            else:
-                err = ((y - want).abs().max() / want.abs().max()).item()
-            med, mn = timeit(run, args.iters)
-            r = dict(op=tag, mode=mode, M=M, N=N, K=K0 + K1, us=med * 1e6, min_us=mn * 1e6,
-                     TFLOPs=flops / med / 1e12, alg_GBs=nbytes / med / 1e9, alg_MB=nbytes / 1e6,
-                     max_err_vs_native=err)
-            print(json.dumps(r), flush=True)
-            results.append(r)
+        def run(mode):
+            with torch.no_grad():
+                if mode == "native":
+                    xa = x0 if x1 is None else torch.cat([x0, x1 + a1 if add else x1], -1)
+                    y = torch.nn.functional.linear(xa, w, b)
+                    return torch.relu_(y) if relu else y
+                return ops.linear(x0, w, b, relu=relu, x2=x1, x2_add=a1)
+
+        for mode in ("native", "split", "bf16"):
+            if mode != "native" and mode not in args.modes.split(","):
+                continue
+            ops.set_gemm_mode(mode)
+            variants = [None] if mode == "native" or not args.variants \
+                else [int(v) for v in args.variants.split(",")]
+            for variant in variants:
+                ops.set_gemm_variant(variant)
+                y = run(mode)
+                if mode == "native":
+                    state["want"] = y
+                    err = 0.0
+                else:
+                    err = ((y - state["want"]).abs().max() / state["want"].abs().max()).item()
+                if mode == "native" and "native" not in args.modes.split(","):
+                    continue
+                med, mn = timeit(lambda: run(mode), args.iters)
+                r = dict(op=tag, mode=mode, variant=variant, M=M, N=N, K=K0 + K1, us=med * 1e6,
+                         min_us=mn * 1e6, TFLOPs=flops / med / 1e12, alg_GBs=nbytes / med / 1e9,
+                         alg_MB=nbytes / 1e6, max_err_vs_native=err)
+                print(json.dumps(r), flush=True)
+                results.append(r)
+        ops.set_gemm_variant(None, pack=True)
         del x0, x1, a1, w, b
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(outdir, exist_ok=True)

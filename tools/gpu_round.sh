@@ -16,6 +16,7 @@ for s in $steps; do
     kquick) timeout 300 python tools/kbench.py --iters 10 > "$out/kbench.log" 2>&1; tail -12 "$out/kbench.log";;
     probe) (cd tools/probes && hipcc --offload-arch=gfx950 -O3 -o atomic_probe atomic_probe.hip 2>/dev/null && timeout 120 ./atomic_probe) > "$out/atomic_probe.log" 2>&1; tail -16 "$out/atomic_probe.log";;
     bench) timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"; cat "$out/bench.json";;
+    bench_eager) timeout 300 python bench.py --no-cpu-baseline --graph off > "$out/bench_eager.json" 2> "$out/bench_eager.err"; cut -c1-300 "$out/bench_eager.json"; tail -2 "$out/bench_eager.err";;
     bench_image) timeout 300 python bench.py --no-cpu-baseline --row-order image > "$out/bench_image.json" 2> "$out/bench_image.err"; cat "$out/bench_image.json";;
     bench_raster) timeout 300 python bench.py --no-cpu-baseline --row-order raster > "$out/bench_raster.json" 2> "$out/bench_raster.err"; cat "$out/bench_raster.json";;
     bench_graph) timeout 300 python bench.py --no-cpu-baseline --graph on > "$out/bench_graph.json" 2> "$out/bench_graph.err"; cat "$out/bench_graph.json"; tail -2 "$out/bench_graph.err";;
@@ -29,7 +30,7 @@ for s in $steps; do
     trace_split) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --gemm split --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -24 "$out/prof_summary.txt" | cut -c1-160;;
     prof_split) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --gemm split --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -24 "$out/prof_summary.txt" | cut -c1-160;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -3 "$out/smoke.log";;
-    prof) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; tail -5 "$out/prof_summary.txt";;
-    trace) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -30 "$out/prof_summary.txt";;
+    prof) PMC=1 timeout 900 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; tail -5 "$out/prof_summary.txt";;
+    trace) PMC=0 timeout 300 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 > "$out/prof_summary.txt" 2>&1; head -30 "$out/prof_summary.txt";;
   esac
 done

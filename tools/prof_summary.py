@@ -34,7 +34,10 @@ def main(out):
     for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
-            k = (r["Kernel_Name"].replace("void ", "").split("(")[0], r["Counter_Name"])
+            name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+            if os.environ.get("PROF_BY_GRID") and r.get("Grid_Size"):
+                name += f" grid={r['Grid_Size']}"
+            k = (name, r["Counter_Name"])
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
         for (k, c), (v, n) in agg.items():
             pmc.setdefault(k, {})[c] = dict(per_dispatch=v / n, dispatches=n)
