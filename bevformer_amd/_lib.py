@@ -39,7 +39,8 @@ class LinearDesc(ctypes.Structure):
                 ("ldx1", ctypes.c_int64), ("lda1", ctypes.c_int64), ("ldw", ctypes.c_int64),
                 ("ldy", ctypes.c_int64), ("N", ctypes.c_int32), ("K0", ctypes.c_int32),
                 ("K1", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 7)]
+                ("variant", ctypes.c_int32), ("group_cols", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 5)]
 
 
 ERR_UNSUPPORTED = -7

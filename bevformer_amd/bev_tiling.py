@@ -140,7 +140,14 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
 
     x = full_query[:, q0:q1].contiguous()
     inter = []
+    # replicated, layer-invariant value projections: one grouped GEMM each (encoder.py docstring)
+    sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value)
     for li, layer in enumerate(encoder.layers):
+        hoisted = {}
+        if sca_vals is not None:
+            hoisted["projected_value"] = sca_vals[li]
+        if tsa_vals is not None:
+            hoisted["tsa_projected_value"] = tsa_vals[li]
         if prev_bev is None:
             # no history: TSA's value is the CURRENT full BEV -> exchange per layer
             full = full_query if li == 0 else all_gather_rows(x, blocks, bev_w, group)
@@ -151,7 +158,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                   bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
                   level_start_index=level_start_index,
                   reference_points_cam=tile.reference_points_cam, bev_mask=tile.bev_mask,
-                  prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), **kwargs)
+                  prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), **hoisted, **kwargs)
         if encoder.return_intermediate:
             inter.append(all_gather_rows(x, blocks, bev_w, group))
     if encoder.return_intermediate:

@@ -444,7 +444,11 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   if (d->ldx0 % 4 != 0 || (w && d->ldw % 4 != 0) || (a0 && d->lda0 % 4 != 0) ||
       (d->K1 > 0 && (d->ldx1 % 4 != 0 || (a1 && d->lda1 % 4 != 0))))
     return BEVMSDA_ERR_UNSUPPORTED;
-  if (d->ldx0 < d->K0 || (w && d->ldw < d->K0 + d->K1) || d->ldy < d->N || (d->K1 > 0 && d->ldx1 < d->K1))
+  const int gcols = d->group_cols;
+  if (gcols < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (gcols > 0 && (gcols % bevmsda::kLinBN != 0 || d->N % gcols != 0)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->ldx0 < d->K0 || (w && d->ldw < d->K0 + d->K1) || d->ldy < (gcols > 0 ? gcols : d->N) ||
+      (d->K1 > 0 && d->ldx1 < d->K1))
     return BEVMSDA_ERR_BAD_SHAPE;
   if (misaligned(x0) || (w && misaligned(w)) || (wpack && misaligned(wpack)) ||
       (reinterpret_cast<uintptr_t>(y) & 3u) != 0 || (a0 && misaligned(a0)) ||
@@ -455,6 +459,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
   a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
+  a.group_cols = gcols;
   const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
   const long long nbn = (d->N + bevmsda::kLinBN - 1) / bevmsda::kLinBN;
   const long long grid = ((nbm + 7) / 8) * 8 * nbn;
@@ -468,7 +473,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
   //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
   //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
-  int v = d->reserved[0] > 0 ? d->reserved[0] - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
+  int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
   if (v < 0 || v > 15) return BEVMSDA_ERR_BAD_OPTION;
   const int wmode = v >> 2;
   if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;

@@ -55,6 +55,7 @@ struct LinArgs {
   long M;
   int N, K0, K1;
   int relu;
+  int group_cols;                  // > 0: output column n goes to matrix n / group_cols (each (M, ldy))
   int nblk_m, nblk_n;
 };
 
@@ -305,18 +306,25 @@ linear_splitbf16_kernel(const LinArgs a) {
     if (WMODE == 3 && kc + BK < K) load_w(c + 1, 0);
   }
 
+  // grouped output: the N columns are `N / group_cols` consecutive (M, ldy) matrices (one
+  // projection per encoder layer from a single pass over the shared input); a 128-column
+  // tile never straddles two groups (group_cols % 128 == 0, checked by the launcher)
+  const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
+  float *const yg = a.y + static_cast<long>(grp) * a.M * a.ldy;
+  const int ncol0 = grp * a.group_cols;     // column of y that output column 0 of this group maps to
+
   // Epilogue.  MFMA D tile: lane holds (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31).
   if (SWAP) {
     // D rows are output columns: registers 4g .. 4g+3 of a lane are n = nb + 8g .. +3 of output
     // row m = lane & 31 -> one float4 store per g (16-byte path needs N, ldy multiples of 4 and
     // a 16-byte aligned y / bias: checked once, uniform)
-    const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 &&
+    const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (a.group_cols & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0);
     if (vec) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);
-        float *yrow = a.y + (m < a.M ? m : 0) * a.ldy;
+        float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
@@ -351,7 +359,7 @@ linear_splitbf16_kernel(const LinArgs a) {
             if (m < a.M && n < a.N) {
               float t = acc[i][j][r] + (a.bias ? a.bias[n] : 0.f);
               if (a.relu) t = t < 0.f ? 0.f : t;
-              a.y[m * a.ldy + n] = t;
+              yg[m * a.ldy + n - ncol0] = t;
             }
           }
         }
@@ -372,7 +380,7 @@ linear_splitbf16_kernel(const LinArgs a) {
           const long m = mb + (r & 3) + 8 * (r >> 2);
           float v = acc[i][j][r] + bv;
           if (a.relu) v = v < 0.f ? 0.f : v;      // NaN stays NaN, as torch.relu
-          if (nok && m < a.M) a.y[m * a.ldy + n] = v;
+          if (nok && m < a.M) yg[m * a.ldy + n - ncol0] = v;
         }
       }
     }

@@ -83,6 +83,48 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._plan_cache[key] = plan
         return plan
 
+    def hoisted_value_projections(self, value, tsa_value):
+        """The layer-invariant projections, issued once for all layers.
+
+        The inputs of ``MSDeformableAttention3D.value_proj`` (camera features,
+        spatial_cross_attention.py:334) and — when a history BEV exists — of
+        ``TemporalSelfAttention.value_proj`` (``[prev_bev, bev_query]`` built before the layer
+        loop, encoder.py:204-209; temporal_self_attention.py:198) do not change from layer to
+        layer; only the weights do.  The reference streams the 189 MB of camera features six
+        times; here one grouped GEMM reads each input once and writes every layer's
+        projected value (``ops.linear(groups=num_layers)``).  Inference path only.
+        Returns (per-layer SCA values or None, per-layer TSA values or None)."""
+        from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
+        from .temporal_self_attention import TemporalSelfAttention
+        if torch.is_grad_enabled() or self.training or ops.gemm_mode() == "native" \
+                or not value.is_cuda or len(self.layers) < 2:
+            return None, None
+        tsas, scas = [], []
+        for layer in self.layers:
+            att = getattr(layer, "attentions", None)
+            if att is None or len(att) != 2 or not isinstance(att[0], TemporalSelfAttention) \
+                    or not isinstance(att[1], SpatialCrossAttention) \
+                    or not isinstance(att[1].deformable_attention, MSDeformableAttention3D):
+                return None, None
+            tsas.append(att[0])
+            scas.append(att[1].deformable_attention)
+        L = len(self.layers)
+        sca_vals = tsa_vals = None
+        Nc, S, bs, C = value.shape
+        feats = value.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
+        w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
+        y = ops.linear(feats, w, b, groups=L, tag="sca_value_proj")
+        if y is not None:
+            M = scas[0].num_heads
+            sca_vals = [y[i].view(bs * Nc, S, M, -1) for i in range(L)]
+        if tsa_value is not None:
+            w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
+            y = ops.linear(tsa_value, w, b, groups=L, tag="tsa_value_proj")
+            if y is not None:
+                M = tsas[0].num_heads
+                tsa_vals = [y[i].view(tsa_value.shape[0], tsa_value.shape[1], M, -1) for i in range(L)]
+        return sca_vals, tsa_vals
+
     @auto_fp16()
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
@@ -114,12 +156,19 @@ class BEVFormerEncoder(TransformerLayerSequence):
 
         output = bev_query
         intermediate = []
-        for layer in self.layers:
+        sca_vals, tsa_vals = self.hoisted_value_projections(value, prev_bev)
+        for li, layer in enumerate(self.layers):
+            hoisted = {}
+            if sca_vals is not None:
+                hoisted["projected_value"] = sca_vals[li]
+            if tsa_vals is not None:
+                hoisted["tsa_projected_value"] = tsa_vals[li]
             output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
                            ref_3d=plan.ref_3d, bev_h=bev_h, bev_w=bev_w,
                            spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                            reference_points_cam=plan.reference_points_cam,
-                           bev_mask=plan.bev_mask, prev_bev=prev_bev, frame_plan=plan, **kwargs)
+                           bev_mask=plan.bev_mask, prev_bev=prev_bev, frame_plan=plan, **hoisted,
+                           **kwargs)
             bev_query = output
             if self.return_intermediate:
                 intermediate.append(output)

@@ -122,12 +122,14 @@ class TemporalSelfAttention(BaseModule):
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, flag="decoder", bev_slice=None, defer_residual=False,
-                **kwargs):
+                tsa_projected_value=None, **kwargs):
         """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
         b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C).
 
         ``bev_slice=(q0, q1)`` (BEV tiling): ``query`` holds only queries
-        [q0, q1) while ``value`` is the full grid."""
+        [q0, q1) while ``value`` is the full grid.  ``tsa_projected_value``
+        (bs*2, Q, M, D): ``value_proj(value)`` already computed by the encoder
+        for all layers at once (``hoisted_value_projections``)."""
         assert self.num_bev_queue == 2
         shared_value = value is None
         if shared_value:
@@ -152,10 +154,14 @@ class TemporalSelfAttention(BaseModule):
                 first = first[:, bev_slice[0]:bev_slice[1]]
         src = query_in if shared_value else value
         num_value = src.shape[1]
-        v = ops.linear_or_torch(src, self.value_proj.weight, self.value_proj.bias, tag="tsa_value_proj")
-        if key_padding_mask is not None:
-            v = v.masked_fill(key_padding_mask[..., None], 0.0)
-        v = v.reshape(v.shape[0], num_value, M, -1)
+        if tsa_projected_value is not None and not shared_value and key_padding_mask is None:
+            v = tsa_projected_value
+        else:
+            v = ops.linear_or_torch(src, self.value_proj.weight, self.value_proj.bias,
+                                    tag="tsa_value_proj")
+            if key_padding_mask is not None:
+                v = v.masked_fill(key_padding_mask[..., None], 0.0)
+            v = v.reshape(v.shape[0], num_value, M, -1)
 
         # one GEMM for offsets (nq*M*L*P*2 columns) and weights (nq*M*L*P columns); on the
         # MFMA kernel the cat([first, query + pos]) input is read in place from its two sources

@@ -338,11 +338,15 @@ def _rows2d(t, K):
     return t, (t.stride(0) if t.shape[0] > 1 else K)
 
 
-def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, tag="linear"):
+def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, groups=1,
+           tag="linear"):
     """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
     ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
     covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
-    32) and the caller then runs the torch ops."""
+    32) and the caller then runs the torch ops.
+
+    ``groups = G > 1``: ``weight`` is the row-wise concatenation of G Linear layers that share
+    the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x."""
     mode = _GEMM["mode"]
     if mode == "native" or not x.is_cuda or x.dtype != torch.float32 \
             or weight.dtype != torch.float32 or not fused_wanted(x, weight, bias, x_add, x2, x2_add):
@@ -376,16 +380,20 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
         if bias.dtype != torch.float32 or bias.numel() != N:
             return None
         b = bias.contiguous()
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if groups > 1 and (N % groups or (N // groups) % 128):
+        return None
+    ncol = N // groups
+    y = torch.empty((groups, M, ncol), dtype=torch.float32, device=x.device)
     if M == 0 or N == 0:
-        return y.view(*lead, N)
+        return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     desc = _lib.LinearDesc(M=M, ldx0=ldx0, lda0=lda0, ldx1=ldx1, lda1=lda1, ldw=w.stride(0),
-                           ldy=y.stride(0), N=N, K0=K0, K1=K1, relu=int(bool(relu)),
-                           precision=0 if mode == "split" else 1)
+                           ldy=ncol, N=N, K0=K0, K1=K1, relu=int(bool(relu)),
+                           precision=0 if mode == "split" else 1,
+                           group_cols=ncol if groups > 1 else 0)
     variant = _GEMM["variant"]
     blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):
-        desc.reserved[0] = 1 + variant
+        desc.variant = 1 + variant
     lib = _lib.load()
     fn = lib.bevmsda_linear_f32 if blob is None else lib.bevmsda_linear_packed_f32
     cb = _GEMM_TIMER["cb"]
@@ -402,7 +410,7 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return None
     _lib.check(rc, "linear")
-    return y.view(*lead, N)
+    return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
 
 
 def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
@@ -415,20 +423,20 @@ def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
     return y
 
 
-def merged_linear_params(owner, first, second):
-    """``cat`` of the weights / biases of two ``nn.Linear`` that share their input (the
-    sampling-offset and attention-weight projections), cached on ``owner`` while nothing
-    needs a gradient and the parameters have not been written to."""
-    if torch.is_grad_enabled() and (first.weight.requires_grad or second.weight.requires_grad):
-        return (torch.cat([first.weight, second.weight], 0), torch.cat([first.bias, second.bias], 0))
-    key = (first.weight._version, second.weight._version, first.bias._version, second.bias._version,
-           first.weight.data_ptr(), second.weight.data_ptr(), first.bias.data_ptr(),
-           second.bias.data_ptr())
-    hit = owner.__dict__.get("_merged_linear")
+def merged_linear_params(owner, *linears, slot="_merged_linear"):
+    """``cat`` of the weights / biases of ``nn.Linear`` layers that share their input (the
+    sampling-offset and attention-weight projections; the value projections of all encoder
+    layers), cached on ``owner`` while nothing needs a gradient and the parameters have not
+    been written to."""
+    if torch.is_grad_enabled() and any(m.weight.requires_grad for m in linears):
+        return (torch.cat([m.weight for m in linears], 0), torch.cat([m.bias for m in linears], 0))
+    key = tuple((m.weight._version, m.bias._version, m.weight.data_ptr(), m.bias.data_ptr())
+                for m in linears)
+    hit = owner.__dict__.get(slot)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     with torch.no_grad():
-        w = torch.cat([first.weight, second.weight], 0)
-        b = torch.cat([first.bias, second.bias], 0)
-    owner.__dict__["_merged_linear"] = (key, w, b)
+        w = torch.cat([m.weight for m in linears], 0)
+        b = torch.cat([m.bias for m in linears], 0)
+    owner.__dict__[slot] = (key, w, b)
     return w, b

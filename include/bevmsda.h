@@ -216,11 +216,18 @@ typedef struct bevmsda_linear_desc {
   int32_t N, K0, K1;
   int32_t relu;                               /* 1: y = max(y, 0) after the bias */
   int32_t precision;                          /* 0 = split-fp32 (3 products), 1 = bf16 inputs */
-  int32_t reserved[7];                        /* reserved[0]: 0 = default launch variant, 1 + v
-                                                 selects variant v (benchmark sweeps): bit 0 of v =
-                                                 64-deep K chunks, bit 1 = dword-row epilogue,
-                                                 bits 2-3 = packed-weight copy mode (1 registers,
-                                                 2 LDS-DMA double-buffered, 3 LDS-DMA single) */
+  int32_t variant;                            /* 0 = default launch variant, 1 + v selects variant v
+                                                 (benchmark sweeps): bit 0 of v = 64-deep K chunks,
+                                                 bit 1 = dword-row epilogue, bits 2-3 = packed-weight
+                                                 copy mode (1 registers, 2 LDS-DMA double-buffered,
+                                                 3 LDS-DMA single) */
+  int32_t group_cols;                         /* 0, or a multiple of 128 dividing N: output column n
+                                                 is written to matrix n / group_cols of
+                                                 N / group_cols consecutive (M, ldy) matrices at y,
+                                                 column n % group_cols — several Linear layers that
+                                                 share their input (the value projections of all
+                                                 encoder layers) in one pass over that input */
+  int32_t reserved[5];
 } bevmsda_linear_desc;
 
 int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1,

@@ -128,6 +128,23 @@ def test_linear_not_covered_returns_none(gemm_mode):
         assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
 
 
+@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14])
+def test_linear_grouped_output(gemm_mode, variant):
+    """groups = G: G Linear layers over one input -> (G, M, N / G) contiguous outputs."""
+    gemm_mode("split")
+    ops.set_gemm_variant(variant)
+    M, K, G, n = 300, 64, 3, 256
+    x, w, b = _rand(2, M // 2, K, seed=21), _rand(G * n, K, seed=22) * 0.1, _rand(G * n, seed=23)
+    with torch.no_grad():
+        y = ops.linear(x, w, b, groups=G)
+        flat = ops.linear(x, w, b)
+    assert y.shape == (G, 2, M // 2, n)
+    for g in range(G):
+        torch.testing.assert_close(y[g], flat[..., g * n:(g + 1) * n], rtol=0, atol=0)
+    with torch.no_grad():
+        assert ops.linear(x, w[: G * 192], b[: G * 192], groups=G) is None     # 192 % 128 != 0
+
+
 def test_packed_weight_is_cached_until_written(gemm_mode):
     gemm_mode("split")
     ops.set_gemm_variant(12)
