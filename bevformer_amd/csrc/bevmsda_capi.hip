@@ -17,6 +17,7 @@ constexpr int kDefaultQtileBwd = 8;
 // projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
+constexpr long kLinearWideTileMinRows = 131072;  // default switches to 256-column block tiles from this M
 
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -460,30 +461,38 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
-  const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
-  const long long nbn = (d->N + bevmsda::kLinBN - 1) / bevmsda::kLinBN;
-  const long long grid = ((nbm + 7) / 8) * 8 * nbn;
-  if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
-  a.nblk_m = static_cast<int>(nbm);
-  a.nblk_n = static_cast<int>(nbn);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 g(static_cast<unsigned>(grid)), b(256);
   const bool add = a.a0 != nullptr || a.a1 != nullptr;
   // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
   //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
   //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
   //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
+  //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
   int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
-  if (v < 0 || v > 15) return BEVMSDA_ERR_BAD_OPTION;
-  const int wmode = v >> 2;
+  // 256-column tiles (2 blocks / CU) only pay once there are enough row panels to keep every CU fed at
+  // that occupancy: measured win at M = 185 k (camera features), loss at M <= 80 k (r1j sweep)
+  if (d->variant <= 0 && wpack && d->M >= kLinearWideTileMinRows) v |= 16;
+  if (v < 0 || v > 31) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 16) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 16) && (d->N % 256 != 0 || gcols % 256 != 0)) v &= ~16;
+  const int bn = (v & 16) ? 256 : bevmsda::kLinBN;
+  const int wmode = (v >> 2) & 3;
+  const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
+  const long long nbn = (d->N + bn - 1) / bn;
+  const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+  if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+  a.nblk_m = static_cast<int>(nbm);
+  a.nblk_n = static_cast<int>(nbn);
+  const dim3 g(static_cast<unsigned>(grid)), b(256);
   if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;
   if (wmode > 0 && (v & 1)) return BEVMSDA_ERR_BAD_OPTION;
   if ((v & 1) && ((d->K0 + d->K1) % 64 != 0 || (d->K1 > 0 && d->K0 % 64 != 0))) v &= ~1;
-#define BEVMSDA_LIN2(NP_, BK_, SW_, WM_)                                                                     \
-  do {                                                                                                       \
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_>), g, b, 0, st, a);  \
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_>), g, b, 0, st, a);     \
+#define BEVMSDA_LIN3(NP_, BK_, SW_, WM_, BN_)                                                                      \
+  do {                                                                                                             \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_, BN_>), g, b, 0, st, a);   \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_, BN_>), g, b, 0, st, a);      \
   } while (0)
+#define BEVMSDA_LIN2(NP_, BK_, SW_, WM_) BEVMSDA_LIN3(NP_, BK_, SW_, WM_, 128)
 #define BEVMSDA_LIN1(NP_)                                                       \
   switch (v) {                                                                  \
     case 0: BEVMSDA_LIN2(NP_, 32, true, 0); break;                              \
@@ -496,11 +505,14 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
     case 10: BEVMSDA_LIN2(NP_, 32, false, 2); break;                            \
     case 12: BEVMSDA_LIN2(NP_, 32, true, 3); break;                             \
     case 14: BEVMSDA_LIN2(NP_, 32, false, 3); break;                            \
+    case 28: BEVMSDA_LIN3(NP_, 32, true, 3, 256); break;                        \
+    case 30: BEVMSDA_LIN3(NP_, 32, false, 3, 256); break;                       \
     default: return BEVMSDA_ERR_BAD_OPTION;                                     \
   }
   if (d->precision == 0) { BEVMSDA_LIN1(3) } else { BEVMSDA_LIN1(1) }
 #undef BEVMSDA_LIN1
 #undef BEVMSDA_LIN2
+#undef BEVMSDA_LIN3
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -59,7 +59,7 @@ struct LinArgs {
   int nblk_m, nblk_n;
 };
 
-constexpr int kLinBM = 128, kLinBN = 128;
+constexpr int kLinBM = 128, kLinBN = 128;   // kLinBN: column-tile granularity of the packed weight image
 constexpr int kLinKGran = 32;               // K0 and K1 must be multiples of this
 
 __device__ __forceinline__ uint32_t lin_pack2(float a, float b) {
@@ -99,14 +99,21 @@ __device__ __forceinline__ float4 lin_add4(const float4 &a, const float4 &b) {
 // SWAP: the MFMA computes the transposed tile (W rows as the A operand), which leaves 4
 // consecutive output columns in 4 consecutive accumulator registers of a lane -> 16-byte
 // stores (4x fewer store instructions); SWAP = false stores dwords in 128-byte row segments.
-constexpr int lin_waves_per_eu(int bk, int wmode, bool add) {
-  return bk == 64 || wmode == 2 ? 2 : (wmode == 3 && !add ? 4 : 3);   // by LDS bytes and VGPR need
+// BN: block tile width.  256 (packed weights by LDS-DMA only) doubles the wavefront tile to
+// 64 x 128: the activation tile is loaded, split and written to LDS once per 256 output columns
+// instead of twice, 12 fragment reads feed 24 MFMAs instead of 8 feeding 12; 128 accumulator
+// VGPRs and 60 KB of LDS leave 2 blocks per CU.
+constexpr int lin_waves_per_eu(int bk, int wmode, bool add, int bn) {
+  return bk == 64 || wmode == 2 || bn == 256 ? 2 : (wmode == 3 && !add ? 4 : 3);   // by LDS bytes and VGPR need
 }
 
-template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE>
+template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128>
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(lin_waves_per_eu(BK, WMODE, ADD), lin_waves_per_eu(BK, WMODE, ADD))))
+__attribute__((amdgpu_waves_per_eu(lin_waves_per_eu(BK, WMODE, ADD, BN), lin_waves_per_eu(BK, WMODE, ADD, BN))))
 linear_splitbf16_kernel(const LinArgs a) {
+  static_assert(BN == 128 || (BN == 256 && WMODE == 3), "BN = 256 needs the packed weight image by LDS-DMA");
+  constexpr int NTW = BN / 128;             // packed 128-row weight tiles per block
+  constexpr int NJ = BN / 64;               // 32-column MFMA tiles per wavefront
   static_assert(NPROD == 1 || NPROD == 3, "NPROD: 1 = bf16 inputs, 3 = split-f32");
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE == 0 || BK == 32), "WMODE");
@@ -120,7 +127,7 @@ linear_splitbf16_kernel(const LinArgs a) {
   constexpr int NPL = LO ? 2 : 1;           // planes per operand: hi (, lo)
   constexpr int WBUFS = WMODE == 2 ? 2 : 1;
   // [A hi | A lo] then WBUFS x [W hi | W lo]
-  __shared__ __attribute__((aligned(16))) uint16_t lds[(1 + WBUFS) * NPL * PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t lds[(1 + WBUFS * NTW) * NPL * PLANE];
   uint16_t *const lds_a = lds;
   uint16_t *const lds_w = lds + NPL * PLANE;
 
@@ -136,7 +143,7 @@ linear_splitbf16_kernel(const LinArgs a) {
   const int nt = seq % a.nblk_n;
   if (mt >= a.nblk_m) return;
   const long m0 = static_cast<long>(mt) * kLinBM;
-  const int n0 = nt * kLinBN;
+  const int n0 = nt * BN;
 
   // staging assignment: row srow (+RPP per pass), k offset skq inside the chunk
   const int srow = tid / TPR;
@@ -154,8 +161,9 @@ linear_splitbf16_kernel(const LinArgs a) {
   constexpr int WCH16 = NPL * PLANE / 8;     // 16-byte pieces of a chunk that this NPROD uses
   constexpr int WPIECES = (WCH16 + 255) / 256;
   const uint4 *wchunk = WMODE > 0
-      ? reinterpret_cast<const uint4 *>(a.wpack) + static_cast<long>(nt) * ((a.K0 + a.K1) / 32) * (2 * PLANE / 8)
+      ? reinterpret_cast<const uint4 *>(a.wpack) + static_cast<long>(nt) * NTW * ((a.K0 + a.K1) / 32) * (2 * PLANE / 8)
       : nullptr;
+  const long wtile_stride = static_cast<long>((a.K0 + a.K1) / 32) * (2 * PLANE / 8);   // uint4 per 128-row tile
   const int K = a.K0 + a.K1;
 
   // running source pointers of the current A segment (re-based once, where the K axis
@@ -201,28 +209,30 @@ linear_splitbf16_kernel(const LinArgs a) {
   // packed W chunk `c` -> registers (WMODE 1) or straight into W buffer `buf` (WMODE 2, 3:
   // LDS-DMA; destination = wave-uniform base + lane * 16, which is exactly the chunk image)
   auto load_w = [&](int c, int buf) {
-    const uint4 *src = wchunk + static_cast<long>(c) * (2 * PLANE / 8);
 #pragma unroll
-    for (int i = 0; i < WPIECES; ++i) {
-      const int idx = i * 256 + tid;
-      if (WCH16 % 256 == 0 || (i * 256 + (tid & ~63)) < WCH16) {     // wave-uniform tail guard
-        if (WMODE == 1) {
-          wq[i] = src[idx];
-        } else {
-          uint16_t *dst = lds_w + buf * NPL * PLANE + (i * 256 + (tid & ~63)) * 8;
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void *)(src + idx),
-              (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+    for (int t = 0; t < NTW; ++t) {
+      const uint4 *src = wchunk + t * wtile_stride + static_cast<long>(c) * (2 * PLANE / 8);
+#pragma unroll
+      for (int i = 0; i < WPIECES; ++i) {
+        const int idx = i * 256 + tid;
+        if (WCH16 % 256 == 0 || (i * 256 + (tid & ~63)) < WCH16) {     // wave-uniform tail guard
+          if (WMODE == 1) {
+            wq[i] = src[idx];
+          } else {
+            uint16_t *dst = lds_w + (buf * NTW + t) * NPL * PLANE + (i * 256 + (tid & ~63)) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx),
+                                             (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+          }
         }
       }
     }
   };
 
-  lin_f32x16 acc[2][2];                      // [m tile][n tile] of the 64 x 64 wavefront tile
+  lin_f32x16 acc[2][NJ];                     // [m tile][n tile] of the 64 x (BN / 2) wavefront tile
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -230,7 +240,8 @@ linear_splitbf16_kernel(const LinArgs a) {
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 8;
   const int a_off = (wm * 64 + frow) * ROW + fk;
-  const int b_off = (wn * 64 + frow) * ROW + fk;
+  // BN = 128: wave column wn reads rows wn * 64 .. of the one W tile; BN = 256: W tile wn entirely
+  const int b_off = (BN == 256 ? wn * NPL * PLANE : wn * 64 * ROW) + frow * ROW + fk;
 
   set_segment(false);
   load_chunk();
@@ -261,7 +272,7 @@ linear_splitbf16_kernel(const LinArgs a) {
           *reinterpret_cast<uint4 *>(&lds_w[(i * 256 + tid) * 8]) = wq[i];
     }
     __syncthreads();          // staged chunk visible (an LDS-DMA in flight is drained here too)
-    const uint16_t *wcur = lds_w + (WMODE == 2 ? (c & 1) * NPL * PLANE : 0);
+    const uint16_t *wcur = lds_w + (WMODE == 2 ? (c & 1) * NTW * NPL * PLANE : 0);
     if (kc + BK < K) {                              // in flight under the MFMAs below
       if (kc + BK == a.K0) set_segment(true);
       load_chunk();
@@ -271,22 +282,23 @@ linear_splitbf16_kernel(const LinArgs a) {
 
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      lin_bf16x8 ah[2], bh[2], al[2], bl[2];
+      lin_bf16x8 ah[2], bh[NJ], al[2], bl[NJ];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ao = a_off + t * 32 * ROW + ks * 16;
-        const int bo = b_off + t * 32 * ROW + ks * 16;
         ah[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[ao]);
+        if (LO) al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
+      }
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) {
+        const int bo = b_off + t * 32 * ROW + ks * 16;
         bh[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[bo]);
-        if (LO) {
-          al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
-          bl[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
-        }
+        if (LO) bl[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (SWAP) {     // D[n][m]: W fragment as the A operand
             if (LO) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
@@ -326,8 +338,8 @@ linear_splitbf16_kernel(const LinArgs a) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);
         float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < NJ; ++j) {
+          const int nb = n0 + wn * (BN / 2) + j * 32 + 4 * (lane >> 5);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = nb + 8 * g;
@@ -351,8 +363,8 @@ linear_splitbf16_kernel(const LinArgs a) {
       for (int i = 0; i < 2; ++i) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < NJ; ++j) {
+          const int nb = n0 + wn * (BN / 2) + j * 32 + 4 * (lane >> 5);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int n = nb + 8 * (r >> 2) + (r & 3);
@@ -368,8 +380,8 @@ linear_splitbf16_kernel(const LinArgs a) {
   } else {
     // for a fixed r the 32 lanes of a half-wave store one contiguous 128-byte row segment
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
       const bool nok = n < a.N;
       const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
 #pragma unroll

@@ -27,7 +27,7 @@ def gemm_mode():
 
 # launch variants of the kernel (include/bevmsda.h): 64-deep chunks, both epilogues, and the
 # three copy modes of the pre-split weight image
-VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14]
+VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 28, 30]
 
 
 def _ref64(x, w, b, relu=False):
@@ -52,6 +52,8 @@ def test_linear_variants(gemm_mode, mode, variant):
     gemm_mode(mode)
     ops.set_gemm_variant(variant)
     M, K0, K1, N = 391, 128, 64, 332
+    if variant is not None and variant & 16:
+        N = 512            # 256-column tiles need N % 256 == 0 (other N fall back to 128 inside the library)
     x0, x1, a1 = _rand(M, K0, seed=11), _rand(M, K1, seed=12), _rand(M, K1, seed=13)
     w, b = _rand(N, K0 + K1, seed=14) * 0.1, _rand(N, seed=15)
     with torch.no_grad():
@@ -82,7 +84,7 @@ def test_linear_matches_fp64(gemm_mode, mode, M, N, K):
         assert lib < BOUND[mode]
 
 
-@pytest.mark.parametrize("variant", [None, 0, 12])
+@pytest.mark.parametrize("variant", [None, 0, 12, 28])
 def test_linear_identity_with_asymmetric_weight(gemm_mode, variant):
     """A = I picks single weights: catches a transposed / permuted accumulator map, and shows
     that an fp32 weight survives the hi + lo split to 2^-17."""
@@ -90,7 +92,7 @@ def test_linear_identity_with_asymmetric_weight(gemm_mode, variant):
     ops.set_gemm_variant(variant)
     K = 128
     x = torch.eye(K, device=DEV)
-    w = torch.arange(200 * K, device=DEV, dtype=torch.float32).reshape(200, K) * 1.0009765625 + 0.3
+    w = torch.arange(256 * K, device=DEV, dtype=torch.float32).reshape(256, K) * 1.0009765625 + 0.3
     with torch.no_grad():
         y = ops.linear(x, w)
     torch.testing.assert_close(y, w.t().contiguous(), rtol=2 ** -16, atol=0)
@@ -128,7 +130,7 @@ def test_linear_not_covered_returns_none(gemm_mode):
         assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
 
 
-@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14])
+@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14, 28, 30])
 def test_linear_grouped_output(gemm_mode, variant):
     """groups = G: G Linear layers over one input -> (G, M, N / G) contiguous outputs."""
     gemm_mode("split")
