@@ -5,6 +5,7 @@
 #include "msda_d32.h"
 #include "rowops.h"
 #include "linear_mfma.h"
+#include "prologue.h"
 
 namespace {
 
@@ -545,6 +546,46 @@ int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, ui
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_rotate_bev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
+                           const float *theta, void *stream) {
+  if (H < 0 || W < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C != 256 && C != 512) return BEVMSDA_ERR_UNSUPPORTED;
+  if (H == 0 || W == 0) return BEVMSDA_OK;
+  if (!src || !dst || !theta) return BEVMSDA_ERR_NULL_POINTER;
+  if (ld_src < C || ld_dst < C) return BEVMSDA_ERR_BAD_SHAPE;
+  if (ld_src % 4 != 0 || ld_dst % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (misaligned(src) || misaligned(dst)) return BEVMSDA_ERR_MISALIGNED;
+  if (src == dst) return BEVMSDA_ERR_BAD_OPTION;          // a gather cannot run in place
+  bevmsda::RotateArgs a;
+  a.src = src; a.dst = dst; a.ld_src = ld_src; a.ld_dst = ld_dst; a.H = H; a.W = W; a.C = C;
+  a.t00 = theta[0]; a.t01 = theta[1]; a.t02 = theta[2]; a.t10 = theta[3]; a.t11 = theta[4]; a.t12 = theta[5];
+  const long long nb = (static_cast<long long>(H) * W + 3) / 4;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 256) hipLaunchKernelGGL((bevmsda::rotate_bev_kernel<1>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bevmsda::rotate_bev_kernel<2>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_flatten_feats_f32(const float *feat, const float *cams_embeds, const float *level_embed, float *out,
+                              int bs, int Nc, int C, int hw, int S, int s0, void *stream) {
+  if (bs < 0 || Nc < 0 || C <= 0 || hw < 0 || S < 0 || s0 < 0 || s0 + hw > S) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C % 64 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (bs == 0 || Nc == 0 || hw == 0) return BEVMSDA_OK;
+  if (!feat || !out) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(out) || (cams_embeds && misaligned(cams_embeds)) || (level_embed && misaligned(level_embed)) ||
+      (reinterpret_cast<uintptr_t>(feat) & 3u) != 0)
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long bz = static_cast<long long>(bs) * Nc;
+  if (bz > 65535 || C / 64 > 65535) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::FlattenArgs a;
+  a.feat = feat; a.cams_embeds = cams_embeds; a.level_embed = level_embed; a.out = out;
+  a.bs = bs; a.Nc = Nc; a.C = C; a.hw = hw; a.S = S; a.s0 = s0;
+  const dim3 grid(static_cast<unsigned>((hw + 63) / 64), static_cast<unsigned>(C / 64), static_cast<unsigned>(bz));
+  hipLaunchKernelGGL(bevmsda::flatten_feats_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -5,7 +5,8 @@ from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .encoder import BEVFormerEncoder, BEVFormerLayer
 from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
 from .temporal_self_attention import TemporalSelfAttention
+from .transformer import PerceptionTransformer
 
 __all__ = ["BEVFormerEncoder", "BEVFormerLayer", "SpatialCrossAttention",
            "MSDeformableAttention3D", "TemporalSelfAttention", "MyCustomBaseTransformerLayer",
-           "FFN"]
+           "FFN", "PerceptionTransformer"]

@@ -1,0 +1,153 @@
+"""PerceptionTransformer: the caller of the BEV encoder.
+
+Same registry name (``TRANSFORMER``), constructor arguments, parameters (``level_embeds``,
+``cams_embeds``, ``reference_points``, ``can_bus_mlp.*``) and method contracts as
+projects/mmdet3d_plugin/bevformer/modules/transformer.py:26-290.  ``get_bev_features``
+(:104-200) is the part on the encoder's path and runs on this package's kernels:
+
+  * ego-motion shift: the same float64 numpy arithmetic on ``img_metas[i]['can_bus']``;
+  * prev-BEV rotation: ``ops.rotate_bev`` — torchvision's nearest-neighbour ``rotate`` as one
+    gather kernel over the (Q, 256) grid (the reference loops over the batch with a
+    permute / rotate / permute round trip per sample and overwrites its argument in place;
+    this implementation leaves the caller's ``prev_bev`` untouched);
+  * camera / level embeddings + flatten: ``ops.flatten_feats`` — one LDS-tiled transpose per
+    level instead of a permuted view, two broadcast adds and a ``cat``;
+  * can-bus MLP: 18 -> 128 -> 256 on ``bs`` rows, left to torch.
+
+``forward`` (:202-290) additionally needs a decoder; it is built through the
+``TRANSFORMER_LAYER_SEQUENCE`` registry when a ``decoder`` config is given (with the
+reference plugin imported that is its ``DetectionTransformerDecoder``).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..registry import (TRANSFORMER, BaseModule, auto_fp16, build_transformer_layer_sequence,
+                        xavier_uniform_)
+from .spatial_cross_attention import MSDeformableAttention3D
+from .temporal_self_attention import TemporalSelfAttention
+
+
+@TRANSFORMER.register_module(force=True)
+class PerceptionTransformer(BaseModule):
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300, encoder=None,
+                 decoder=None, embed_dims=256, rotate_prev_bev=True, use_shift=True,
+                 use_can_bus=True, can_bus_norm=True, use_cams_embeds=True,
+                 rotate_center=[100, 100], **kwargs):
+        super().__init__(**kwargs)
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.decoder = build_transformer_layer_sequence(decoder) if decoder is not None else None
+        self.embed_dims = embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.fp16_enabled = False
+        self.rotate_prev_bev = rotate_prev_bev
+        self.use_shift = use_shift
+        self.use_can_bus = use_can_bus
+        self.can_bus_norm = can_bus_norm
+        self.use_cams_embeds = use_cams_embeds
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.init_layers()
+        self.rotate_center = rotate_center
+
+    def init_layers(self):
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
+        self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+        self.reference_points = nn.Linear(self.embed_dims, 3)
+        self.can_bus_mlp = nn.Sequential(
+            nn.Linear(18, self.embed_dims // 2), nn.ReLU(inplace=True),
+            nn.Linear(self.embed_dims // 2, self.embed_dims), nn.ReLU(inplace=True))
+        if self.can_bus_norm:
+            self.can_bus_mlp.add_module("norm", nn.LayerNorm(self.embed_dims))
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (MSDeformableAttention3D, TemporalSelfAttention)) \
+                    or type(m).__name__ == "CustomMSDeformableAttention":
+                try:
+                    m.init_weight()
+                except AttributeError:
+                    m.init_weights()
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.cams_embeds)
+        xavier_uniform_(self.reference_points, bias=0.0)
+        # transformer.py:102 calls mmcv's xavier_init on the can_bus_mlp *Sequential*, which has
+        # no .weight / .bias of its own: a no-op (its Linear layers keep the loop's init above)
+
+    @staticmethod
+    def bev_shift(img_metas, bev_h, bev_w, grid_length, use_shift):
+        """transformer.py:123-141 -> (bs, 2) float64 numpy (x, y)."""
+        delta_x = np.array([each["can_bus"][0] for each in img_metas])
+        delta_y = np.array([each["can_bus"][1] for each in img_metas])
+        ego_angle = np.array([each["can_bus"][-2] / np.pi * 180 for each in img_metas])
+        grid_length_y, grid_length_x = grid_length[0], grid_length[1]
+        translation_length = np.sqrt(delta_x ** 2 + delta_y ** 2)
+        translation_angle = np.arctan2(delta_y, delta_x) / np.pi * 180
+        bev_angle = ego_angle - translation_angle
+        shift_y = translation_length * np.cos(bev_angle / 180 * np.pi) / grid_length_y / bev_h
+        shift_x = translation_length * np.sin(bev_angle / 180 * np.pi) / grid_length_x / bev_w
+        return np.stack([shift_x * use_shift, shift_y * use_shift], -1)
+
+    @auto_fp16(apply_to=("mlvl_feats", "bev_queries", "prev_bev", "bev_pos"))
+    def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512],
+                         bev_pos=None, prev_bev=None, **kwargs):
+        """mlvl_feats: list of (bs, Nc, C, h, w); bev_queries (Q, C); bev_pos (bs, C, bev_h,
+        bev_w); prev_bev (bs, Q, C) / (Q, bs, C) / None -> bev_embed (bs, Q, C)."""
+        bs = mlvl_feats[0].size(0)
+        img_metas = kwargs["img_metas"]
+        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        shift = bev_queries.new_tensor(self.bev_shift(img_metas, bev_h, bev_w, grid_length,
+                                                      self.use_shift))
+        if prev_bev is not None:
+            if prev_bev.shape[1] == bev_h * bev_w:
+                prev_bev = prev_bev.permute(1, 0, 2)
+            if self.rotate_prev_bev:
+                angles = [img_metas[i]["can_bus"][-1] for i in range(bs)]
+                prev_bev = ops.rotate_bev(prev_bev, angles, self.rotate_center, bev_h, bev_w)
+
+        can_bus = bev_queries.new_tensor(np.array([each["can_bus"] for each in img_metas]))
+        can_bus = self.can_bus_mlp(can_bus)[None, :, :]
+        bev_queries = bev_queries + can_bus * self.use_can_bus
+
+        feat_flatten, spatial_shapes, level_start_index = ops.flatten_feats(
+            mlvl_feats, self.cams_embeds if self.use_cams_embeds else None, self.level_embeds)
+
+        return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
+                            bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, prev_bev=prev_bev, shift=shift,
+                            **kwargs)
+
+    @auto_fp16(apply_to=("mlvl_feats", "bev_queries", "object_query_embed", "prev_bev", "bev_pos"))
+    def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w,
+                grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,
+                prev_bev=None, **kwargs):
+        """transformer.py:202-290 -> (bev_embed (Q, bs, C), inter_states, init_reference_out,
+        inter_references_out)."""
+        if self.decoder is None:
+            raise RuntimeError("PerceptionTransformer.forward needs a decoder (built from the "
+                               "`decoder` config); get_bev_features does not")
+        bev_embed = self.get_bev_features(mlvl_feats, bev_queries, bev_h, bev_w,
+                                          grid_length=grid_length, bev_pos=bev_pos,
+                                          prev_bev=prev_bev, **kwargs)
+        bs = mlvl_feats[0].size(0)
+        query_pos, query = torch.split(object_query_embed, self.embed_dims, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+        query = query.permute(1, 0, 2)
+        query_pos = query_pos.permute(1, 0, 2)
+        bev_embed = bev_embed.permute(1, 0, 2)
+        inter_states, inter_references = self.decoder(
+            query=query, key=None, value=bev_embed, query_pos=query_pos,
+            reference_points=reference_points, reg_branches=reg_branches,
+            cls_branches=cls_branches,
+            spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
+            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+        return bev_embed, inter_states, init_reference_out, inter_references

@@ -440,3 +440,76 @@ def merged_linear_params(owner, *linears, slot="_merged_linear"):
         b = torch.cat([m.bias for m in linears], 0)
     owner.__dict__[slot] = (key, w, b)
     return w, b
+
+
+# ---------------------------------------------------------------------------
+# The encoder's caller (PerceptionTransformer.get_bev_features): csrc/prologue.h
+# ---------------------------------------------------------------------------
+
+def rotation_theta(angle_deg, center, h, w):
+    """The normalised 2 x 3 inverse affine matrix torchvision's ``rotate(img, angle,
+    center=center)`` hands to ``grid_sample`` (``rotate`` negates the angle and re-centres
+    ``center`` on the image centre; ``_gen_affine_grid`` divides row 0 by w/2 and row 1 by
+    h/2), as 6 fp32 values computed with the same fp32 roundings."""
+    import math
+    cx, cy = 1.0 * (center[0] - w * 0.5), 1.0 * (center[1] - h * 0.5)
+    rot = math.radians(-angle_deg)
+    a, b, c, d = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    m = [d, -b, 0.0, -c, a, 0.0]
+    m[2] += m[0] * (-cx) + m[1] * (-cy)
+    m[5] += m[3] * (-cx) + m[4] * (-cy)
+    m[2] += cx
+    m[5] += cy
+    theta = torch.tensor(m, dtype=torch.float32).reshape(2, 3)
+    return (theta / torch.tensor([[0.5 * w], [0.5 * h]], dtype=torch.float32)).reshape(-1).tolist()
+
+
+def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
+    """prev_bev (Q, bs, C) -> a new tensor whose batch entry i is rotated by ``angles_deg[i]``
+    about ``center`` (nearest, zero fill): ``bevmsda_rotate_bev_f32`` (transformer.py:146-156).
+    The argument is not written to (the reference overwrites it in place)."""
+    _req(prev_bev.is_cuda and prev_bev.dtype == torch.float32 and prev_bev.dim() == 3,
+         "bevmsda: prev_bev must be a float32 (Q, bs, C) GPU tensor")
+    Q, bs, C = prev_bev.shape
+    _req(Q == bev_h * bev_w, "bevmsda: prev_bev rows != bev_h * bev_w")
+    src = prev_bev.contiguous()
+    out = torch.empty_like(src)
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(bs):
+            theta = (ctypes.c_float * 6)(*rotation_theta(float(angles_deg[i]), center, bev_h, bev_w))
+            rc = lib.bevmsda_rotate_bev_f32(src.data_ptr() + i * C * 4, bs * C, out.data_ptr() + i * C * 4,
+                                            bs * C, bev_h, bev_w, C, theta, st)
+            _lib.check(rc, "rotate_bev")
+    return out
+
+
+def flatten_feats(mlvl_feats, cams_embeds, level_embeds):
+    """list of (bs, Nc, C, h, w) -> feat_flatten (Nc, S, bs, C) with ``+ cams_embeds[cam]``
+    (or None) ``+ level_embeds[lvl]``, plus spatial_shapes (L, 2) and level_start_index (L,)
+    int64 device tensors (transformer.py:165-184): ``bevmsda_flatten_feats_f32``."""
+    f0 = mlvl_feats[0]
+    _req(f0.is_cuda and f0.dtype == torch.float32, "bevmsda: camera features must be float32 GPU tensors")
+    bs, Nc, C = f0.shape[:3]
+    shapes = [(int(f.shape[3]), int(f.shape[4])) for f in mlvl_feats]
+    S = sum(h * w for h, w in shapes)
+    out = torch.empty((Nc, S, bs, C), dtype=torch.float32, device=f0.device)
+    lib = _lib.load()
+    ce = cams_embeds.float().contiguous() if cams_embeds is not None else None
+    le = level_embeds.float().contiguous()
+    s0 = 0
+    with torch.cuda.device(f0.device):
+        st = torch.cuda.current_stream().cuda_stream
+        for lvl, (f, (h, w)) in enumerate(zip(mlvl_feats, shapes)):
+            _req(tuple(f.shape[:3]) == (bs, Nc, C) and f.dtype == torch.float32,
+                 "bevmsda: inconsistent feature levels")
+            f = f.contiguous()
+            rc = lib.bevmsda_flatten_feats_f32(_ptr(f), _ptr(ce) if ce is not None else None,
+                                               le.data_ptr() + lvl * C * 4, _ptr(out), bs, Nc, C, h * w,
+                                               S, s0, st)
+            _lib.check(rc, "flatten_feats")
+            s0 += h * w
+    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=f0.device)
+    level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+    return out, spatial_shapes, level_start_index

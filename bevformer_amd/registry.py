@@ -112,6 +112,14 @@ except Exception:  # no mmcv in this environment (or only the oracle's stub)
             nn.Sequential.__init__(self, *args)
 
 
+try:  # mmdet's registry of whole transformers (modules/transformer.py:14,26)
+    if not HAVE_MMCV:
+        raise ImportError
+    from mmdet.models.utils.builder import TRANSFORMER
+except Exception:
+    TRANSFORMER = Registry("Transformer")
+
+
 def _build(cfg, registry, default_args=None):
     if HAVE_MMCV:
         from mmcv.utils import build_from_cfg as _bfc
@@ -133,6 +141,10 @@ def build_transformer_layer(cfg, default_args=None):
 
 def build_transformer_layer_sequence(cfg, default_args=None):
     return _build(cfg, TRANSFORMER_LAYER_SEQUENCE, default_args)
+
+
+def build_transformer(cfg, default_args=None):
+    return _build(cfg, TRANSFORMER, default_args)
 
 
 def xavier_uniform_(module, bias=0.0):

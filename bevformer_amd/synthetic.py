@@ -134,6 +134,52 @@ def make_inputs(name, seed=0, bs=1, temporal=False, device="cpu", dtype=torch.fl
     return mv(bev_query), mv(feat), kwargs
 
 
+def transformer_cfg(name):
+    """The ``transformer=dict(type='PerceptionTransformer', ...)`` block of the reference
+    configs (projects/configs/bevformer/bevformer_base.py:70-106) around ``encoder_cfg(name)``,
+    without a decoder; ``rotate_center`` is the grid centre (the configs' [100, 100] for the
+    200 x 200 base grid)."""
+    w = WORKLOADS[name]
+    return dict(type="PerceptionTransformer", num_feature_levels=len(w["shapes"]),
+                num_cams=NUM_CAMS, rotate_prev_bev=True, use_shift=True, use_can_bus=True,
+                embed_dims=EMBED_DIMS, rotate_center=[w["bev_w"] // 2, w["bev_h"] // 2],
+                encoder=encoder_cfg(name))
+
+
+def make_can_bus(seed=0, yaw_delta_deg=4.0):
+    """An 18-float ``can_bus`` vector with the entries the path reads
+    (datasets/nuscenes_dataset.py:148-165): [0:2] ego translation since the previous frame
+    (m), [-2] ego yaw (rad), [-1] yaw delta (deg); the rest only feeds the can-bus MLP."""
+    g = np.random.default_rng(seed)
+    cb = g.standard_normal(18) * 0.1
+    cb[0], cb[1] = 2.0, 1.5
+    cb[-2] = 0.3
+    cb[-1] = yaw_delta_deg
+    return cb
+
+
+def make_transformer_inputs(name, seed=0, bs=1, temporal=False, device="cpu"):
+    """Arguments of one ``PerceptionTransformer.get_bev_features`` call (call site:
+    dense_heads/bevformer_head.py:150-160): (mlvl_feats, bev_queries, kwargs)."""
+    w = WORKLOADS[name]
+    g = torch.Generator().manual_seed(seed)
+    Q = w["bev_h"] * w["bev_w"]
+    mlvl = [torch.randn(bs, NUM_CAMS, EMBED_DIMS, h, ww, generator=g) for h, ww in w["shapes"]]
+    bev_queries = torch.randn(Q, EMBED_DIMS, generator=g)
+    bev_pos = torch.randn(bs, EMBED_DIMS, w["bev_h"], w["bev_w"], generator=g)
+    prev_bev = torch.randn(bs, Q, EMBED_DIMS, generator=g) if temporal else None
+    metas = make_img_metas(name, bs)
+    for i, m in enumerate(metas):
+        m["can_bus"] = make_can_bus(seed + i, yaw_delta_deg=4.0 + 3.0 * i)
+
+    def mv(t):
+        return None if t is None else t.to(device)
+
+    kwargs = dict(bev_h=w["bev_h"], bev_w=w["bev_w"], grid_length=(0.512, 0.512), bev_pos=mv(bev_pos),
+                  prev_bev=mv(prev_bev), img_metas=metas)
+    return [mv(f) for f in mlvl], mv(bev_queries), kwargs
+
+
 def trained_like_(state_dict, seed=1):
     """Weight regime (ii) of SURVEY §8d, applied in place to a reference-keyed
     ``state_dict``: the reference initialisation is degenerate for parity work

@@ -247,6 +247,22 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
                               const uint16_t *wpack, const float *bias,
                               const bevmsda_linear_desc *desc, float *y, void *stream);
 
+/* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
+ *
+ * bevmsda_rotate_bev_f32: dst = rotate(src) of an (H, W) grid of C-float rows (row p at
+ * ptr + p * ld) with nearest sampling and zero fill: torchvision.transforms.functional.rotate
+ * as called on prev_bev at transformer.py:146-156.  theta = the 2 x 3 inverse affine matrix in
+ * torchvision's normalised form (row 0 divided by W/2, row 1 by H/2: `rescaled_theta` of
+ * _gen_affine_grid), computed by the caller from (angle, center).  C = 256 or 512; src != dst.
+ *
+ * bevmsda_flatten_feats_f32: one feature level feat (bs, Nc, C, hw) -> rows [s0, s0 + hw) of
+ * out (Nc, S, bs, C), adding cams_embeds[cam] (Nc, C; may be NULL) and then level_embed (C; may
+ * be NULL) — transformer.py:165-184.  C a multiple of 64. */
+int bevmsda_rotate_bev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W,
+                           int C, const float *theta, void *stream);
+int bevmsda_flatten_feats_f32(const float *feat, const float *cams_embeds, const float *level_embed,
+                              float *out, int bs, int Nc, int C, int hw, int S, int s0, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,17 @@ CPU tensors, what these reference files compute (all paths relative to
   temporal_self_attention.py:128-272
   spatial_cross_attention.py:76-175, 273-399
   custom_base_transformer_layer.py:72-163   (FFN/LayerNorm construction)
+  transformer.py:104-200      PerceptionTransformer.get_bev_features (the encoder's caller:
+                              ego-motion shift, prev-BEV rotation, can-bus MLP, camera /
+                              level embeddings, flatten) — SURVEY.md §8f rank 1
   mmcv-full 1.4.0 (not on disk): multi_scale_deformable_attn_pytorch, FFN
+  torchvision 0.10.1 (not on disk; docs/install.md:15 pins torch 1.9.1 whose matching
+                              torchvision is 0.10.1): transforms.functional.rotate — PARITY
+                              UNPINNED for this one function: restated from its published
+                              algorithm in ``rotate_nearest`` below; the reference's own
+                              transformer.py is executed with this restatement bound to the
+                              name ``rotate`` (oracle/mmcv_stub.py), which pins everything
+                              around it but not its inside.
 
 Pinning status: the reference ships no tests or golden vectors for this path
 (SURVEY.md §4, §8c), so this restatement is pinned against the reference's own
@@ -276,3 +286,121 @@ def encoder_forward(sd, bev_query, feats, *, bev_h, bev_w, bev_pos, spatial_shap
                           bev_h, bev_w, spatial_shapes, prev, msda=msda)
         inter.append(x)
     return torch.stack(inter) if return_intermediate else x
+
+
+# --------------------------------------------------------------------------
+# PerceptionTransformer.get_bev_features (transformer.py:104-200)
+# --------------------------------------------------------------------------
+
+def _inverse_affine_matrix(center, angle_deg):
+    """torchvision.transforms.functional._get_inverse_affine_matrix for a pure rotation
+    (translate 0, scale 1, shear 0): [d, -b, ., -c, a, .] with the centre terms."""
+    rot = np.deg2rad(angle_deg)
+    cx, cy = center
+    a, b, c, d = np.cos(rot), -np.sin(rot), np.sin(rot), np.cos(rot)
+    m = [d, -b, 0.0, -c, a, 0.0]
+    m[2] += m[0] * (-cx) + m[1] * (-cy)
+    m[5] += m[3] * (-cx) + m[4] * (-cy)
+    m[2] += cx
+    m[5] += cy
+    return [float(v) for v in m]
+
+
+def rotate_source_index(h, w, angle_deg, center, device="cpu"):
+    """Source pixel of every output pixel of ``rotate(img (C,h,w), angle, center=center)``
+    with nearest interpolation, as flat indices (h*w,) int64, -1 where the source falls
+    outside the image (zero fill).  torchvision 0.10 algorithm: ``rotate`` negates the angle
+    and re-centres ``center`` on the image centre; ``_gen_affine_grid`` builds the output
+    grid from pixel centres; ``grid_sample(nearest, zeros, align_corners=False)``
+    un-normalises with ((g + 1) * size - 1) / 2 and rounds half to even."""
+    center_f = [1.0 * (c - s * 0.5) for c, s in zip(center, [w, h])]
+    theta = torch.tensor(_inverse_affine_matrix(center_f, -angle_deg), dtype=torch.float32,
+                         device=device).reshape(1, 2, 3)
+    d = 0.5
+    base = torch.empty(1, h, w, 3, dtype=torch.float32, device=device)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + d, w * 0.5 + d - 1, steps=w, device=device))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + d, h * 0.5 + d - 1, steps=h,
+                                      device=device).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32,
+                                                    device=device)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(h * w, 2)
+    ix = torch.round(((grid[:, 0] + 1) * w - 1) / 2)          # torch.round: half to even
+    iy = torch.round(((grid[:, 1] + 1) * h - 1) / 2)
+    ok = (ix >= 0) & (ix <= w - 1) & (iy >= 0) & (iy <= h - 1)
+    idx = (iy * w + ix).long()
+    return torch.where(ok, idx, torch.full_like(idx, -1))
+
+
+def rotate_nearest(img, angle_deg, center):
+    """``torchvision.transforms.functional.rotate(img (C,h,w), angle, center=center)`` with
+    its defaults (nearest, no expand, zero fill) — transformer.py:152-153."""
+    C, h, w = img.shape
+    idx = rotate_source_index(h, w, angle_deg, center, img.device)
+    flat = img.reshape(C, h * w)
+    out = flat[:, idx.clamp(min=0)] * (idx >= 0).to(img.dtype)
+    return out.view(C, h, w)
+
+
+def bev_shift(img_metas, bev_h, bev_w, grid_length=(0.512, 0.512), use_shift=True):
+    """Ego-motion shift of the BEV reference points (transformer.py:123-141) -> (bs, 2)
+    float64 numpy array (x, y)."""
+    delta_x = np.array([m["can_bus"][0] for m in img_metas])
+    delta_y = np.array([m["can_bus"][1] for m in img_metas])
+    ego_angle = np.array([m["can_bus"][-2] / np.pi * 180 for m in img_metas])
+    translation_length = np.sqrt(delta_x ** 2 + delta_y ** 2)
+    translation_angle = np.arctan2(delta_y, delta_x) / np.pi * 180
+    bev_angle = ego_angle - translation_angle
+    shift_y = translation_length * np.cos(bev_angle / 180 * np.pi) / grid_length[0] / bev_h
+    shift_x = translation_length * np.sin(bev_angle / 180 * np.pi) / grid_length[1] / bev_w
+    return np.stack([shift_x * use_shift, shift_y * use_shift], -1)
+
+
+def get_bev_features(tsd, esd, mlvl_feats, bev_queries, bev_h, bev_w, *, bev_pos, img_metas,
+                     pc_range, grid_length=(0.512, 0.512), prev_bev=None, rotate_prev_bev=True,
+                     use_shift=True, use_can_bus=True, can_bus_norm=True, use_cams_embeds=True,
+                     rotate_center=(100, 100), rotate_fn=rotate_nearest):
+    """PerceptionTransformer.get_bev_features (transformer.py:104-200).
+
+    ``tsd``: the transformer's own parameters (``level_embeds``, ``cams_embeds``,
+    ``can_bus_mlp.{0,2,norm}.*``); ``esd``: the encoder's state_dict (keys without the
+    ``encoder.`` prefix).  mlvl_feats: list of (bs, Nc, C, h, w); bev_queries (Q, C);
+    bev_pos (bs, C, bev_h, bev_w); prev_bev (Q, bs, C) or (bs, Q, C) or None -> (bs, Q, C)."""
+    bs = mlvl_feats[0].size(0)
+    bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+    bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+    shift = bev_queries.new_tensor(bev_shift(img_metas, bev_h, bev_w, grid_length, use_shift))
+    if prev_bev is not None:
+        if prev_bev.shape[1] == bev_h * bev_w:
+            prev_bev = prev_bev.permute(1, 0, 2)
+        if rotate_prev_bev:
+            prev_bev = prev_bev.clone()
+            for i in range(bs):
+                angle = img_metas[i]["can_bus"][-1]
+                tmp = prev_bev[:, i].reshape(bev_h, bev_w, -1).permute(2, 0, 1)
+                tmp = rotate_fn(tmp, angle, center=list(rotate_center))
+                prev_bev[:, i] = tmp.permute(1, 2, 0).reshape(bev_h * bev_w, -1)
+    can_bus = bev_queries.new_tensor(np.array([m["can_bus"] for m in img_metas]))
+    x = F.relu(F.linear(can_bus, tsd["can_bus_mlp.0.weight"], tsd["can_bus_mlp.0.bias"]))
+    x = F.relu(F.linear(x, tsd["can_bus_mlp.2.weight"], tsd["can_bus_mlp.2.bias"]))
+    if can_bus_norm:
+        x = F.layer_norm(x, (x.shape[-1],), tsd["can_bus_mlp.norm.weight"],
+                         tsd["can_bus_mlp.norm.bias"])
+    bev_queries = bev_queries + x[None] * use_can_bus
+    flat, shapes = [], []
+    for lvl, feat in enumerate(mlvl_feats):
+        _, num_cam, c, h, w = feat.shape
+        feat = feat.flatten(3).permute(1, 0, 3, 2)
+        if use_cams_embeds:
+            feat = feat + tsd["cams_embeds"][:, None, None, :].to(feat.dtype)
+        feat = feat + tsd["level_embeds"][None, None, lvl:lvl + 1, :].to(feat.dtype)
+        shapes.append((h, w))
+        flat.append(feat)
+    feat_flatten = torch.cat(flat, 2).permute(0, 2, 1, 3)
+    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long)
+    level_start_index = torch.cat((spatial_shapes.new_zeros((1,)),
+                                   spatial_shapes.prod(1).cumsum(0)[:-1]))
+    return encoder_forward(esd, bev_queries, feat_flatten, bev_h=bev_h, bev_w=bev_w,
+                           bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                           level_start_index=level_start_index, prev_bev=prev_bev, shift=shift,
+                           img_metas=img_metas, pc_range=pc_range)

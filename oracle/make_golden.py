@@ -3,7 +3,7 @@
 Every fixture is produced by the REFERENCE'S OWN FILES
 (/root/reference/projects/mmdet3d_plugin/bevformer/modules/{encoder,
 spatial_cross_attention,temporal_self_attention,custom_base_transformer_layer,
-multi_scale_deformable_attn_function}.py) executed unmodified on CPU under
+multi_scale_deformable_attn_function,transformer}.py) executed unmodified on CPU under
 oracle/mmcv_stub.py, on the seeded synthetic inputs of bevformer_amd/synthetic.py.
 Inputs and weights are NOT stored (they are regenerated from the seeds; their
 checksums are stored and verified by the tests), outputs are.
@@ -24,6 +24,7 @@ from oracle import mmcv_stub  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 ENCODER_CASES = [("micro", False), ("micro", True), ("micro4", False), ("micro4", True),
                  ("tiny", True)]
+TRANSFORMER_CASES = [("micro4", 1), ("micro", 2)]
 WEIGHT_SEED, INPUT_SEED = 3, 0
 
 
@@ -56,6 +57,37 @@ def main():
                     input_sha256=checksum(ins), weights_sha256=checksum([sd[k] for k in sorted(sd)]),
                     producer="reference files under oracle/mmcv_stub.py", torch=torch.__version__)
         path = os.path.join(OUT, f"encoder_{name}_{'hist' if temporal else 'first'}.pt")
+        torch.save(blob, path)
+        print(path, tuple(out.shape), os.path.getsize(path))
+
+    # the encoder's caller: the reference's PerceptionTransformer.get_bev_features
+    # (modules/transformer.py:104-200, unmodified; torchvision's rotate = the oracle's
+    # restatement, see the header of oracle/bevformer_cpu.py).  The encoder inside gets the
+    # same seeded weights as the encoder fixtures above; the transformer's own parameters
+    # (embeddings, can-bus MLP: 0.2 MB) are stored.
+    for name, bs in TRANSFORMER_CASES:
+        cfg = S.transformer_cfg(name)
+        ref = mmcv_stub.build_reference_transformer(
+            cfg["encoder"], num_feature_levels=cfg["num_feature_levels"],
+            rotate_center=cfg["rotate_center"])
+        torch.manual_seed(1)
+        ref.init_weights()
+        _, enc_sd = reference_state_dict(name)
+        ref.encoder.load_state_dict(enc_sd)
+        own = {k: v.clone() for k, v in ref.state_dict().items()
+               if not k.startswith(("encoder.", "decoder."))}
+        mlvl, bq, kw = S.make_transformer_inputs(name, seed=INPUT_SEED, bs=bs, temporal=True)
+        with torch.no_grad():
+            out = ref.get_bev_features(mlvl, bq, kw["bev_h"], kw["bev_w"], grid_length=kw["grid_length"],
+                                       bev_pos=kw["bev_pos"], prev_bev=kw["prev_bev"].clone(),
+                                       img_metas=kw["img_metas"])
+        blob = dict(workload=name, bs=bs, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED,
+                    output=out.clone(), own_parameters=own,
+                    input_sha256=checksum(mlvl + [bq, kw["bev_pos"], kw["prev_bev"]]),
+                    weights_sha256=checksum([enc_sd[k] for k in sorted(enc_sd)]),
+                    producer="reference transformer.py + encoder files under oracle/mmcv_stub.py",
+                    torch=torch.__version__)
+        path = os.path.join(OUT, f"bev_features_{name}_bs{bs}.pt")
         torch.save(blob, path)
         print(path, tuple(out.shape), os.path.getsize(path))
 

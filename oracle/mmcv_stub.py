@@ -155,6 +155,7 @@ def install(ext_module=None):
 
     regs = {n: _Registry(n) for n in ("ATTENTION", "TRANSFORMER_LAYER", "TRANSFORMER_LAYER_SEQUENCE",
                                       "FEEDFORWARD_NETWORK", "POSITIONAL_ENCODING")}
+    transformer_registry = _Registry("Transformer")
 
     def build_attention(cfg, default_args=None):
         return _build_from_cfg(cfg, regs["ATTENTION"], default_args)
@@ -270,7 +271,36 @@ def install(ext_module=None):
                 "projects.mmdet3d_plugin.models.utils", "projects.mmdet3d_plugin.bevformer"):
         mod(pkg, __path__=[])
     mod("projects.mmdet3d_plugin.models.utils.bricks", run_time=run_time)
+    mod("projects.mmdet3d_plugin.models.utils.visual", save_tensor=lambda *a, **k: None)
     mod("projects.mmdet3d_plugin.bevformer.modules", __path__=[_MODULES_DIR])
+
+    # what modules/transformer.py (the encoder's caller) and decoder.py
+    # import on top of the above: mmdet's TRANSFORMER registry, torchvision's rotate (absent
+    # here: bound to the oracle's restatement, oracle/bevformer_cpu.py::rotate_nearest), and
+    # two plotting / image libraries decoder.py imports without using on this path
+    for pkg in ("mmdet", "mmdet.models", "mmdet.models.utils"):
+        mod(pkg, __path__=[])
+    mod("mmdet.models.utils.builder", TRANSFORMER=transformer_registry)
+    if "torchvision" not in sys.modules:
+        for pkg in ("torchvision", "torchvision.transforms"):
+            mod(pkg, __path__=[], __bevformer_amd_stub__=True)
+        mod("torchvision.transforms.functional", rotate=bevformer_cpu.rotate_nearest)
+    if "cv2" not in sys.modules:
+        try:
+            import cv2  # noqa: F401
+        except ImportError:
+            mod("cv2")
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except ImportError:
+        mod("matplotlib", __path__=[])
+        mod("matplotlib.pyplot")
+
+    @regs["TRANSFORMER_LAYER_SEQUENCE"].register_module()
+    class NullDecoder(_BaseModule):
+        """Placeholder for ``decoder=dict(type='NullDecoder')``: get_bev_features never
+        touches the decoder, but PerceptionTransformer.__init__ builds one
+        (transformer.py:54)."""
     return mmcv
 
 
@@ -295,6 +325,19 @@ def load_reference(ext_module=None):
         build_transformer_layer_sequence=sys.modules["mmcv.cnn.bricks.transformer"]
         .build_transformer_layer_sequence)
     return ns
+
+
+def build_reference_transformer(encoder_cfg, ext_module=None, **kwargs):
+    """The reference's own ``PerceptionTransformer`` (modules/transformer.py, unmodified) around
+    the reference encoder built from ``encoder_cfg``; ``torchvision...rotate`` is the oracle's
+    restatement (torchvision is not installed here)."""
+    load_reference(ext_module)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod = importlib.import_module("projects.mmdet3d_plugin.bevformer.modules.transformer")
+        t = mod.PerceptionTransformer(encoder=copy.deepcopy(encoder_cfg),
+                                      decoder=dict(type="NullDecoder"), **kwargs)
+    return t.eval()
 
 
 def build_reference_encoder(cfg, ext_module=None):

@@ -64,19 +64,46 @@ def _oracle_gather_mean(rows, idx, scale):
     return out * scale.reshape(-1, 1)
 
 
+def _oracle_rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
+    out = prev_bev.clone()
+    for i in range(prev_bev.shape[1]):
+        img = prev_bev[:, i].reshape(bev_h, bev_w, -1).permute(2, 0, 1)
+        out[:, i] = O.rotate_nearest(img, angles_deg[i], center).permute(1, 2, 0).reshape(bev_h * bev_w, -1)
+    return out
+
+
+def _oracle_flatten_feats(mlvl_feats, cams_embeds, level_embeds):
+    """Contract of ``bevmsda_flatten_feats_f32`` in torch ops (transformer.py:165-184)."""
+    flat, shapes = [], []
+    for lvl, feat in enumerate(mlvl_feats):
+        h, w = feat.shape[3:]
+        feat = feat.flatten(3).permute(1, 0, 3, 2)
+        if cams_embeds is not None:
+            feat = feat + cams_embeds[:, None, None, :]
+        feat = feat + level_embeds[None, None, lvl:lvl + 1, :]
+        shapes.append((h, w))
+        flat.append(feat)
+    out = torch.cat(flat, 2).permute(0, 2, 1, 3).contiguous()
+    ss = torch.as_tensor(shapes, dtype=torch.long)
+    return out, ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+
+
 @contextlib.contextmanager
 def oracle_ops():
     """Route the package's operator calls through the CPU oracle so that the
     HOST logic of the modules (ragged rows, merged GEMMs, geometry, plans,
     tiling) can be parity-tested without a GPU.  Test-only: the product path
     itself has no CPU implementation."""
-    saved = (ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean)
-    ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean = \
-        _oracle_msda, _oracle_msda_ragged, _oracle_msda_fused, _oracle_gather_mean
+    saved = (ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean, ops.rotate_bev,
+             ops.flatten_feats)
+    ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean, ops.rotate_bev, ops.flatten_feats = \
+        _oracle_msda, _oracle_msda_ragged, _oracle_msda_fused, _oracle_gather_mean, \
+        _oracle_rotate_bev, _oracle_flatten_feats
     try:
         yield
     finally:
-        ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean = saved
+        (ops.msda, ops.msda_ragged, ops.msda_fused, ops.gather_mean, ops.rotate_bev,
+         ops.flatten_feats) = saved
 
 
 def build_pair(name, seed=3, device="cpu"):
@@ -89,3 +116,27 @@ def build_pair(name, seed=3, device="cpu"):
     S.trained_like_(sd, seed=seed)
     enc.load_state_dict(sd)
     return enc.to(device), sd
+
+
+def build_transformer_pair(name, seed=3, device="cpu"):
+    """(product PerceptionTransformer, its state_dict with trained-like encoder weights and
+    N(0,1)-scale embeddings / can-bus MLP)."""
+    import bevformer_amd
+    from bevformer_amd import synthetic as S
+    torch.manual_seed(0)
+    t = bevformer_amd.build_transformer(S.transformer_cfg(name)).eval()
+    t.init_weights()
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    S.trained_like_(enc, seed=seed)
+    for k, v in enc.items():
+        sd["encoder." + k] = v
+    t.load_state_dict(sd)
+    return t.to(device), sd
+
+
+def split_transformer_sd(sd):
+    """-> (transformer-own parameters, encoder state_dict without the prefix)."""
+    own = {k: v for k, v in sd.items() if not k.startswith(("encoder.", "decoder."))}
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    return own, enc

@@ -97,3 +97,54 @@ def test_hip_operator_matches_fixture_on_gpu():
         torch.testing.assert_close(gv.cpu(), c["grad_value"], rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(ga.cpu(), c["grad_attn"], rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(gl.cpu(), c["grad_loc"], rtol=1e-3, atol=1e-3)
+
+
+# -- the encoder's caller (PerceptionTransformer.get_bev_features) --------
+
+BEVF = ["bev_features_micro4_bs1", "bev_features_micro_bs2"]
+
+
+def _regenerate_transformer(blob):
+    name, bs = blob["workload"], blob["bs"]
+    t = bevformer_amd.build_transformer(S.transformer_cfg(name)).eval()
+    torch.manual_seed(0)
+    enc0 = bevformer_amd.build_transformer_layer_sequence(S.encoder_cfg(name))
+    enc = S.trained_like_({k: v.clone() for k, v in enc0.state_dict().items()},
+                          seed=blob["weight_seed"])
+    assert _sha([enc[k] for k in sorted(enc)]) == blob["weights_sha256"], "seeded weights differ"
+    sd = dict(blob["own_parameters"])
+    sd.update({"encoder." + k: v for k, v in enc.items()})
+    t.load_state_dict(sd)
+    mlvl, bq, kw = S.make_transformer_inputs(name, seed=blob["input_seed"], bs=bs, temporal=True)
+    assert _sha(mlvl + [bq, kw["bev_pos"], kw["prev_bev"]]) == blob["input_sha256"], \
+        "seeded inputs differ from the fixture's"
+    return t, sd, mlvl, bq, kw
+
+
+@pytest.mark.parametrize("fixture", BEVF)
+def test_oracle_reproduces_reference_bev_features(fixture):
+    blob = torch.load(os.path.join(GOLD, fixture + ".pt"), weights_only=False)
+    t, sd, mlvl, bq, kw = _regenerate_transformer(blob)
+    own = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    w = S.WORKLOADS[blob["workload"]]
+    got = O.get_bev_features(own, enc, mlvl, bq, kw["bev_h"], kw["bev_w"], bev_pos=kw["bev_pos"],
+                             img_metas=kw["img_metas"], pc_range=S.PC_RANGE,
+                             grid_length=kw["grid_length"], prev_bev=kw["prev_bev"],
+                             rotate_center=(w["bev_w"] // 2, w["bev_h"] // 2))
+    assert torch.equal(got, blob["output"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", BEVF)
+def test_product_bev_features_match_fixture_on_gpu(fixture):
+    """The product PerceptionTransformer.get_bev_features (rotation and flatten kernels, the
+    whole encoder) against the reference's own output: same tolerance as the encoder fixtures."""
+    blob = torch.load(os.path.join(GOLD, fixture + ".pt"), weights_only=False)
+    t, _, mlvl, bq, kw = _regenerate_transformer(blob)
+    dev = torch.device("cuda:0")
+    t = t.to(dev)
+    kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    with torch.no_grad():
+        got = t.get_bev_features([f.to(dev) for f in mlvl], bq.to(dev), **kw).cpu()
+    torch.testing.assert_close(got, blob["output"], rtol=1e-3, atol=1e-3)

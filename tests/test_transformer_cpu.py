@@ -1,0 +1,107 @@
+"""PerceptionTransformer.get_bev_features on CPU: the oracle's
+restatement against the reference's own transformer.py (build container only), and the host
+logic of the product class against the oracle with the kernels routed through the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from bevformer_amd import synthetic as S
+from oracle import bevformer_cpu as O
+from oracle import mmcv_stub
+
+from helpers import build_transformer_pair, oracle_ops, split_transformer_sd
+
+
+def _oracle_bev(sd, mlvl, bq, kw, name, **flags):
+    own, enc = split_transformer_sd(sd)
+    w = S.WORKLOADS[name]
+    return O.get_bev_features(own, enc, mlvl, bq, kw["bev_h"], kw["bev_w"], bev_pos=kw["bev_pos"],
+                              img_metas=kw["img_metas"], pc_range=S.PC_RANGE,
+                              grid_length=kw["grid_length"], prev_bev=kw["prev_bev"],
+                              rotate_center=(w["bev_w"] // 2, w["bev_h"] // 2), **flags)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name,bs", [("micro", 1), ("micro4", 2)])
+@pytest.mark.parametrize("temporal", [False, True])
+def test_oracle_prologue_matches_reference_file(name, bs, temporal):
+    """The reference's PerceptionTransformer.get_bev_features, unmodified, under the stub
+    (torchvision's rotate bound to the oracle's restatement) == the oracle's function."""
+    cfg = S.transformer_cfg(name)
+    ref = mmcv_stub.build_reference_transformer(
+        cfg["encoder"], num_feature_levels=cfg["num_feature_levels"], rotate_center=cfg["rotate_center"])
+    torch.manual_seed(1)
+    ref.init_weights()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    own, enc = split_transformer_sd(sd)
+    S.trained_like_(enc, seed=3)
+    sd.update({"encoder." + k: v for k, v in enc.items()})
+    ref.load_state_dict(sd)
+    mlvl, bq, kw = S.make_transformer_inputs(name, seed=0, bs=bs, temporal=temporal)
+    with torch.no_grad():
+        prev = None if kw["prev_bev"] is None else kw["prev_bev"].clone()   # the reference rotates in place
+        want = ref.get_bev_features(mlvl, bq, kw["bev_h"], kw["bev_w"], grid_length=kw["grid_length"],
+                                    bev_pos=kw["bev_pos"], prev_bev=prev, img_metas=kw["img_metas"])
+        got = _oracle_bev(sd, mlvl, bq, kw, name)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.reference
+def test_product_transformer_has_reference_parameters():
+    cfg = S.transformer_cfg("micro4")
+    ref = mmcv_stub.build_reference_transformer(
+        cfg["encoder"], num_feature_levels=cfg["num_feature_levels"], rotate_center=cfg["rotate_center"])
+    mine, _ = build_transformer_pair("micro4")
+    a, b = mine.state_dict(), ref.state_dict()
+    assert list(a) == list(b)
+    assert all(a[k].shape == b[k].shape for k in a)
+
+
+@pytest.mark.parametrize("name,bs,temporal", [("micro", 1, True), ("micro4", 2, True), ("micro4", 1, False)])
+def test_product_prologue_host_logic(name, bs, temporal):
+    t, sd = build_transformer_pair(name)
+    mlvl, bq, kw = S.make_transformer_inputs(name, seed=1, bs=bs, temporal=temporal)
+    prev_before = None if kw["prev_bev"] is None else kw["prev_bev"].clone()
+    with torch.no_grad(), oracle_ops():
+        got = t.get_bev_features(mlvl, bq, **kw)
+        want = _oracle_bev(sd, mlvl, bq, kw, name)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+    if temporal:      # unlike the reference, the caller's prev_bev is left untouched
+        assert torch.equal(kw["prev_bev"], prev_before)
+
+
+def test_switches_follow_the_reference_flags():
+    t, sd = build_transformer_pair("micro")
+    t.use_shift = t.use_can_bus = t.use_cams_embeds = t.rotate_prev_bev = False
+    mlvl, bq, kw = S.make_transformer_inputs("micro", seed=2, temporal=True)
+    with torch.no_grad(), oracle_ops():
+        got = t.get_bev_features(mlvl, bq, **kw)
+        want = _oracle_bev(sd, mlvl, bq, kw, "micro", use_shift=False, use_can_bus=False,
+                           use_cams_embeds=False, rotate_prev_bev=False)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_rotation_restatement_properties():
+    """torchvision is not installed: the restated nearest-neighbour rotate is checked on what
+    must hold for any correct implementation — identity at 0 degrees, exact quarter turns about
+    the pixel-grid centre, zero fill outside, and inverse consistency of the index map."""
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(3, 8, 8, generator=g)
+    assert torch.equal(O.rotate_nearest(img, 0.0, [4, 4]), img)
+    # centre (4, 4) in pixel-corner coordinates = the exact centre of an 8 x 8 grid:
+    # +90 degrees is counter-clockwise in image coordinates (torchvision convention)
+    assert torch.equal(O.rotate_nearest(img, 90.0, [4, 4]), torch.rot90(img, 1, (1, 2)))
+    assert torch.equal(O.rotate_nearest(img, 180.0, [4, 4]), torch.rot90(img, 2, (1, 2)))
+    idx = O.rotate_source_index(12, 10, 33.0, [5, 6])
+    assert (idx == -1).any() and (idx >= 0).any() and idx.max() < 120
+    out = O.rotate_nearest(torch.ones(1, 12, 10), 33.0, [5, 6])
+    assert torch.equal(out.flatten() == 0, idx == -1)
+
+
+def test_shift_matches_closed_form():
+    metas = S.make_img_metas("micro")
+    metas[0]["can_bus"] = S.make_can_bus(0)
+    sh = O.bev_shift(metas, 12, 10)
+    # |t| = 2.5 m, heading 0.3 rad vs motion direction atan2(1.5, 2.0)
+    ang = 0.3 - np.arctan2(1.5, 2.0)
+    np.testing.assert_allclose(sh[0], [2.5 * np.sin(ang) / 0.512 / 10, 2.5 * np.cos(ang) / 0.512 / 12], rtol=1e-12)
