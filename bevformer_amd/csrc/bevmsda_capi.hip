@@ -585,7 +585,9 @@ int bevmsda_flatten_feats_f32(const float *feat, const float *cams_embeds, const
   a.feat = feat; a.cams_embeds = cams_embeds; a.level_embed = level_embed; a.out = out;
   a.bs = bs; a.Nc = Nc; a.C = C; a.hw = hw; a.S = S; a.s0 = s0;
   const dim3 grid(static_cast<unsigned>((hw + 63) / 64), static_cast<unsigned>(C / 64), static_cast<unsigned>(bz));
-  hipLaunchKernelGGL(bevmsda::flatten_feats_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const bool vec = hw % 4 == 0 && !misaligned(feat);
+  if (vec) hipLaunchKernelGGL(bevmsda::flatten_feats_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(bevmsda::flatten_feats_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

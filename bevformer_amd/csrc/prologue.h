@@ -64,18 +64,31 @@ struct FlattenArgs {
   int bs, Nc, C, hw, S, s0; // s0: first row of this level inside S
 };
 
-// grid: (ceil(hw / 64), C / 64, bs * Nc); 256 threads
+// grid: (ceil(hw / 64), C / 64, bs * Nc); 256 threads.  VEC: 16-byte loads along the pixel axis
+// (hw % 4 == 0 and a 16-byte aligned level: the two fine levels, 94 % of the bytes).
+template <bool VEC>
 __global__ void __launch_bounds__(256) flatten_feats_kernel(const FlattenArgs a) {
   __shared__ float tile[64][65];          // [channel][pixel], +1 pad: conflict-free transposed reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int b = blockIdx.z / a.Nc, cam = blockIdx.z % a.Nc;
   const float *src = a.feat + (static_cast<long>(blockIdx.z) * a.C + c0) * a.hw;
-  const int p = p0 + lane;
+  if (VEC) {
+    const int pq = (tid & 15) * 4;        // 16 lanes x float4 = one 256-byte row piece
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = wave * 16 + i;
-    tile[c][lane] = p < a.hw ? src[static_cast<long>(c) * a.hw + p] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int c = (tid >> 4) + 16 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + pq < a.hw) v = *reinterpret_cast<const float4 *>(src + static_cast<long>(c) * a.hw + p0 + pq);
+      tile[c][pq] = v.x; tile[c][pq + 1] = v.y; tile[c][pq + 2] = v.z; tile[c][pq + 3] = v.w;
+    }
+  } else {
+    const int p = p0 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = wave * 16 + i;
+      tile[c][lane] = p < a.hw ? src[static_cast<long>(c) * a.hw + p] : 0.f;
+    }
   }
   __syncthreads();
   const int c4 = (tid & 15) * 4;
