@@ -244,7 +244,10 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             fence()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: the RCCL watchdog thread keeps polling events of earlier eager
+            # collectives; in the default "global" mode its hipEventQuery during our capture
+            # aborts the process ("operation not permitted when stream is capturing")
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g_out = step()
             graph.replay()
             fence()
@@ -323,9 +326,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.first_frame)
             line["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if world > 1 or args.force_tiling:
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes a version banner through C stdio, flushed at exit: push it out first so
+        # that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
