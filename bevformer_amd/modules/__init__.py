@@ -2,6 +2,7 @@
 (same names as projects/mmdet3d_plugin/bevformer/modules/__init__.py:3-5)."""
 from .bricks import FFN
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
+from .decoder import CustomMSDeformableAttention, DetectionTransformerDecoder
 from .encoder import BEVFormerEncoder, BEVFormerLayer
 from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
 from .temporal_self_attention import TemporalSelfAttention
@@ -9,4 +10,5 @@ from .transformer import PerceptionTransformer
 
 __all__ = ["BEVFormerEncoder", "BEVFormerLayer", "SpatialCrossAttention",
            "MSDeformableAttention3D", "TemporalSelfAttention", "MyCustomBaseTransformerLayer",
-           "FFN", "PerceptionTransformer"]
+           "FFN", "PerceptionTransformer", "CustomMSDeformableAttention",
+           "DetectionTransformerDecoder"]

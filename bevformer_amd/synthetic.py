@@ -134,6 +134,35 @@ def make_inputs(name, seed=0, bs=1, temporal=False, device="cpu", dtype=torch.fl
     return mv(bev_query), mv(feat), kwargs
 
 
+def decoder_cfg(num_layers=2, num_levels=1):
+    """A ``DetectionTransformerDecoder`` config in the style of bevformer_base.py:106-130 whose
+    layers only use classes that live in the reference tree: cross-attention into the BEV grid
+    (``CustomMSDeformableAttention``), norm, FFN, norm (the configs' self-attention is mmcv's
+    ``MultiheadAttention`` inside mmdet's ``DetrTransformerDecoderLayer`` — third-party)."""
+    return dict(
+        type="DetectionTransformerDecoder", num_layers=num_layers, return_intermediate=True,
+        transformerlayers=dict(
+            type="MyCustomBaseTransformerLayer", batch_first=False,     # (num_query, bs, C) layout,
+            attn_cfgs=[dict(type="CustomMSDeformableAttention", embed_dims=EMBED_DIMS,   # as the decoder
+                            num_levels=num_levels)],
+            feedforward_channels=EMBED_DIMS * 2, ffn_dropout=0.1,
+            operation_order=("cross_attn", "norm", "ffn", "norm")))
+
+
+def make_decoder_inputs(bev_h, bev_w, num_query=37, bs=2, seed=0, device="cpu"):
+    """query / query_pos (nq, bs, C), value = bev_embed (Q, bs, C), reference_points
+    (bs, nq, 3) in (0, 1), the (1, 2) / (1,) BEV level tensors (transformer.py:274-284)."""
+    g = torch.Generator().manual_seed(seed)
+    Q = bev_h * bev_w
+    query = torch.randn(num_query, bs, EMBED_DIMS, generator=g)
+    query_pos = torch.randn(num_query, bs, EMBED_DIMS, generator=g)
+    value = torch.randn(Q, bs, EMBED_DIMS, generator=g)
+    ref = torch.rand(bs, num_query, 3, generator=g) * 0.9 + 0.05
+    shapes = torch.tensor([[bev_h, bev_w]], dtype=torch.long)
+    start = torch.tensor([0], dtype=torch.long)
+    return [t.to(device) for t in (query, query_pos, value, ref, shapes, start)]
+
+
 def transformer_cfg(name):
     """The ``transformer=dict(type='PerceptionTransformer', ...)`` block of the reference
     configs (projects/configs/bevformer/bevformer_base.py:70-106) around ``encoder_cfg(name)``,

@@ -16,6 +16,8 @@ CPU tensors, what these reference files compute (all paths relative to
   transformer.py:104-200      PerceptionTransformer.get_bev_features (the encoder's caller:
                               ego-motion shift, prev-BEV rotation, can-bus MLP, camera /
                               level embeddings, flatten) — SURVEY.md §8f rank 1
+  decoder.py:53-129, 133-345  DetectionTransformerDecoder layer loop / reference-point
+                              refinement, CustomMSDeformableAttention — SURVEY.md §8f rank 3
   mmcv-full 1.4.0 (not on disk): multi_scale_deformable_attn_pytorch, FFN
   torchvision 0.10.1 (not on disk; docs/install.md:15 pins torch 1.9.1 whose matching
                               torchvision is 0.10.1): transforms.functional.rotate — PARITY
@@ -404,3 +406,66 @@ def get_bev_features(tsd, esd, mlvl_feats, bev_queries, bev_h, bev_w, *, bev_pos
                            bev_pos=bev_pos, spatial_shapes=spatial_shapes,
                            level_start_index=level_start_index, prev_bev=prev_bev, shift=shift,
                            img_metas=img_metas, pc_range=pc_range)
+
+
+# --------------------------------------------------------------------------
+# decoder.py: CustomMSDeformableAttention (:133-345), DetectionTransformerDecoder (:53-129)
+# --------------------------------------------------------------------------
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def custom_ms_deformable_attention(sd, pre, query, value, reference_points, spatial_shapes, *,
+                                   query_pos=None, identity=None, num_heads=8, num_levels=1,
+                                   num_points=4, batch_first=False, msda=msda_gridsample):
+    """decoder.py:247-345 (eval mode: dropout is the identity).  query (nq, bs, C), value
+    (nv, bs, C) unless batch_first; reference_points (bs, nq, L, 2 | 4)."""
+    if value is None:
+        value = query
+    if identity is None:
+        identity = query
+    if query_pos is not None:
+        query = query + query_pos
+    if not batch_first:
+        query = query.permute(1, 0, 2)
+        value = value.permute(1, 0, 2)
+    bs, nq, _ = query.shape
+    nv = value.shape[1]
+    M, L, P = num_heads, num_levels, num_points
+    v = _lin(sd, pre + "value_proj", value).view(bs, nv, M, -1)
+    off = _lin(sd, pre + "sampling_offsets", query).view(bs, nq, M, L, P, 2)
+    att = _lin(sd, pre + "attention_weights", query).view(bs, nq, M, L * P).softmax(-1)
+    att = att.view(bs, nq, M, L, P)
+    if reference_points.shape[-1] == 2:
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    else:
+        loc = reference_points[:, :, None, :, None, :2] \
+            + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
+    out = _lin(sd, pre + "output_proj", msda(v, spatial_shapes, loc, att))
+    if not batch_first:
+        out = out.permute(1, 0, 2)
+    return out + identity
+
+
+def detection_decoder(layer_fns, query, reference_points, reg_branches=None,
+                      return_intermediate=False):
+    """decoder.py:89-129 over ``layer_fns[lid](output, reference_points_input)``."""
+    output, inter, inter_ref = query, [], []
+    for lid, fn in enumerate(layer_fns):
+        output = fn(output, reference_points[..., :2].unsqueeze(2)).permute(1, 0, 2)
+        if reg_branches is not None:
+            tmp = reg_branches[lid](output)
+            new = torch.zeros_like(reference_points)
+            new[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
+            new[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
+            reference_points = new.sigmoid().detach()
+        output = output.permute(1, 0, 2)
+        if return_intermediate:
+            inter.append(output)
+            inter_ref.append(reference_points)
+    if return_intermediate:
+        return torch.stack(inter), torch.stack(inter_ref)
+    return output, reference_points

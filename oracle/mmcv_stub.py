@@ -340,6 +340,24 @@ def build_reference_transformer(encoder_cfg, ext_module=None, **kwargs):
     return t.eval()
 
 
+def load_reference_decoder(ext_module=None):
+    """The reference's own decoder.py (unmodified): namespace with
+    ``CustomMSDeformableAttention``, ``DetectionTransformerDecoder``, ``inverse_sigmoid`` and the
+    stub's builders (its layers can be the reference's ``MyCustomBaseTransformerLayer``)."""
+    load_reference(ext_module)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = "projects.mmdet3d_plugin.bevformer.modules."
+        dec = importlib.import_module(base + "decoder")
+        importlib.import_module(base + "custom_base_transformer_layer")
+    return types.SimpleNamespace(
+        module=dec, CustomMSDeformableAttention=dec.CustomMSDeformableAttention,
+        DetectionTransformerDecoder=dec.DetectionTransformerDecoder,
+        inverse_sigmoid=dec.inverse_sigmoid,
+        build_transformer_layer_sequence=sys.modules["mmcv.cnn.bricks.transformer"]
+        .build_transformer_layer_sequence)
+
+
 def build_reference_encoder(cfg, ext_module=None):
     ns = load_reference(ext_module)
     with warnings.catch_warnings():
