@@ -6,9 +6,9 @@ from .decoder import CustomMSDeformableAttention, DetectionTransformerDecoder
 from .encoder import BEVFormerEncoder, BEVFormerLayer
 from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
 from .temporal_self_attention import TemporalSelfAttention
-from .transformer import PerceptionTransformer
+from .transformer import PerceptionTransformer, PerceptionTransformerBEVEncoder
 
 __all__ = ["BEVFormerEncoder", "BEVFormerLayer", "SpatialCrossAttention",
            "MSDeformableAttention3D", "TemporalSelfAttention", "MyCustomBaseTransformerLayer",
-           "FFN", "PerceptionTransformer", "CustomMSDeformableAttention",
+           "FFN", "PerceptionTransformer", "PerceptionTransformerBEVEncoder", "CustomMSDeformableAttention",
            "DetectionTransformerDecoder"]

@@ -151,3 +151,73 @@ class PerceptionTransformer(BaseModule):
             spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
             level_start_index=torch.tensor([0], device=query.device), **kwargs)
         return bev_embed, inter_states, init_reference_out, inter_references
+
+
+@TRANSFORMER.register_module(force=True)
+class PerceptionTransformerBEVEncoder(BaseModule):
+    """The BEVFormerV2 client of the same encoder (modules/transformerV2.py:55-173): camera /
+    level embeddings + flatten (``ops.flatten_feats``) and one encoder call without history
+    (temporal fusion happens outside, in ``PerceptionTransformerV2``'s ``ResNetFusion``).  The
+    training-time BEV-augmentation resampling (:143-172) stays a torch ``grid_sample``."""
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300, encoder=None,
+                 embed_dims=256, use_cams_embeds=True, rotate_center=[100, 100], **kwargs):
+        super().__init__(**kwargs)
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.embed_dims = embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.fp16_enabled = False
+        self.use_cams_embeds = use_cams_embeds
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.rotate_center = rotate_center
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
+        if self.use_cams_embeds:
+            self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (MSDeformableAttention3D, TemporalSelfAttention)) \
+                    or type(m).__name__ == "CustomMSDeformableAttention":
+                try:
+                    m.init_weight()
+                except AttributeError:
+                    m.init_weights()
+        nn.init.normal_(self.level_embeds)
+        if self.use_cams_embeds:
+            nn.init.normal_(self.cams_embeds)
+
+    def forward(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512], bev_pos=None,
+                prev_bev=None, **kwargs):
+        """-> (bs, bev_h * bev_w, C); ``prev_bev`` is accepted and ignored, as in the reference."""
+        bs = mlvl_feats[0].size(0)
+        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        feat_flatten, spatial_shapes, level_start_index = ops.flatten_feats(
+            mlvl_feats, self.cams_embeds if self.use_cams_embeds else None, self.level_embeds)
+        bev_embed = self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
+                                 bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                                 level_start_index=level_start_index, prev_bev=None,
+                                 shift=bev_queries.new_tensor([0, 0]).unsqueeze(0), **kwargs)
+        prev_bev = bev_embed
+        meta0 = kwargs["img_metas"][0]
+        if "aug_param" in meta0 and "GlobalRotScaleTransImage_param" in meta0["aug_param"]:
+            rot_angle, scale_ratio, flip_dx, flip_dy, bda_mat, only_gt = \
+                meta0["aug_param"]["GlobalRotScaleTransImage_param"]
+            prev_bev = prev_bev.reshape(bs, bev_h, bev_w, -1).permute(0, 3, 1, 2)
+            if only_gt:
+                ref_y, ref_x = torch.meshgrid(
+                    torch.linspace(0.5, bev_h - 0.5, bev_h, dtype=bev_queries.dtype, device=bev_queries.device),
+                    torch.linspace(0.5, bev_w - 0.5, bev_w, dtype=bev_queries.dtype, device=bev_queries.device),
+                    indexing="ij")
+                grid = torch.stack((ref_x / bev_w, ref_y / bev_h), -1)
+                grid_shift = (grid * 2.0 - 1.0).unsqueeze(0).unsqueeze(-1)
+                mat = bda_mat[:2, :2].to(grid_shift).view(1, 1, 1, 2, 2).repeat(
+                    grid_shift.shape[0], grid_shift.shape[1], grid_shift.shape[2], 1, 1)
+                grid_shift = torch.matmul(mat, grid_shift).squeeze(-1)
+                prev_bev = torch.nn.functional.grid_sample(prev_bev, grid_shift, align_corners=False)
+            prev_bev = prev_bev.reshape(bs, -1, bev_h * bev_w).permute(0, 2, 1)
+        return prev_bev

@@ -275,33 +275,66 @@ def install(ext_module=None):
     mod("projects.mmdet3d_plugin.bevformer.modules", __path__=[_MODULES_DIR])
 
     # what modules/transformer.py (the encoder's caller) and decoder.py
-    # import on top of the above: mmdet's TRANSFORMER registry, torchvision's rotate (absent
-    # here: bound to the oracle's restatement, oracle/bevformer_cpu.py::rotate_nearest), and
-    # two plotting / image libraries decoder.py imports without using on this path
+    # import on top of the above: mmdet's TRANSFORMER registry; torchvision's rotate and the
+    # two plotting / image libraries decoder.py imports without using are bound only while
+    # those files are being imported (_absent_third_party below), so that nothing else in the
+    # process ever sees a fake torchvision / cv2
     for pkg in ("mmdet", "mmdet.models", "mmdet.models.utils"):
         mod(pkg, __path__=[])
     mod("mmdet.models.utils.builder", TRANSFORMER=transformer_registry)
-    if "torchvision" not in sys.modules:
-        for pkg in ("torchvision", "torchvision.transforms"):
-            mod(pkg, __path__=[], __bevformer_amd_stub__=True)
-        mod("torchvision.transforms.functional", rotate=bevformer_cpu.rotate_nearest)
-    if "cv2" not in sys.modules:
-        try:
-            import cv2  # noqa: F401
-        except ImportError:
-            mod("cv2")
-    try:
-        import matplotlib.pyplot  # noqa: F401
-    except ImportError:
-        mod("matplotlib", __path__=[])
-        mod("matplotlib.pyplot")
-
+    # transformerV2.py imports mmdet's ResNet blocks and mmcv's conv builder for ResNetFusion
+    # (not on the encoder's path): import targets only
+    mod("mmdet.models.backbones", __path__=[])
+    mod("mmdet.models.backbones.resnet", Bottleneck=type("Bottleneck", (nn.Module,), {}),
+        BasicBlock=type("BasicBlock", (nn.Module,), {}))
+    sys.modules["mmcv.cnn"].build_conv_layer = lambda *a, **k: None
     @regs["TRANSFORMER_LAYER_SEQUENCE"].register_module()
     class NullDecoder(_BaseModule):
         """Placeholder for ``decoder=dict(type='NullDecoder')``: get_bev_features never
         touches the decoder, but PerceptionTransformer.__init__ builds one
         (transformer.py:54)."""
     return mmcv
+
+
+class _absent_third_party:
+    """While the reference's transformer.py / decoder.py are imported: ``torchvision``'s
+    ``rotate`` = the oracle's restatement (torchvision is not installed; bound at import by
+    ``from torchvision.transforms.functional import rotate``, transformer.py:18), and empty
+    ``cv2`` / ``matplotlib.pyplot`` import targets when those are missing (decoder.py:9,12).
+    Everything is removed from ``sys.modules`` again on exit."""
+
+    def __enter__(self):
+        from . import bevformer_cpu
+        self.added = []
+
+        def add(name, **attrs):
+            if name not in sys.modules:
+                m = types.ModuleType(name)
+                m.__dict__.update(attrs)
+                sys.modules[name] = m
+                self.added.append(name)
+        try:
+            import torchvision.transforms.functional  # noqa: F401
+        except ImportError:
+            add("torchvision", __path__=[])
+            add("torchvision.transforms", __path__=[])
+            add("torchvision.transforms.functional", rotate=bevformer_cpu.rotate_nearest)
+        for name in ("cv2",):
+            try:
+                importlib.import_module(name)
+            except ImportError:
+                add(name)
+        try:
+            importlib.import_module("matplotlib.pyplot")
+        except ImportError:
+            add("matplotlib", __path__=[])
+            add("matplotlib.pyplot")
+        return self
+
+    def __exit__(self, *exc):
+        for name in self.added:
+            sys.modules.pop(name, None)
+        return False
 
 
 def load_reference(ext_module=None):
@@ -332,11 +365,21 @@ def build_reference_transformer(encoder_cfg, ext_module=None, **kwargs):
     the reference encoder built from ``encoder_cfg``; ``torchvision...rotate`` is the oracle's
     restatement (torchvision is not installed here)."""
     load_reference(ext_module)
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), _absent_third_party():
         warnings.simplefilter("ignore")
         mod = importlib.import_module("projects.mmdet3d_plugin.bevformer.modules.transformer")
         t = mod.PerceptionTransformer(encoder=copy.deepcopy(encoder_cfg),
                                       decoder=dict(type="NullDecoder"), **kwargs)
+    return t.eval()
+
+
+def build_reference_bev_encoder_v2(encoder_cfg, ext_module=None, **kwargs):
+    """The reference's ``PerceptionTransformerBEVEncoder`` (modules/transformerV2.py, unmodified)."""
+    load_reference(ext_module)
+    with warnings.catch_warnings(), _absent_third_party():
+        warnings.simplefilter("ignore")
+        mod = importlib.import_module("projects.mmdet3d_plugin.bevformer.modules.transformerV2")
+        t = mod.PerceptionTransformerBEVEncoder(encoder=copy.deepcopy(encoder_cfg), **kwargs)
     return t.eval()
 
 
@@ -345,7 +388,7 @@ def load_reference_decoder(ext_module=None):
     ``CustomMSDeformableAttention``, ``DetectionTransformerDecoder``, ``inverse_sigmoid`` and the
     stub's builders (its layers can be the reference's ``MyCustomBaseTransformerLayer``)."""
     load_reference(ext_module)
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), _absent_third_party():
         warnings.simplefilter("ignore")
         base = "projects.mmdet3d_plugin.bevformer.modules."
         dec = importlib.import_module(base + "decoder")

@@ -78,3 +78,21 @@ def test_get_bev_features_matches_oracle(name, bs, temporal):
     # ones whose TSA input differs, i.e. bound the number of rows out of tolerance
     err = (got - want).abs().amax(-1)
     assert (err > 1e-3).float().mean().item() < 2e-3, err.max().item()
+
+
+def test_v2_bev_encoder_client_matches_oracle():
+    """PerceptionTransformerBEVEncoder (modules/transformerV2.py:55-141): flatten + embeddings
+    + one encoder call without history."""
+    from test_transformer_cpu import _v2_pair
+    mine, sd, cfg = _v2_pair("micro4")
+    own, enc = split_transformer_sd(sd)
+    mlvl, bq, kw = S.make_transformer_inputs("micro4", seed=5, bs=2)
+    with torch.no_grad():
+        feats, shapes, start = _oracle_flatten_feats(mlvl, own["cams_embeds"], own["level_embeds"])
+        want = O.encoder_forward(enc, bq.unsqueeze(1).repeat(1, 2, 1), feats, bev_h=kw["bev_h"], bev_w=kw["bev_w"],
+                                 bev_pos=kw["bev_pos"].flatten(2).permute(2, 0, 1), spatial_shapes=shapes,
+                                 level_start_index=start, prev_bev=None, shift=torch.zeros(1, 2),
+                                 img_metas=kw["img_metas"], pc_range=S.PC_RANGE)
+        got = mine.to(DEV)([f.to(DEV) for f in mlvl], bq.to(DEV), kw["bev_h"], kw["bev_w"],
+                           bev_pos=kw["bev_pos"].to(DEV), img_metas=kw["img_metas"]).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=1e-3)

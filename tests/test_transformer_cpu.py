@@ -105,3 +105,42 @@ def test_shift_matches_closed_form():
     # |t| = 2.5 m, heading 0.3 rad vs motion direction atan2(1.5, 2.0)
     ang = 0.3 - np.arctan2(1.5, 2.0)
     np.testing.assert_allclose(sh[0], [2.5 * np.sin(ang) / 0.512 / 10, 2.5 * np.cos(ang) / 0.512 / 12], rtol=1e-12)
+
+
+# -- BEVFormerV2's client of the encoder (modules/transformerV2.py:55-173) -----------------------
+
+def _v2_pair(name, seed=11):
+    import bevformer_amd
+    cfg = S.transformer_cfg(name)
+    torch.manual_seed(seed)
+    mine = bevformer_amd.build_transformer(dict(type="PerceptionTransformerBEVEncoder",
+                                                num_feature_levels=cfg["num_feature_levels"],
+                                                encoder=cfg["encoder"])).eval()
+    mine.init_weights()
+    sd = {k: v.clone() for k, v in mine.state_dict().items()}
+    own, enc = split_transformer_sd(sd)
+    S.trained_like_(enc, seed=3)
+    sd.update({"encoder." + k: v for k, v in enc.items()})
+    mine.load_state_dict(sd)
+    return mine, sd, cfg
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("aug", [False, True])
+def test_v2_bev_encoder_matches_reference_file(aug):
+    mine, sd, cfg = _v2_pair("micro4")
+    ref = mmcv_stub.build_reference_bev_encoder_v2(cfg["encoder"],
+                                                   num_feature_levels=cfg["num_feature_levels"])
+    assert list(ref.state_dict()) == list(sd)
+    ref.load_state_dict(sd)
+    mlvl, bq, kw = S.make_transformer_inputs("micro4", seed=4, bs=1)
+    if aug:   # BEV augmentation of BEVFormerV2 training: resample the BEV by a 2 x 2 matrix
+        c, s_ = 0.9659258, 0.2588190
+        kw["img_metas"][0]["aug_param"] = dict(GlobalRotScaleTransImage_param=(
+            15.0, 1.0, False, False, torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]), True))
+    args = dict(grid_length=kw["grid_length"], bev_pos=kw["bev_pos"], img_metas=kw["img_metas"])
+    with torch.no_grad():
+        want = ref(mlvl, bq, kw["bev_h"], kw["bev_w"], **args)
+        with oracle_ops():
+            got = mine(mlvl, bq, kw["bev_h"], kw["bev_w"], **args)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
