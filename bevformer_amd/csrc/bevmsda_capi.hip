@@ -18,7 +18,6 @@ constexpr int kDefaultQtileBwd = 8;
 // projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
-constexpr long kLinearWideTileMinRows = 131072;  // default switches to 256-column block tiles from this M
 
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -469,12 +468,14 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
   //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
   //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
+  //   bit 5: fragments-first schedule (copy mode 3, 128-column tiles): see linear_mfma.h FRAGS
   int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
-  // 256-column tiles (2 blocks / CU) only pay once there are enough row panels to keep every CU fed at
-  // that occupancy: measured win at M = 185 k (camera features), loss at M <= 80 k (r1j sweep)
-  if (d->variant <= 0 && wpack && d->M >= kLinearWideTileMinRows) v |= 16;
-  if (v < 0 || v > 31) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 16) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
+  // 256-column tiles (2 blocks / CU) and the fragments-first schedule (3 blocks / CU) stay opt-in: both
+  // measured within noise of, or behind, the 4-blocks-per-CU default on every layer shape (r1j / r1l
+  // sweeps; the hoisted N = 1536 projection got 11 % slower with 256-column tiles, r1k vs r1i)
+  if (v < 0 || v > 63) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 48) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 48) == 48) return BEVMSDA_ERR_BAD_OPTION;
   if ((v & 16) && (d->N % 256 != 0 || gcols % 256 != 0)) v &= ~16;
   const int bn = (v & 16) ? 256 : bevmsda::kLinBN;
   const int wmode = (v >> 2) & 3;
@@ -494,6 +495,11 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
     else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_, BN_>), g, b, 0, st, a);      \
   } while (0)
 #define BEVMSDA_LIN2(NP_, BK_, SW_, WM_) BEVMSDA_LIN3(NP_, BK_, SW_, WM_, 128)
+#define BEVMSDA_LIN4(NP_, SW_)                                                                                          \
+  do {                                                                                                                  \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, true>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, true>), g, b, 0, st, a);     \
+  } while (0)
 #define BEVMSDA_LIN1(NP_)                                                       \
   switch (v) {                                                                  \
     case 0: BEVMSDA_LIN2(NP_, 32, true, 0); break;                              \
@@ -508,12 +514,15 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
     case 14: BEVMSDA_LIN2(NP_, 32, false, 3); break;                            \
     case 28: BEVMSDA_LIN3(NP_, 32, true, 3, 256); break;                        \
     case 30: BEVMSDA_LIN3(NP_, 32, false, 3, 256); break;                       \
+    case 44: BEVMSDA_LIN4(NP_, true); break;                                    \
+    case 46: BEVMSDA_LIN4(NP_, false); break;                                   \
     default: return BEVMSDA_ERR_BAD_OPTION;                                     \
   }
   if (d->precision == 0) { BEVMSDA_LIN1(3) } else { BEVMSDA_LIN1(1) }
 #undef BEVMSDA_LIN1
 #undef BEVMSDA_LIN2
 #undef BEVMSDA_LIN3
+#undef BEVMSDA_LIN4
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

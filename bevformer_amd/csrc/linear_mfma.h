@@ -107,10 +107,16 @@ constexpr int lin_waves_per_eu(int bk, int wmode, bool add, int bn) {
   return bk == 64 || wmode == 2 || bn == 256 ? 2 : (wmode == 3 && !add ? 4 : 3);   // by LDS bytes and VGPR need
 }
 
-template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128>
+// FRAGS: all MFMA fragments of a chunk (both k-steps, both operands: 64 VGPRs) are read into
+// registers first, ONE barrier follows, and the LDS-DMA of the next weight chunk is issued
+// before the 24 MFMAs instead of after them: the MFMA phase has no LDS dependence and both
+// operand streams of the next chunk are in flight under it (3 blocks / CU by VGPRs).
+template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128, bool FRAGS = false>
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(lin_waves_per_eu(BK, WMODE, ADD, BN), lin_waves_per_eu(BK, WMODE, ADD, BN))))
+__attribute__((amdgpu_waves_per_eu(FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN),
+                                   FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN))))
 linear_splitbf16_kernel(const LinArgs a) {
+  static_assert(!FRAGS || (WMODE == 3 && BN == 128 && BK == 32), "FRAGS: packed weights by LDS-DMA, 128 x 128 x 32");
   static_assert(BN == 128 || (BN == 256 && WMODE == 3), "BN = 256 needs the packed weight image by LDS-DMA");
   constexpr int NTW = BN / 128;             // packed 128-row weight tiles per block
   constexpr int NJ = BN / 64;               // 32-column MFMA tiles per wavefront
@@ -271,13 +277,57 @@ linear_splitbf16_kernel(const LinArgs a) {
         if (WCH16 % 256 == 0 || i * 256 + tid < WCH16)
           *reinterpret_cast<uint4 *>(&lds_w[(i * 256 + tid) * 8]) = wq[i];
     }
+    if (FRAGS && kc + BK < K) {                     // xr is free again: next activations first
+      if (kc + BK == a.K0) set_segment(true);
+      load_chunk();
+    }
     __syncthreads();          // staged chunk visible (an LDS-DMA in flight is drained here too)
     const uint16_t *wcur = lds_w + (WMODE == 2 ? (c & 1) * NTW * NPL * PLANE : 0);
-    if (kc + BK < K) {                              // in flight under the MFMAs below
+    if (!FRAGS && kc + BK < K) {                    // in flight under the MFMAs below
       if (kc + BK == a.K0) set_segment(true);
       load_chunk();
       if (WMODE == 1) load_w(c + 1, 0);
       if (WMODE == 2) load_w(c + 1, (c + 1) & 1);
+    }
+
+    if (FRAGS) {
+      lin_bf16x8 ah[2][2], bh[2][2], al[2][2], bl[2][2];     // [k-step][tile]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ao = a_off + t * 32 * ROW + ks * 16;
+          const int bo = b_off + t * 32 * ROW + ks * 16;
+          ah[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[ao]);
+          bh[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[bo]);
+          if (LO) {
+            al[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
+            bl[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
+          }
+        }
+      __syncthreads();        // every fragment of this chunk is in registers: both LDS areas are free
+      if (kc + BK < K) load_w(c + 1, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (SWAP) {
+              if (LO) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][j], al[ks][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+              }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+            } else {
+              if (LO) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+              }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
+          }
+      continue;
     }
 
 #pragma unroll
