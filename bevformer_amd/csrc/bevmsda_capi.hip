@@ -469,17 +469,19 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
   //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
   //   bit 5: fragments-first schedule (copy mode 3, 128-column tiles): see linear_mfma.h FRAGS
+  //   bit 6: 64-row block tiles, 5 blocks / CU (copy mode 3, 128-column tiles): see linear_mfma.h BM
   int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
   // 256-column tiles (2 blocks / CU) and the fragments-first schedule (3 blocks / CU) stay opt-in: both
   // measured within noise of, or behind, the 4-blocks-per-CU default on every layer shape (r1j / r1l
   // sweeps; the hoisted N = 1536 projection got 11 % slower with 256-column tiles, r1k vs r1i)
-  if (v < 0 || v > 63) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 48) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 48) == 48) return BEVMSDA_ERR_BAD_OPTION;
+  if (v < 0 || v > 127) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 112) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 112) != 0 && (v & 112) != 16 && (v & 112) != 32 && (v & 112) != 64) return BEVMSDA_ERR_BAD_OPTION;
   if ((v & 16) && (d->N % 256 != 0 || gcols % 256 != 0)) v &= ~16;
   const int bn = (v & 16) ? 256 : bevmsda::kLinBN;
   const int wmode = (v >> 2) & 3;
-  const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
+  const int bm = (v & 64) ? 64 : bevmsda::kLinBM;
+  const long long nbm = (d->M + bm - 1) / bm;
   const long long nbn = (d->N + bn - 1) / bn;
   const long long grid = ((nbm + 7) / 8) * 8 * nbn;
   if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
@@ -495,6 +497,11 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
     else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_, BN_>), g, b, 0, st, a);      \
   } while (0)
 #define BEVMSDA_LIN2(NP_, BK_, SW_, WM_) BEVMSDA_LIN3(NP_, BK_, SW_, WM_, 128)
+#define BEVMSDA_LIN5(NP_, SW_)                                                                                               \
+  do {                                                                                                                       \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);     \
+  } while (0)
 #define BEVMSDA_LIN4(NP_, SW_)                                                                                          \
   do {                                                                                                                  \
     if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, true>), g, b, 0, st, a);  \
@@ -515,6 +522,8 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
     case 28: BEVMSDA_LIN3(NP_, 32, true, 3, 256); break;                        \
     case 30: BEVMSDA_LIN3(NP_, 32, false, 3, 256); break;                       \
     case 44: BEVMSDA_LIN4(NP_, true); break;                                    \
+    case 76: BEVMSDA_LIN5(NP_, true); break;                                    \
+    case 78: BEVMSDA_LIN5(NP_, false); break;                                   \
     case 46: BEVMSDA_LIN4(NP_, false); break;                                   \
     default: return BEVMSDA_ERR_BAD_OPTION;                                     \
   }
@@ -523,6 +532,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
 #undef BEVMSDA_LIN2
 #undef BEVMSDA_LIN3
 #undef BEVMSDA_LIN4
+#undef BEVMSDA_LIN5
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -111,36 +111,44 @@ constexpr int lin_waves_per_eu(int bk, int wmode, bool add, int bn) {
 // registers first, ONE barrier follows, and the LDS-DMA of the next weight chunk is issued
 // before the 24 MFMAs instead of after them: the MFMA phase has no LDS dependence and both
 // operand streams of the next chunk are in flight under it (3 blocks / CU by VGPRs).
-template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128, bool FRAGS = false>
+// BM: rows per block.  64 (packed weights by LDS-DMA only): the four wavefronts sit side by side
+// along N (wavefront tile 64 x 32, 32 accumulator VGPRs), the activation tile is 64 rows (10 KB):
+// 30 KB of LDS and < 100 VGPRs let 5 blocks = 20 waves share a CU, and twice as many, smaller
+// blocks even out the last wave of blocks on the short (M = 40 k) projections.
+template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128, bool FRAGS = false, int BM = 128>
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN),
-                                   FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN))))
+__attribute__((amdgpu_waves_per_eu(BM == 64 ? (ADD ? 4 : 5) : (FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN)),
+                                   BM == 64 ? (ADD ? 4 : 5) : (FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN)))))
 linear_splitbf16_kernel(const LinArgs a) {
+  static_assert(BM == 128 || (BM == 64 && WMODE == 3 && BN == 128 && BK == 32 && !FRAGS),
+                "BM = 64: packed weights by LDS-DMA, 64 x 128 x 32");
   static_assert(!FRAGS || (WMODE == 3 && BN == 128 && BK == 32), "FRAGS: packed weights by LDS-DMA, 128 x 128 x 32");
   static_assert(BN == 128 || (BN == 256 && WMODE == 3), "BN = 256 needs the packed weight image by LDS-DMA");
   constexpr int NTW = BN / 128;             // packed 128-row weight tiles per block
-  constexpr int NJ = BN / 64;               // 32-column MFMA tiles per wavefront
+  constexpr int WNW = BM == 64 ? 4 : 2;     // wavefronts along N (x 4 / WNW along M)
+  constexpr int NJ = BN / WNW / 32;         // 32-column MFMA tiles per wavefront
   static_assert(NPROD == 1 || NPROD == 3, "NPROD: 1 = bf16 inputs, 3 = split-f32");
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE == 0 || BK == 32), "WMODE");
   constexpr bool LO = NPROD == 3;
   constexpr int ROW = BK + 8;               // bf16 elements per LDS row (16-byte pad: the 16 lanes
                                             // of a ds_read_b128 group hit 16 distinct 4-bank slots)
-  constexpr int PLANE = 128 * ROW;
+  constexpr int PLANE = 128 * ROW;          // one 128-row plane (weight tiles are always 128 rows)
+  constexpr int APLANE = BM * ROW;          // one activation plane
   constexpr int TPR = BK / 8;               // staging threads per row
   constexpr int RPP = 256 / TPR;            // rows per staging pass
-  constexpr int NP = 128 / RPP;             // staging passes
+  constexpr int NP = BM / RPP;              // staging passes
   constexpr int NPL = LO ? 2 : 1;           // planes per operand: hi (, lo)
   constexpr int WBUFS = WMODE == 2 ? 2 : 1;
   // [A hi | A lo] then WBUFS x [W hi | W lo]
-  __shared__ __attribute__((aligned(16))) uint16_t lds[(1 + WBUFS * NTW) * NPL * PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NPL * APLANE + WBUFS * NTW * NPL * PLANE];
   uint16_t *const lds_a = lds;
-  uint16_t *const lds_w = lds + NPL * PLANE;
+  uint16_t *const lds_w = lds + NPL * APLANE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BM == 64 ? 0 : wave >> 1, wn = BM == 64 ? wave : wave & 1;
 
   // XCD-aware tile map (see header)
   const int xcd = blockIdx.x & 7;
@@ -148,7 +156,7 @@ linear_splitbf16_kernel(const LinArgs a) {
   const int mt = (seq / a.nblk_n) * 8 + xcd;
   const int nt = seq % a.nblk_n;
   if (mt >= a.nblk_m) return;
-  const long m0 = static_cast<long>(mt) * kLinBM;
+  const long m0 = static_cast<long>(mt) * BM;
   const int n0 = nt * BN;
 
   // staging assignment: row srow (+RPP per pass), k offset skq inside the chunk
@@ -247,7 +255,7 @@ linear_splitbf16_kernel(const LinArgs a) {
   const int fk = (lane >> 5) * 8;
   const int a_off = (wm * 64 + frow) * ROW + fk;
   // BN = 128: wave column wn reads rows wn * 64 .. of the one W tile; BN = 256: W tile wn entirely
-  const int b_off = (BN == 256 ? wn * NPL * PLANE : wn * 64 * ROW) + frow * ROW + fk;
+  const int b_off = (BN == 256 ? wn * NPL * PLANE : wn * (BN / WNW) * ROW) + frow * ROW + fk;
 
   set_segment(false);
   load_chunk();
@@ -264,7 +272,7 @@ linear_splitbf16_kernel(const LinArgs a) {
       }
       lin_split8<LO>(xr[p][0], xr[p][1], hi, lo);
       *reinterpret_cast<uint4 *>(&lds_a[off]) = hi;
-      if (LO) *reinterpret_cast<uint4 *>(&lds_a[PLANE + off]) = lo;
+      if (LO) *reinterpret_cast<uint4 *>(&lds_a[APLANE + off]) = lo;
       if (WMODE == 0) {
         lin_split8<LO>(wr[p][0], wr[p][1], hi, lo);
         *reinterpret_cast<uint4 *>(&lds_w[off]) = hi;
@@ -301,7 +309,7 @@ linear_splitbf16_kernel(const LinArgs a) {
           ah[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[ao]);
           bh[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[bo]);
           if (LO) {
-            al[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
+            al[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[APLANE + ao]);
             bl[ks][t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
           }
         }
@@ -337,7 +345,7 @@ linear_splitbf16_kernel(const LinArgs a) {
       for (int t = 0; t < 2; ++t) {
         const int ao = a_off + t * 32 * ROW + ks * 16;
         ah[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[ao]);
-        if (LO) al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[PLANE + ao]);
+        if (LO) al[t] = *reinterpret_cast<const lin_bf16x8 *>(&lds_a[APLANE + ao]);
       }
 #pragma unroll
       for (int t = 0; t < NJ; ++t) {
@@ -389,7 +397,7 @@ linear_splitbf16_kernel(const LinArgs a) {
         float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int nb = n0 + wn * (BN / 2) + j * 32 + 4 * (lane >> 5);
+          const int nb = n0 + wn * (BN / WNW) + j * 32 + 4 * (lane >> 5);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = nb + 8 * g;
@@ -414,7 +422,7 @@ linear_splitbf16_kernel(const LinArgs a) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int nb = n0 + wn * (BN / 2) + j * 32 + 4 * (lane >> 5);
+          const int nb = n0 + wn * (BN / WNW) + j * 32 + 4 * (lane >> 5);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int n = nb + 8 * (r >> 2) + (r & 3);
@@ -431,7 +439,7 @@ linear_splitbf16_kernel(const LinArgs a) {
     // for a fixed r the 32 lanes of a half-wave store one contiguous 128-byte row segment
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      const int n = n0 + wn * (BN / WNW) + j * 32 + (lane & 31);
       const bool nok = n < a.N;
       const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
 #pragma unroll

@@ -221,8 +221,8 @@ typedef struct bevmsda_linear_desc {
                                                  bit 1 = dword-row epilogue, bits 2-3 = packed-weight
                                                  copy mode (1 registers, 2 LDS-DMA double-buffered,
                                                  3 LDS-DMA single), bit 4 = 256-column block tiles,
-                                                 bit 5 = fragments-first schedule (both with copy
-                                                 mode 3 only) */
+                                                 bit 5 = fragments-first schedule, bit 6 = 64-row
+                                                 block tiles (one of bits 4-6, copy mode 3 only) */
   int32_t group_cols;                         /* 0, or a multiple of 128 dividing N: output column n
                                                  is written to matrix n / group_cols of
                                                  N / group_cols consecutive (M, ldy) matrices at y,

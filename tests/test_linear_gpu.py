@@ -27,7 +27,7 @@ def gemm_mode():
 
 # launch variants of the kernel (include/bevmsda.h): 64-deep chunks, both epilogues, and the
 # three copy modes of the pre-split weight image
-VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 28, 30, 44, 46]
+VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 28, 30, 44, 46, 76, 78]
 
 
 def _ref64(x, w, b, relu=False):
@@ -84,7 +84,7 @@ def test_linear_matches_fp64(gemm_mode, mode, M, N, K):
         assert lib < BOUND[mode]
 
 
-@pytest.mark.parametrize("variant", [None, 0, 12, 28, 44])
+@pytest.mark.parametrize("variant", [None, 0, 12, 28, 44, 76])
 def test_linear_identity_with_asymmetric_weight(gemm_mode, variant):
     """A = I picks single weights: catches a transposed / permuted accumulator map, and shows
     that an fp32 weight survives the hi + lo split to 2^-17."""
@@ -130,7 +130,7 @@ def test_linear_not_covered_returns_none(gemm_mode):
         assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
 
 
-@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14, 28, 30, 44])
+@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14, 28, 30, 44, 76])
 def test_linear_grouped_output(gemm_mode, variant):
     """groups = G: G Linear layers over one input -> (G, M, N / G) contiguous outputs."""
     gemm_mode("split")
