@@ -73,6 +73,8 @@ SIGNATURES = {
     "bevmsda_linear_f32": ([_c_void_p] * 6 + [ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_packed_f32": ([_c_void_p] * 6 + [ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p],
                                   _c_int),
+    "bevmsda_linear_gather_packed_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                          ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                        _c_int),

@@ -435,7 +435,7 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
 
 static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
                          const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
-                         void *stream) {
+                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -459,10 +459,11 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
   a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
+  a.gidx = gidx; a.gscale = gscale;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool add = a.a0 != nullptr || a.a1 != nullptr;
+  const bool add = a.a0 != nullptr || a.a1 != nullptr || gidx != nullptr;
   // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
   //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
   //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
@@ -547,6 +548,17 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
                               void *stream) {
   if (!wpack) return BEVMSDA_ERR_NULL_POINTER;
   return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream);
+}
+
+int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx, const float *scale,
+                                     const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d,
+                                     float *y, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (!wpack || !idx || !scale) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->K1 != 0) return BEVMSDA_ERR_BAD_SHAPE;
+  bevmsda_linear_desc dd = *d;
+  dd.ldx0 = ld_rows;
+  return linear_launch(rows, nullptr, nullptr, nullptr, nullptr, wpack, bias, &dd, y, stream, idx, scale);
 }
 
 int64_t bevmsda_linear_packed_bytes(int N, int K) {

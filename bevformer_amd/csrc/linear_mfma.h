@@ -49,6 +49,9 @@ struct LinArgs {
   const float *w;                  // (N, K0 + K1) row-major (WMODE 0)
   long ldw;
   const uint16_t *wpack;           // pre-split weight image (WMODE > 0), see lin_pack_weight_kernel
+  const int32_t *gidx;             // gather mode (ADD kernels): A[m, :] = gscale[m] * sum_{j < 2, gidx[m, j] >= 0}
+  const float *gscale;             //   x0[gidx[m, j], :]  — SpatialCrossAttention's camera mean folded into
+                                   //   the A-load of its output projection (spatial_cross_attention.py:165-173)
   const float *bias;               // (N) or nullptr
   float *y;
   long ldy;
@@ -180,12 +183,32 @@ linear_splitbf16_kernel(const LinArgs a) {
   const long wtile_stride = static_cast<long>((a.K0 + a.K1) / 32) * (2 * PLANE / 8);   // uint4 per 128-row tile
   const int K = a.K0 + a.K1;
 
+  // gather mode: the (up to two) source rows of every staged row and its scale, once per block
+  const bool gather = ADD && a.gidx != nullptr;
+  int gi0[NP], gi1[NP];
+  float gs[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    gi0[p] = gather ? a.gidx[gm[p] * 2] : 0;
+    gi1[p] = gather ? a.gidx[gm[p] * 2 + 1] : 0;
+    gs[p] = gather ? a.gscale[gm[p]] : 1.f;
+  }
+
   // running source pointers of the current A segment (re-based once, where the K axis
   // switches from x0 to x1); a chunk never straddles the switch (K0 % BK == 0 is checked
   // by the launcher for the BK in use)
   const float *xp[NP], *ap[NP];
   bool has_add = false;
   auto set_segment = [&](bool second) {
+    if (ADD && gather) {      // single source: the two gathered rows play the parts of x and addend
+      has_add = true;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        xp[p] = a.x0 + static_cast<long>(gi0[p] < 0 ? 0 : gi0[p]) * a.ldx0 + skq;
+        ap[p] = a.x0 + static_cast<long>(gi1[p] < 0 ? 0 : gi1[p]) * a.ldx0 + skq;
+      }
+      return;
+    }
     const float *xs = second ? a.x1 : a.x0;
     const float *as = second ? a.a1 : a.a0;
     const long ldx = second ? a.ldx1 : a.ldx0;
@@ -267,8 +290,18 @@ linear_splitbf16_kernel(const LinArgs a) {
       uint4 hi, lo;
       const int off = (p * RPP + srow) * ROW + skq;
       if (ADD && staged_add) {
-        xr[p][0] = lin_add4(xr[p][0], ar[p][0]);
-        xr[p][1] = lin_add4(xr[p][1], ar[p][1]);
+        if (gather) {           // (row0 + row1) * scale with absent rows as zeros: gather_mean's arithmetic
+          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 r0 = gi0[p] >= 0 ? xr[p][h] : z, r1 = gi1[p] >= 0 ? ar[p][h] : z;
+            xr[p][h] = make_float4((r0.x + r1.x) * gs[p], (r0.y + r1.y) * gs[p], (r0.z + r1.z) * gs[p],
+                                   (r0.w + r1.w) * gs[p]);
+          }
+        } else {
+          xr[p][0] = lin_add4(xr[p][0], ar[p][0]);
+          xr[p][1] = lin_add4(xr[p][1], ar[p][1]);
+        }
       }
       lin_split8<LO>(xr[p][0], xr[p][1], hi, lo);
       *reinterpret_cast<uint4 *>(&lds_a[off]) = hi;

@@ -236,7 +236,7 @@ class SpatialCrossAttention(BaseModule):
             projected_value = self.deformable_attention.project_value(feats)
 
         da = self.deformable_attention
-        slots = None
+        slots, projected = None, False
         if frame_plan is not None and frame_plan.q_rows is not None \
                 and ops.fused_wanted(query, projected_value):
             # inference path: every BEV query is projected ONCE (the reference projects a
@@ -246,7 +246,14 @@ class SpatialCrossAttention(BaseModule):
                 query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
                 frame_plan.row_query32, spatial_shapes, level_start_index)
             if out_rows is not None:
-                slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
+                # camera mean + output projection in one kernel where the GEMM kernel is in use
+                proj = ops.linear_gather_mean(out_rows, frame_plan.q_rows, inv_count,
+                                              self.output_proj.weight, self.output_proj.bias,
+                                              tag="sca_output_proj")
+                if proj is not None:
+                    slots, projected = proj.view(bs, Q, C), True
+                else:
+                    slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
         if slots is None:
             q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
             out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
@@ -254,8 +261,9 @@ class SpatialCrossAttention(BaseModule):
             slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
             slots.index_add_(0, row_query, out_rows)
             slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
-        slots = ops.linear_or_torch(slots, self.output_proj.weight, self.output_proj.bias,
-                                    tag="sca_output_proj")
+        if not projected:
+            slots = ops.linear_or_torch(slots, self.output_proj.weight, self.output_proj.bias,
+                                        tag="sca_output_proj")
         if defer_residual and not (self.training and self.dropout.p > 0):
             return slots, inp_residual          # the layer fuses "+ residual" into its LayerNorm
         return self.dropout(slots) + inp_residual

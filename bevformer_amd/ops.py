@@ -413,6 +413,48 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
 
 
+def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
+    """``linear(gather_mean(rows, idx, scale), weight, bias)`` in one kernel
+    (``bevmsda_linear_gather_packed_f32``): the camera mean of SpatialCrossAttention folded into
+    the A-load of its output projection.  idx (Q, 2) int32.  Returns ``None`` when not covered
+    (GEMM mode ``native``, packing off, autograd, more than two cameras per query)."""
+    mode = _GEMM["mode"]
+    if mode == "native" or not _GEMM["pack"] or _GEMM["variant"] is not None \
+            or not rows.is_cuda or rows.dtype != torch.float32 or weight.dtype != torch.float32 \
+            or not fused_wanted(rows, weight, bias) or idx.dim() != 2 or idx.shape[1] != 2 \
+            or idx.dtype != torch.int32 or rows.dim() != 2 or rows.shape[1] % 32 \
+            or weight.shape[1] != rows.shape[1]:
+        return None
+    rows = rows if rows.stride(1) == 1 and rows.stride(0) % 4 == 0 else rows.contiguous()
+    idx = idx.contiguous()
+    scale = scale.reshape(-1).float().contiguous()
+    Qn, N, K = idx.shape[0], weight.shape[0], rows.shape[1]
+    if scale.numel() != Qn:
+        return None
+    w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0
+                   and weight.data_ptr() % 16 == 0) else weight.contiguous()
+    blob = packed_weight(w)
+    if blob is None:
+        return None
+    b = bias.contiguous() if bias is not None else None
+    y = torch.empty((Qn, N), dtype=torch.float32, device=rows.device)
+    if Qn == 0:
+        return y
+    desc = _lib.LinearDesc(M=Qn, ldx0=rows.stride(0), ldw=K, ldy=N, N=N, K0=K, K1=0, relu=0,
+                           precision=0 if mode == "split" else 1)
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    ctx = cb(tag, 2.0 * Qn * N * K, 4.0 * (rows.numel() + N * K + Qn * N)) if cb is not None else _NoTimer()
+    with torch.cuda.device(rows.device), ctx:
+        rc = lib.bevmsda_linear_gather_packed_f32(_ptr(rows), rows.stride(0), _ptr(idx), _ptr(scale), _ptr(blob),
+                                                  _ptr(b) if b is not None else None, ctypes.byref(desc),
+                                                  _ptr(y), torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear_gather_mean")
+    return y
+
+
 def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
     """``linear`` with the torch statement as the not-covered path (single-source form)."""
     y = linear(x, weight, bias, relu=relu, tag=tag)

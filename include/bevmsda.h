@@ -248,6 +248,14 @@ int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, ui
 int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
                               const uint16_t *wpack, const float *bias,
                               const bevmsda_linear_desc *desc, float *y, void *stream);
+/* The packed projection with bevmsda_gather_mean_f32 folded into its A-load:
+ *     A[m, :] = scale[m] * sum_{j < 2, idx[m, j] >= 0} rows[idx[m, j], :]      (idx: (M, 2) int32)
+ * — SpatialCrossAttention's per-camera scatter-add, camera-count division and output_proj
+ * (spatial_cross_attention.py:165-173) in one kernel; same arithmetic as the two-step path
+ * (bit-identical result).  desc->K1 must be 0, desc->ldx0 is replaced by ld_rows. */
+int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx,
+                                     const float *scale, const uint16_t *wpack, const float *bias,
+                                     const bevmsda_linear_desc *desc, float *y, void *stream);
 
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *

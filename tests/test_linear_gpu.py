@@ -170,3 +170,23 @@ def test_linear_propagates_nan_rows_only(gemm_mode):
         y = ops.linear(x, w, relu=True)
     assert torch.isnan(y[17]).all()
     assert torch.isfinite(torch.cat([y[:17], y[18:]])).all()
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_gather_mean_is_the_two_step_result(gemm_mode, mode):
+    """Camera mean folded into the A-load: bit-identical to gather_mean followed by linear."""
+    gemm_mode(mode)
+    g = torch.Generator().manual_seed(31)
+    R, Q, C = 700, 517, 256
+    rows = _rand(R, C, seed=32)
+    idx = torch.randint(0, R, (Q, 2), generator=g, dtype=torch.int32)
+    idx[torch.rand(Q, generator=g) < 0.7, 1] = -1            # most queries: one camera
+    idx[:5] = -1                                             # a few: none
+    cnt = (idx >= 0).sum(1).clamp(min=1).float()
+    scale, w, b = (1.0 / cnt).to(DEV), _rand(256, C, seed=33) * 0.1, _rand(256, seed=34)
+    idx = idx.to(DEV)
+    with torch.no_grad():
+        got = ops.linear_gather_mean(rows, idx, scale, w, b)
+        want = ops.linear(ops.gather_mean(rows, idx, scale), w, b)
+    assert got is not None and torch.equal(got, want)
+    assert torch.equal(got[:5], b.expand(5, -1))             # empty rows: bias only
