@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--gemm", default=None, choices=["split", "bf16", "native"],
                     help="how the Linear layers run (bevformer_amd.ops.set_gemm_mode); default: the "
                          "package default / BEVMSDA_GEMM")
+    ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
+                    help="SCA sampling kernel with the coarsest level staged in LDS (default: package default)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -205,6 +207,8 @@ def main():
 
     if args.gemm:
         ops.set_gemm_mode(args.gemm)
+    if args.sca_lds:
+        ops.set_sca_lds_level(args.sca_lds == "on")
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
     ops.set_gemm_timer(timer.gemm)
@@ -305,6 +309,7 @@ def main():
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
                        "sca_row_order": enc.sca_row_order,
+                       "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
                                          "3 bf16 MFMA products per fp32 product, fp32 accumulate",
                                 "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",

@@ -66,6 +66,8 @@ SIGNATURES = {
                                   _c_int),
     "bevmsda_fused_forward_bf16": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                    _c_int),
+    "bevmsda_fused_forward_lds_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_int, _c_int, _c_void_p,
+                                                          _c_void_p], _c_int),
     "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,
                                                      _c_void_p, _c_void_p], _c_int),
     "bevmsda_gather_mean_f32": ([_c_void_p] * 3 + [ctypes.c_int64, _c_int, _c_int,

@@ -75,15 +75,19 @@ def slice_plan(plan, q0, q1):
     q = plan.row_query - b * Q
     keep = (q >= q0) & (q < q1)
     new_row_query = (b[keep] * (q1 - q0) + (q[keep] - q0)).contiguous()
-    from .modules.geometry import build_q_rows
+    from .modules.geometry import build_q_rows, camera_runs
+    new_row_batch = plan.row_batch[keep].contiguous()
+    cam_start, max_cam_rows = camera_runs(new_row_batch, plan.cam_start.numel() - 1) \
+        if plan.cam_start is not None else (None, 0)
     return replace(
         plan, ref_3d=plan.ref_3d[:, :, q0:q1], ref_2d=plan.ref_2d[:, q0:q1],
         reference_points_cam=plan.reference_points_cam[:, :, q0:q1],
         bev_mask=plan.bev_mask[:, :, q0:q1],
         row_query=new_row_query, row_query32=new_row_query.to(torch.int32),
         q_rows=build_q_rows(new_row_query, plan.bs * (q1 - q0)),
-        row_batch=plan.row_batch[keep].contiguous(), row_ref=plan.row_ref[keep].contiguous(),
-        inv_count=plan.inv_count[:, q0:q1].contiguous(), hits=[])
+        row_batch=new_row_batch, row_ref=plan.row_ref[keep].contiguous(),
+        inv_count=plan.inv_count[:, q0:q1].contiguous(), hits=[], cam_start=cam_start,
+        max_cam_rows=max_cam_rows)
 
 
 def all_gather_rows(local, blocks, bev_w, group=None):

@@ -15,6 +15,7 @@ using bevmsda::bf16_t;
 // library defaults (chosen from the sweeps recorded in DESIGN.md)
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
+constexpr int kLdsLevelRowsPerBlock = 256;   // rows of one (camera, head) per block of the LDS-level kernel
 // projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
@@ -274,6 +275,43 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+// SCA forward with the coarsest level staged in LDS (msda_d32.h, msda_fused_d32_ldslevel_kernel)
+int fused_lds_impl(const float *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
+                   const float *logits, const float *ref, const int32_t *row_src, const int32_t *cam_start,
+                   const bevmsda_fused_desc *d, int lds_pixels, int max_cam_rows, float *out, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->R < 0 || d->N <= 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->A <= 0 || lds_pixels < 0 || max_cam_rows < 0)
+    return BEVMSDA_ERR_BAD_SHAPE;
+  const unsigned long long bytes = 1ULL * d->N * d->S * d->M * d->D * sizeof(float);
+  if (d->D != 32 || d->P != 8 || d->K != 1 || d->L < 1 || d->L > 4 || d->ref_mode != 0 || d->vmul != 1 ||
+      d->vadd != 0 || bytes >= (1ULL << 31) || (d->proj_row & 1) || (d->off_head & 1) || lds_pixels == 0 ||
+      lds_pixels > 512)                                   // 512 pixels x 128 B = the 64 KB a block may take
+    return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->R == 0 || max_cam_rows == 0) return BEVMSDA_OK;
+  if (!value || !shapes || !lstart || !offs || !logits || !ref || !out || !cam_start) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(value) || misaligned(out) || (reinterpret_cast<uintptr_t>(offs) & 7u) ||
+      (reinterpret_cast<uintptr_t>(ref) & 7u) || (reinterpret_cast<uintptr_t>(logits) & 3u))
+    return BEVMSDA_ERR_MISALIGNED;
+  bevmsda::FusedLdsArgs g{};
+  bevmsda::FusedArgs &f = g.f;
+  KArgs &a = f.k;
+  a.value = value; a.shapes = shapes; a.lstart = lstart; a.out = out; a.row_batch = nullptr;
+  a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = 1; a.P = d->P;
+  f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
+  f.off_head = d->off_head; f.off_k = 0; f.lg_head = d->lg_head; f.lg_k = 0;
+  f.K = 1; f.A = d->A; f.ref_mode = 0; f.vmul = 1; f.vadd = 0; f.out_scale = 1.0f;
+  g.cam_start = cam_start;
+  g.rows_per_block = kLdsLevelRowsPerBlock;
+  g.chunks = (max_cam_rows + g.rows_per_block - 1) / g.rows_per_block;
+  g.lds_pixels = lds_pixels;
+  const long long nb = 1LL * d->N * d->M * g.chunks;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const size_t lds_bytes = static_cast<size_t>(lds_pixels) * 32 * sizeof(float);
+  hipLaunchKernelGGL((bevmsda::msda_fused_d32_ldslevel_kernel<3>), dim3(static_cast<unsigned>(nb)), dim3(256), lds_bytes,
+                     static_cast<hipStream_t>(stream), g);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -398,6 +436,15 @@ int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const bevmsda_fused_desc *desc, uint16_t *out, void *stream) {
   return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out,
                             stream);
+}
+
+int bevmsda_fused_forward_lds_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                  const float *offs, const float *logits, const float *ref,
+                                  const int32_t *row_src, const int32_t *cam_start,
+                                  const bevmsda_fused_desc *desc, int lds_pixels, int max_cam_rows, float *out,
+                                  void *stream) {
+  return fused_lds_impl(value, spatial_shapes, level_start, offs, logits, ref, row_src, cam_start, desc,
+                        lds_pixels, max_cam_rows, out, stream);
 }
 
 int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,

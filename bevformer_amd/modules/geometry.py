@@ -93,6 +93,10 @@ class FramePlan:
     q_rows: Optional[torch.Tensor] = None       # (bs*Q, J) int32: rows of every slot, -1 = none
     hits: List[int] = field(default_factory=list)
     level_shapes_host: Optional[list] = None
+    # rows are grouped by value batch entry (j*Nc + cam): first row of every entry's run, for the
+    # SCA kernel variant that stages one (camera, head) level slice in LDS
+    cam_start: Optional[torch.Tensor] = None    # (bs*Nc + 1,) int32
+    max_cam_rows: int = 0
 
 
 def _morton_key(u, v, bits=7):
@@ -177,7 +181,17 @@ def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas
         build_sca_rows(ref_cam, bev_mask, row_order)
     plan.row_query32 = plan.row_query.to(torch.int32)
     plan.q_rows = build_q_rows(plan.row_query, bs * bev_h * bev_w)
+    plan.cam_start, plan.max_cam_rows = camera_runs(plan.row_batch, bs * len(plan.hits))
     return plan
+
+
+def camera_runs(row_batch, num_entries):
+    """(first row of every value batch entry's run (num_entries + 1,) int32, longest run) of a
+    row list grouped by entry (one host sync, at plan time)."""
+    counts = torch.bincount(row_batch.long(), minlength=num_entries)
+    start = torch.zeros(num_entries + 1, dtype=torch.int32, device=row_batch.device)
+    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return start, (int(counts.max().item()) if row_batch.numel() else 0)
 
 
 def plan_key(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas, device, dtype):

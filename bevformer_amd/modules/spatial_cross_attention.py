@@ -136,7 +136,7 @@ class MSDeformableAttention3D(BaseModule):
         return v.view(value.shape[0], value.shape[1], self.num_heads, -1)
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
-                                       spatial_shapes, level_start_index):
+                                       spatial_shapes, level_start_index, frame_plan=None):
         """queries (Q, C) projected once; row r samples with the projection row
         ``row_src[r]`` and its own anchors ``row_ref[r]`` -> (R, C), or None when
         the fused kernel does not cover the shape."""
@@ -147,10 +147,17 @@ class MSDeformableAttention3D(BaseModule):
         n_off = self.sampling_offsets.out_features
         w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
         proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
+        lds = {}
+        if ops._FUSED["lds_level"] and frame_plan is not None and frame_plan.cam_start is not None:
+            px = getattr(frame_plan, "_last_level_pixels", None)
+            if px is None:                      # one host read per plan (shapes live on the device)
+                px = frame_plan._last_level_pixels = int(spatial_shapes[-1].prod().item())
+            lds = dict(cam_start=frame_plan.cam_start, max_cam_rows=frame_plan.max_cam_rows,
+                       lds_pixels=px)
         out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
                              row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
                              off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
-                             vmul=1, vadd=0, row_src=row_src, tag="sca_fwd")
+                             vmul=1, vadd=0, row_src=row_src, tag="sca_fwd", **lds)
         return None if out is None else out.to(queries.dtype)
 
     def forward_ragged(self, query_rows, value, row_ref, row_batch, spatial_shapes,
@@ -244,7 +251,7 @@ class SpatialCrossAttention(BaseModule):
             # reads its query's projection row through row_src; the camera mean is a gather
             out_rows = da.forward_rows_shared_projection(
                 query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
-                frame_plan.row_query32, spatial_shapes, level_start_index)
+                frame_plan.row_query32, spatial_shapes, level_start_index, frame_plan=frame_plan)
             if out_rows is not None:
                 # camera mean + output projection in one kernel where the GEMM kernel is in use
                 proj = ops.linear_gather_mean(out_rows, frame_plan.q_rows, inv_count,

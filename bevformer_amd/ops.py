@@ -146,7 +146,16 @@ def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, at
                                  attention_weights, row_batch, tag)
 
 
-_FUSED = {"enabled": True}
+_FUSED = {"enabled": True,
+          # SCA sampling with the coarsest feature level staged in LDS (csrc/msda_d32.h,
+          # msda_fused_d32_ldslevel_kernel): opt-in, BEVMSDA_SCA_LDS=1 / set_sca_lds_level(True)
+          "lds_level": os.environ.get("BEVMSDA_SCA_LDS", "0") == "1"}
+
+
+def set_sca_lds_level(flag):
+    """SpatialCrossAttention's sampling kernel with the last feature level of a (camera, head)
+    staged in LDS (rows grouped by camera; fp32)."""
+    _FUSED["lds_level"] = bool(flag)
 
 
 def set_fused_front_end(flag):
@@ -164,7 +173,7 @@ def fused_wanted(*tensors):
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd"):
+               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -204,6 +213,20 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
             + R * M * D * value.element_size()
         cb = _TIMER["cb"]
         ctx = cb(tag, alg) if cb is not None else _NoTimer()
+        rc = _lib.ERR_UNSUPPORTED
+        if _FUSED["lds_level"] and cam_start is not None and store == torch.float32 and K == 1 \
+                and ref_mode == 0 and 0 < lds_pixels <= 512 and max_cam_rows > 0:
+            with ctx:
+                rc = lib.bevmsda_fused_forward_lds_f32(
+                    _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
+                    logits.data_ptr(), _ptr(ref), _ptr(row_src) if row_src is not None else None,
+                    _ptr(cam_start), ctypes.byref(desc), int(lds_pixels), int(max_cam_rows), _ptr(out),
+                    torch.cuda.current_stream().cuda_stream)
+            if rc == 0:
+                return out
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "msda_fused forward (LDS level)")
+            ctx = cb(tag, alg) if cb is not None else _NoTimer()
         with ctx:
             rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
                     logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,

@@ -178,6 +178,19 @@ int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const int32_t *row_src, const bevmsda_fused_desc *desc,
                                uint16_t *out, void *stream);
 
+/* bevmsda_fused_forward_f32 for SpatialCrossAttention with the LAST feature level staged in
+ * LDS: rows must be grouped by camera (value batch entry), cam_start (N + 1) int32 holds the
+ * first row of every camera's run, lds_pixels = H * W of the last level (<= 512: 64 KB of LDS
+ * per block), max_cam_rows = the longest run.  Requirements: D = 32, P = 8, K = 1, ref_mode 0
+ * (pillar anchors), vmul = 1, vadd = 0; anything else returns BEVMSDA_ERR_UNSUPPORTED and the
+ * caller uses bevmsda_fused_forward_f32.  Same results as that entry point (same coefficient
+ * arithmetic, taps of the last level read from LDS instead of through the vector-memory path). */
+int bevmsda_fused_forward_lds_f32(const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start, const float *offs, const float *logits,
+                                  const float *ref, const int32_t *row_src, const int32_t *cam_start,
+                                  const bevmsda_fused_desc *desc, int lds_pixels, int max_cam_rows,
+                                  float *out, void *stream);
+
 /* Row-wise helpers of the encoder layer (csrc/rowops.h), fp32, forward only.
  *
  * out = LayerNorm(x + res) * gamma + beta over the last dimension C (res may be NULL):

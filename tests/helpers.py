@@ -23,7 +23,7 @@ def _oracle_msda_ragged(value, shapes, start, loc, attn, row_batch, tag=None):
 
 
 def _oracle_msda_fused(value, shapes, start, proj, n_off, ref, row_batch, *, M, L, P, K, off_head,
-                       off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None, tag=None):
+                       off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None, tag=None, **_lds):
     """CPU statement of the fused entry point's contract (include/bevmsda.h,
     ``bevmsda_fused_forward_*``) out of torch ops + the oracle operator: what the
     kernel must compute for a given descriptor."""

@@ -130,3 +130,27 @@ def test_plan_cache_makes_steady_state_sync_free():
         b = enc(q, f, f, **kw)
         assert len(enc._plan_cache) == 1
     torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,bs", [("micro4", 1), ("micro4", 2), ("tiny", 1), ("micro", 1)])
+def test_sca_coarse_level_from_lds_is_identical(name, bs):
+    """The SCA sampling kernel with the last feature level staged in LDS computes the same
+    coefficients and accumulates in the same order as the default kernel: identical encoder
+    output (4 levels, 1 level, bs = 2 exercises the per-entry camera runs)."""
+    enc, sd = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=0, bs=bs, temporal=True)
+    args = (q.to(DEV), f.to(DEV), f.to(DEV))
+    try:
+        with torch.no_grad():
+            ops.set_sca_lds_level(False)
+            want = enc(*args, **_to_dev(kw))
+            ops.set_sca_lds_level(True)
+            got = enc(*args, **_to_dev(kw))
+    finally:
+        ops.set_sca_lds_level(False)
+    plan = next(iter(enc._plan_cache.values()))
+    assert plan.cam_start is not None and plan.max_cam_rows > 0
+    torch.testing.assert_close(got, want, rtol=0, atol=1e-6)
+    with torch.no_grad():
+        ref = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+    torch.testing.assert_close(got.cpu(), ref, **TOL)
