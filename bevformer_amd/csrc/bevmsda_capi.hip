@@ -262,14 +262,17 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   // register budget: 4 waves/SIMD for multi-level calls (SCA), 8 for the 1-level call (TSA)
   // (tools/kbench.py sweep, profiles/r1)
+  // desc->reserved[0] = 4 or 8 overrides the choice (benchmark sweeps)
+  if (d->reserved[0] != 0 && d->reserved[0] != 4 && d->reserved[0] != 8) return BEVMSDA_ERR_BAD_OPTION;
+  const bool wide = d->reserved[0] ? d->reserved[0] == 4 : d->L > 1;     // 4 waves / SIMD: more taps in flight
   if (d->P == 8) {
-    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), 0, st, f);
+    if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 8>), grid, dim3(256), 0, st, f);
   } else if (d->K == 2) {
-    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4>), grid, dim3(256), 0, st, f);
+    if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 8>), grid, dim3(256), 0, st, f);
   } else {
-    if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 4>), grid, dim3(256), 0, st, f);
+    if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 4>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 8>), grid, dim3(256), 0, st, f);
   }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;

@@ -165,7 +165,7 @@ typedef struct bevmsda_fused_desc {
   int32_t K, A, ref_mode;
   int32_t off_head, off_k, lg_head, lg_k;
   int32_t vmul, vadd;
-  int32_t reserved[6];
+  int32_t reserved[6];   /* reserved[0]: 0 = default, 4 / 8 = kernel sized for 4 / 8 waves per SIMD */
 } bevmsda_fused_desc;
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,

@@ -14,7 +14,9 @@ timeout -k 5 $PASS_TIMEOUT rocprofv3 --kernel-trace --stats --output-format csv 
 if [ "${PMC:-1}" = "1" ]; then
   for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
               "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
+              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+              "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+              "GRBM_GUI_ACTIVE"; do
     name=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
     timeout -k 5 $PASS_TIMEOUT rocprofv3 --pmc $pass --kernel-include-regex "msda|bevsca|bevtsa|linear_splitbf16" --output-format csv \
         -d "$out/pmc_$name" -- "$@" > "$out/pmc_$name.log" 2>&1 || echo "pass '$pass' failed/timed out" >> "$out/failed_passes.txt"
