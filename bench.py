@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--gemm", default=None, choices=["split", "bf16", "native"],
                     help="how the Linear layers run (bevformer_amd.ops.set_gemm_mode); default: the "
                          "package default / BEVMSDA_GEMM")
+    ap.add_argument("--value-storage", default="fp32", choices=["fp32", "bf16"],
+                    help="storage of the projected value tensors (bf16: written by the projection "
+                         "kernel, sampled by the 16-byte-lane bf16 kernel; arithmetic stays fp32)")
     ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
                     help="SCA sampling kernel with the coarsest level staged in LDS (default: package default)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
@@ -209,6 +212,8 @@ def main():
         ops.set_gemm_mode(args.gemm)
     if args.sca_lds:
         ops.set_sca_lds_level(args.sca_lds == "on")
+    if args.value_storage == "bf16":
+        ops.set_value_storage(torch.bfloat16)
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
     ops.set_gemm_timer(timer.gemm)
@@ -310,6 +315,7 @@ def main():
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
                        "sca_row_order": enc.sca_row_order,
                        "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
+                       "value_storage": args.value_storage,
                        "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
                                          "3 bf16 MFMA products per fp32 product, fp32 accumulate",
                                 "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",

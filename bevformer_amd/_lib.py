@@ -40,7 +40,7 @@ class LinearDesc(ctypes.Structure):
                 ("ldy", ctypes.c_int64), ("N", ctypes.c_int32), ("K0", ctypes.c_int32),
                 ("K1", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
                 ("variant", ctypes.c_int32), ("group_cols", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 5)]
+                ("out_bf16", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 ERR_UNSUPPORTED = -7

@@ -254,6 +254,12 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   f.off_head = d->off_head; f.off_k = d->off_k; f.lg_head = d->lg_head; f.lg_k = d->lg_k;
   f.K = d->K; f.A = d->A; f.ref_mode = d->ref_mode; f.vmul = d->vmul; f.vadd = d->vadd;
   f.out_scale = 1.0f / static_cast<float>(d->K);
+  f.out_f32 = 0;
+  if constexpr (sizeof(T) == 2) {
+    // desc->reserved[2] = 1: `out` is an fp32 (R, M*D) matrix (16-byte-lane bf16 kernel only)
+    if (d->reserved[2] != 0 && d->reserved[1] != 0) return BEVMSDA_ERR_BAD_OPTION;
+    f.out_f32 = d->reserved[2] ? 1 : 0;
+  }
   const long tiles = (a.NQ + a.qtile - 1) / a.qtile;
   const long nb = (tiles * a.qtile * a.M + 31) / 32;
   if (nb >= (1LL << 31) - 8) return BEVMSDA_ERR_TOO_LARGE;
@@ -262,8 +268,25 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   // register budget: 4 waves/SIMD for multi-level calls (SCA), 8 for the 1-level call (TSA)
   // (tools/kbench.py sweep, profiles/r1)
-  // desc->reserved[0] = 4 or 8 overrides the choice (benchmark sweeps)
+  // desc->reserved[0] = 4 or 8 overrides the choice (benchmark sweeps); desc->reserved[1] = 1 selects the
+  // 8-byte-lane bf16 kernel instead of the 16-byte-lane one (bf16 storage only)
   if (d->reserved[0] != 0 && d->reserved[0] != 4 && d->reserved[0] != 8) return BEVMSDA_ERR_BAD_OPTION;
+  if constexpr (sizeof(T) == 2) {
+    if (d->reserved[1] == 0) {
+      const bool wide16 = d->reserved[0] ? d->reserved[0] == 4 : true;   // 8 accumulators: the 64-VGPR form spills
+      if (d->P == 8) {
+        if (wide16) hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<8, 1, 4>), grid, dim3(256), 0, st, f);
+        else hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<8, 1, 8>), grid, dim3(256), 0, st, f);
+      } else if (d->K == 2) {
+        if (wide16) hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<4, 2, 4>), grid, dim3(256), 0, st, f);
+        else hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<4, 2, 8>), grid, dim3(256), 0, st, f);
+      } else {
+        if (wide16) hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<4, 1, 4>), grid, dim3(256), 0, st, f);
+        else hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_kernel<4, 1, 8>), grid, dim3(256), 0, st, f);
+      }
+      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+    }
+  }
   const bool wide = d->reserved[0] ? d->reserved[0] == 4 : d->L > 1;     // 4 waves / SIMD: more taps in flight
   if (d->P == 8) {
     if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), 0, st, f);
@@ -512,6 +535,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.gidx = gidx; a.gscale = gscale;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
+  a.out_bf16 = d->out_bf16 ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool add = a.a0 != nullptr || a.a1 != nullptr || gidx != nullptr;
   // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
@@ -542,6 +566,10 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;
   if (wmode > 0 && (v & 1)) return BEVMSDA_ERR_BAD_OPTION;
   if ((v & 1) && ((d->K0 + d->K1) % 64 != 0 || (d->K1 > 0 && d->K0 % 64 != 0))) v &= ~1;
+  // bf16 output: only the transposed-tile epilogue packs it (4 consecutive columns per lane)
+  if (d->out_bf16 && ((v & 2) || d->N % 4 != 0 || d->ldy % 4 != 0 || (gcols % 4) != 0 ||
+                      (reinterpret_cast<uintptr_t>(y) & 7u) != 0 || (bias && misaligned(bias))))
+    return BEVMSDA_ERR_UNSUPPORTED;
 #define BEVMSDA_LIN3(NP_, BK_, SW_, WM_, BN_)                                                                      \
   do {                                                                                                             \
     if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_, BN_>), g, b, 0, st, a);   \

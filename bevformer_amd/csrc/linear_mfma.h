@@ -59,6 +59,7 @@ struct LinArgs {
   int N, K0, K1;
   int relu;
   int group_cols;                  // > 0: output column n goes to matrix n / group_cols (each (M, ldy))
+  int out_bf16;                    // 1: y holds bf16 (round-to-nearest-even of the fp32 result), ldy in elements
   int nblk_m, nblk_n;
 };
 
@@ -444,7 +445,15 @@ linear_splitbf16_kernel(const LinArgs a) {
                 v.z = v.z < 0.f ? 0.f : v.z;
                 v.w = v.w < 0.f ? 0.f : v.w;
               }
-              *reinterpret_cast<float4 *>(yrow + n) = v;
+              if (a.out_bf16) {             // same element offsets, 2-byte elements
+                uint2 pk;
+                pk.x = lin_pack2(v.x, v.y);
+                pk.y = lin_pack2(v.z, v.w);
+                uint16_t *yb = reinterpret_cast<uint16_t *>(a.y) + (yrow - a.y) + n;
+                *reinterpret_cast<uint2 *>(yb) = pk;
+              } else {
+                *reinterpret_cast<float4 *>(yrow + n) = v;
+              }
             }
           }
         }

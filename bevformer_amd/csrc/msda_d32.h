@@ -216,6 +216,8 @@ struct FusedArgs {
   int ref_mode;         // 0: point p uses anchor p % A (pillar anchors); 1: level l uses ref l
   int vmul, vadd;       // value batch entry of (row, q) = base * vmul + q * vadd, base = row_batch[r] or r / Q
   float out_scale;      // 1 / K
+  int out_f32;          // bf16-storage kernels only: write the output rows as fp32 (the consumer is the
+                        // fp32 output projection) instead of bf16
 };
 
 template <int X>
@@ -441,6 +443,129 @@ msda_fused_d32_ldslevel_kernel(const FusedLdsArgs g) {
       float *op = static_cast<float *>(a.out) + (r * a.M + m) * D + lig * 4;
       *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+  }
+}
+
+// ------------------------------------------------------------------ bf16 storage, 16-byte lanes
+// With bf16 storage a tap of one head is 64 bytes.  The 8-byte-per-lane form above (TapLoad<bf16_t>)
+// halves the bytes but not the number of lane requests, and the kernel is bound by the request
+// rate, not by bytes (no gain).  Here a lane fetches 16 bytes = 8 channels, four
+// lanes cover a tap, and the two halves of an 8-lane group fetch the two x-adjacent taps of a
+// bilinear footprint in ONE instruction (lanes 0-3: x0, lanes 4-7: x0 + 1; a second instruction
+// for the row below): 2 requests per point instead of 4, the same 16 bytes per lane as the fp32
+// kernel.  Each half accumulates its taps over 8 channels; one xor-4 exchange at the end adds
+// the halves.  Point ownership, parameter broadcast, softmax / location prologue and the queue
+// mean are those of msda_fused_d32_kernel.
+template <int J0, int j, int CNT>
+struct IssuePointsB8 {
+  static __device__ __forceinline__ void run(const PointParams &p, __amdgpu_buffer_rsrc_t r, uint32_t lane_term,
+                                             bool upper, uint32_t dyb, uint4 (&v)[CNT][2], float (&k)[CNT][2]) {
+    constexpr int J = J0 + j;
+    const uint32_t o = bcast8<J>(p.off) + lane_term;           // lane_term already holds "+ dxb" for the upper half
+    const float k00 = bcast8<J>(p.k00), k01 = bcast8<J>(p.k01);
+    const float k10 = bcast8<J>(p.k10), k11 = bcast8<J>(p.k11);
+    k[j][0] = upper ? k01 : k00;
+    k[j][1] = upper ? k11 : k10;
+    v[j][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(o), 0, 0));
+    v[j][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(o + dyb), 0, 0));
+    if constexpr (j + 1 < CNT) IssuePointsB8<J0, j + 1, CNT>::run(p, r, lane_term, upper, dyb, v, k);
+  }
+};
+
+__device__ __forceinline__ void fma8_bf16(float kk, const uint4 &w, float (&acc)[8]) {
+  acc[0] = fmaf(kk, bf16_lo(w.x), acc[0]); acc[1] = fmaf(kk, bf16_hi(w.x), acc[1]);
+  acc[2] = fmaf(kk, bf16_lo(w.y), acc[2]); acc[3] = fmaf(kk, bf16_hi(w.y), acc[3]);
+  acc[4] = fmaf(kk, bf16_lo(w.z), acc[4]); acc[5] = fmaf(kk, bf16_hi(w.z), acc[5]);
+  acc[6] = fmaf(kk, bf16_lo(w.w), acc[6]); acc[7] = fmaf(kk, bf16_hi(w.w), acc[7]);
+}
+
+template <int CNT>
+__device__ __forceinline__ void sample_points_b8(const PointParams &p, __amdgpu_buffer_rsrc_t r, uint32_t lane_term,
+                                                 bool upper, uint32_t dyb, float (&acc)[8]) {
+  uint4 v[CNT][2];
+  float k[CNT][2];
+  IssuePointsB8<0, 0, CNT>::run(p, r, lane_term, upper, dyb, v, k);
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    fma8_bf16(k[j][0], v[j][0], acc);
+    fma8_bf16(k[j][1], v[j][1], acc);
+  }
+}
+
+template <int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
+  constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
+  static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
+  const KArgs &a = f.k;
+  const int lig = threadIdx.x & 7;
+  const bool upper = lig >= 4;                           // this lane's taps: x0 + 1
+  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  long r; int m;
+  map_group(G, a, r, m);
+  const bool active = r < a.NQ;
+  if (!active) r = a.NQ - 1;
+  const int L = a.L;
+  const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
+  const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * 2;
+  const uint32_t lane_term = (lig & 3) * 16 + (upper ? pix_bytes : 0u);
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  const bool owner = lig < NP;
+  const bool live = active && owner;
+  const int q = owner ? lig / PT : 0;
+  const int pj = owner ? lig % PT : 0;
+  const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
+  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * 2);
+  const long rs = f.row_src ? static_cast<long>(f.row_src[r]) : r;
+  const float *__restrict__ lgp = f.logits + rs * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
+  const float2 *__restrict__ ofp =
+      reinterpret_cast<const float2 *>(f.offs + rs * f.proj_row + m * f.off_head + q * f.off_k) + pj;
+  const float2 *__restrict__ rfp = reinterpret_cast<const float2 *>(f.ref) + (r * f.K + q) * f.A;
+
+  float e0 = lgp[0];
+  float e1 = L > 1 ? lgp[PT] : -INFINITY;
+  float e2 = L > 2 ? lgp[2 * PT] : -INFINITY;
+  float e3 = L > 3 ? lgp[3 * PT] : -INFINITY;
+  float2 of = ofp[0];
+  float2 rf = rfp[f.ref_mode == 0 ? pj % f.A : 0];
+  const float mx = lanes_max<PT>(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
+  e0 = expf(e0 - mx); e1 = expf(e1 - mx); e2 = expf(e2 - mx); e3 = expf(e3 - mx);
+  const float sum = lanes_sum<PT>((e0 + e1) + (e2 + e3));
+
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+    const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+    const float lx = rf.x + of.x / static_cast<float>(W);
+    const float ly = rf.y + of.y / static_cast<float>(H);
+    const float e = l == 0 ? e0 : (l == 1 ? e1 : (l == 2 ? e2 : e3));
+    const float aw = live ? e / sum : 0.f;
+    const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
+    if (l + 1 < L) {
+      of = ofp[(l + 1) * PT];
+      if (f.ref_mode == 1) rf = rfp[l + 1];
+    }
+    sample_points_b8<NP>(p, rsrc, lane_term, upper, static_cast<uint32_t>(W) * pix_bytes, acc);
+  }
+  // add the two halves (lane ^ 4 holds the other x tap's partial sums over the same 8 channels)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] += xor8<4>(acc[c]);
+  if (active && !upper && f.out_f32) {
+    const float sc = f.out_scale;
+    float *op = static_cast<float *>(a.out) + (r * a.M + m) * D + (lig & 3) * 8;
+    *reinterpret_cast<float4 *>(op) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
+    *reinterpret_cast<float4 *>(op + 4) = make_float4(acc[4] * sc, acc[5] * sc, acc[6] * sc, acc[7] * sc);
+  } else if (active && !upper) {
+    const float sc = f.out_scale;
+    bf16_t *op = static_cast<bf16_t *>(a.out) + (r * a.M + m) * D + (lig & 3) * 8;
+    uint4 t;
+    t.x = f32_to_bf16(acc[0] * sc) | (f32_to_bf16(acc[1] * sc) << 16);
+    t.y = f32_to_bf16(acc[2] * sc) | (f32_to_bf16(acc[3] * sc) << 16);
+    t.z = f32_to_bf16(acc[4] * sc) | (f32_to_bf16(acc[5] * sc) << 16);
+    t.w = f32_to_bf16(acc[6] * sc) | (f32_to_bf16(acc[7] * sc) << 16);
+    *reinterpret_cast<uint4 *>(op) = t;
   }
 }
 

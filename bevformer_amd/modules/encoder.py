@@ -113,13 +113,14 @@ class BEVFormerEncoder(TransformerLayerSequence):
         Nc, S, bs, C = value.shape
         feats = value.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
         w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
-        y = ops.linear(feats, w, b, groups=L, tag="sca_value_proj")
+        store = ops.value_storage()          # bf16 storage: the GEMM rounds its fp32 result on the way out
+        y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj")
         if y is not None:
             M = scas[0].num_heads
             sca_vals = [y[i].view(bs * Nc, S, M, -1) for i in range(L)]
         if tsa_value is not None:
             w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
-            y = ops.linear(tsa_value, w, b, groups=L, tag="tsa_value_proj")
+            y = ops.linear(tsa_value, w, b, groups=L, out_dtype=store, tag="tsa_value_proj")
             if y is not None:
                 M = tsas[0].num_heads
                 tsa_vals = [y[i].view(tsa_value.shape[0], tsa_value.shape[1], M, -1) for i in range(L)]

@@ -44,6 +44,10 @@ def _timed(tag, value, loc, attn, out_elems):
     return cb(tag, alg)
 
 
+def value_storage():
+    return _STORAGE["dtype"]
+
+
 def set_value_storage(dtype):
     """fp32 (reference semantics, default) or bf16 storage of the projected
     value tensor inside the sampling kernels (fp32 arithmetic either way)."""
@@ -206,13 +210,19 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     if os.environ.get("BEVMSDA_FUSED_WPE"):           # benchmark sweeps: register budget of the kernel
         desc.reserved[0] = int(os.environ["BEVMSDA_FUSED_WPE"])
     lib = _lib.load()
-    out = torch.empty((R, M * D), dtype=store, device=value.device)
+    if store == torch.bfloat16 and not os.environ.get("BEVMSDA_BF16_LANES8"):
+        desc.reserved[2] = 1            # 16-byte-lane kernel writes fp32 rows for the fp32 output projection
+        out = torch.empty((R, M * D), dtype=torch.float32, device=value.device)
+    else:
+        if store == torch.bfloat16:
+            desc.reserved[1] = 1        # benchmark knob: the 8-byte-lane bf16 kernel
+        out = torch.empty((R, M * D), dtype=store, device=value.device)
     fn = lib.bevmsda_fused_forward_f32 if store == torch.float32 else lib.bevmsda_fused_forward_bf16
     logits = proj[:, n_off:]
     with torch.cuda.device(value.device):
         # algorithmic bytes: value + raw projection row (offsets 8 B + logit 4 B per point) + out
         alg = value.numel() * value.element_size() + R * M * K * L * P * 12 \
-            + R * M * D * value.element_size()
+            + R * M * D * out.element_size()
         cb = _TIMER["cb"]
         ctx = cb(tag, alg) if cb is not None else _NoTimer()
         rc = _lib.ERR_UNSUPPORTED
@@ -364,7 +374,7 @@ def _rows2d(t, K):
 
 
 def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, groups=1,
-           tag="linear"):
+           out_dtype=torch.float32, tag="linear"):
     """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
     ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
     covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
@@ -408,13 +418,16 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     if groups > 1 and (N % groups or (N // groups) % 128):
         return None
     ncol = N // groups
-    y = torch.empty((groups, M, ncol), dtype=torch.float32, device=x.device)
+    if out_dtype not in (torch.float32, torch.bfloat16) or (out_dtype == torch.bfloat16 and N % 4):
+        return None
+    y = torch.empty((groups, M, ncol), dtype=out_dtype, device=x.device)
     if M == 0 or N == 0:
         return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     desc = _lib.LinearDesc(M=M, ldx0=ldx0, lda0=lda0, ldx1=ldx1, lda1=lda1, ldw=w.stride(0),
                            ldy=ncol, N=N, K0=K0, K1=K1, relu=int(bool(relu)),
                            precision=0 if mode == "split" else 1,
-                           group_cols=ncol if groups > 1 else 0)
+                           group_cols=ncol if groups > 1 else 0,
+                           out_bf16=int(out_dtype == torch.bfloat16))
     variant = _GEMM["variant"]
     blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):

@@ -165,7 +165,9 @@ typedef struct bevmsda_fused_desc {
   int32_t K, A, ref_mode;
   int32_t off_head, off_k, lg_head, lg_k;
   int32_t vmul, vadd;
-  int32_t reserved[6];   /* reserved[0]: 0 = default, 4 / 8 = kernel sized for 4 / 8 waves per SIMD */
+  int32_t reserved[6];   /* [0]: 0 = default, 4 / 8 = kernel sized for 4 / 8 waves per SIMD; bf16 entry point
+                            only: [1] = 1 selects the 8-byte-lane kernel instead of the 16-byte-lane one,
+                            [2] = 1 (16-byte-lane kernel) makes `out` an fp32 (R, M*D) matrix */
 } bevmsda_fused_desc;
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
@@ -242,7 +244,11 @@ typedef struct bevmsda_linear_desc {
                                                  column n % group_cols — several Linear layers that
                                                  share their input (the value projections of all
                                                  encoder layers) in one pass over that input */
-  int32_t reserved[5];
+  int32_t out_bf16;                           /* 1: y is a bf16 matrix (the fp32 result rounded to
+                                                 nearest even; ldy / group layout in elements) — the
+                                                 projected value of the bf16-storage sampling path;
+                                                 float4-epilogue variants only, N and ldy % 4 == 0 */
+  int32_t reserved[4];
 } bevmsda_linear_desc;
 
 int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1,

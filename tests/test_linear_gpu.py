@@ -190,3 +190,18 @@ def test_linear_gather_mean_is_the_two_step_result(gemm_mode, mode):
         want = ops.linear(ops.gather_mean(rows, idx, scale), w, b)
     assert got is not None and torch.equal(got, want)
     assert torch.equal(got[:5], b.expand(5, -1))             # empty rows: bias only
+
+
+@pytest.mark.parametrize("variant", [None, 0, 12])
+def test_linear_bf16_output_is_the_rounded_fp32_result(gemm_mode, variant):
+    gemm_mode("split")
+    ops.set_gemm_variant(variant)
+    x, w, b = _rand(3, 100, 64, seed=41), _rand(512, 64, seed=42) * 0.1, _rand(512, seed=43)
+    with torch.no_grad():
+        y32 = ops.linear(x, w, b, groups=2)
+        y16 = ops.linear(x, w, b, groups=2, out_dtype=torch.bfloat16)
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    ops.set_gemm_variant(2)                 # dword-row epilogue: no bf16 packing -> not covered
+    with torch.no_grad():
+        assert ops.linear(x, w, b, out_dtype=torch.bfloat16) is None

@@ -251,3 +251,29 @@ def test_fused_front_end_declines_unsupported_shapes():
     got = ops.msda_fused(value.to(DEV), sh.to(DEV), start.to(DEV), proj.to(DEV), n_off2, ref.to(DEV),
                          None, **kw)
     assert got is None      # P = 2 is not covered: the caller must use the unfused operator
+
+
+@pytest.mark.parametrize("kind", ["sca", "tsa"])
+def test_fused_front_end_bf16_storage_kernels(kind, monkeypatch):
+    """bf16 value storage: the 16-byte-lane kernel (two x-adjacent taps per request, fp32 output
+    rows) and the 8-byte-lane kernel against the oracle evaluated on the bf16-rounded value —
+    what is left is fp32 accumulation order (and, for the bf16-output kernel, one output
+    rounding)."""
+    from bevformer_amd import ops
+    from helpers import _oracle_msda_fused
+    value, sh, start, proj, n_off, ref, rb, kw = _fused_case(kind, seed=12)
+    vb = value.to(torch.bfloat16)
+    want = _oracle_msda_fused(vb.float(), sh, start, proj, n_off, ref, rb, **kw)
+    args = (vb.to(DEV), sh.to(DEV), start.to(DEV), proj.to(DEV), n_off, ref.to(DEV),
+            rb.to(DEV) if rb is not None else None)
+    ops.set_value_storage(torch.bfloat16)
+    try:
+        got16 = ops.msda_fused(*args, **kw)
+        monkeypatch.setenv("BEVMSDA_BF16_LANES8", "1")
+        got8 = ops.msda_fused(*args, **kw)
+    finally:
+        ops.set_value_storage(torch.float32)
+    assert got16 is not None and got16.dtype == torch.float32
+    torch.testing.assert_close(got16.cpu(), want, rtol=1e-4, atol=2e-5)
+    assert got8.dtype == torch.bfloat16
+    torch.testing.assert_close(got8.float().cpu(), want, rtol=1e-2, atol=1e-2)
