@@ -309,7 +309,9 @@ def main():
             "value": Q * args.steps / dt, "unit": "BEV queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # arithmetic type of the path: fp32 accumulation / sampling / softmax / LayerNorm always;
+            # "bf16" when the GEMM operands are rounded to bf16 (--gemm bf16)
+            "dtype": "bf16" if ops.gemm_mode() == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"bevformer_{args.workload} BEV encoder forward, 1 frame/step, "
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
