@@ -17,7 +17,6 @@ import warnings
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..registry import ATTENTION, TRANSFORMER_LAYER_SEQUENCE, BaseModule, constant_, xavier_uniform_

@@ -19,7 +19,6 @@ import warnings
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..registry import ATTENTION, BaseModule, build_attention, constant_, xavier_uniform_
