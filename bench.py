@@ -46,6 +46,9 @@ def parse():
                          "kernel, sampled by the 16-byte-lane bf16 kernel; arithmetic stays fp32)")
     ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
                     help="SCA sampling kernel with the coarsest level staged in LDS (default: package default)")
+    ap.add_argument("--backward", action="store_true",
+                    help="time forward + backward of the encoder (autograd path: unfused operator with its "
+                         "backward kernels, hipBLASLt fp32 GEMMs; eager launches; BASELINE configs[2] style)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -218,7 +221,17 @@ def main():
     ops.set_kernel_timer(timer)
     ops.set_gemm_timer(timer.gemm)
 
+    if args.backward:
+        g_out = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        qg, fg = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
+
     def step():
+        if args.backward:       # fwd + bwd w.r.t. parameters, BEV queries and camera features
+            enc.zero_grad(set_to_none=True)
+            qg.grad = fg.grad = None
+            out = enc(qg, fg, fg, **kw)
+            out.backward(g_out)
+            return out.detach()
         with torch.no_grad():
             return enc(q, f, f, **kw)
 
@@ -237,7 +250,7 @@ def main():
     # around every sampling / GEMM launch of two eager steps right before; or (--graph off, or
     # a failed capture) eager launches with the events recorded inside the timed region.
     graph = None
-    use_graph = args.graph in ("on", "auto")
+    use_graph = args.graph in ("on", "auto") and not args.backward
     graph_note = "eager"
     if use_graph:
         timer.enabled = True            # kernel durations from an eager pass (events cannot
@@ -312,7 +325,7 @@ def main():
             # arithmetic type of the path: fp32 accumulation / sampling / softmax / LayerNorm always;
             # "bf16" when the GEMM operands are rounded to bf16 (--gemm bf16)
             "dtype": "bf16" if ops.gemm_mode() == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"bevformer_{args.workload} BEV encoder forward, 1 frame/step, "
+            "config": {"workload": f"bevformer_{args.workload} BEV encoder {'forward + backward' if args.backward else 'forward'}, 1 frame/step, "
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
                        "sca_row_order": enc.sca_row_order,
