@@ -328,7 +328,7 @@ def main():
             "config": {"workload": f"bevformer_{args.workload} BEV encoder {'forward + backward' if args.backward else 'forward'}, 1 frame/step, "
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
-                       "sca_row_order": enc.sca_row_order,
+                       "sca_row_order": enc.row_order() if not args.backward else ("raster" if enc.sca_row_order == "auto" else enc.sca_row_order),
                        "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "value_storage": args.value_storage,
                        "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
