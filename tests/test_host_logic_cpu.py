@@ -1,0 +1,87 @@
+"""Host-side helpers of the product package that need no GPU: cached merged / packed parameters,
+the rotation matrix handed to the rotate kernel, camera runs of the frame plan, the row order
+policy, the row-view helper of the projection op."""
+import torch
+import torch.nn as nn
+
+from bevformer_amd import ops
+from bevformer_amd import synthetic as S
+from bevformer_amd.modules import geometry
+from oracle import bevformer_cpu as O
+
+from helpers import build_pair
+
+
+def test_merged_linear_params_cache_follows_parameter_versions():
+    owner, a, b = nn.Module(), nn.Linear(8, 4), nn.Linear(8, 6)
+    with torch.no_grad():
+        w1, b1 = ops.merged_linear_params(owner, a, b)
+        w2, _ = ops.merged_linear_params(owner, a, b)
+        assert w2 is w1 and w1.shape == (10, 8) and b1.shape == (10,)
+        a.weight.mul_(2.0)                                   # in-place update bumps the version
+        w3, _ = ops.merged_linear_params(owner, a, b)
+        assert w3 is not w1 and torch.equal(w3[:4], a.weight)
+    # under autograd the concatenation must stay in the graph: never cached
+    w4, _ = ops.merged_linear_params(owner, a, b)
+    assert w4.requires_grad and w4 is not w3
+
+
+def test_rotation_theta_reproduces_the_restated_torchvision_grid():
+    """ops.rotation_theta feeds bevmsda_rotate_bev_f32; evaluating the kernel's arithmetic with it
+    in torch must give the oracle's source-index map (up to fp32 rounding ties)."""
+    for h, w, center, angle in ((12, 10, (5, 6), 4.0), (200, 200, (100, 100), -3.7), (37, 53, (20, 11), 33.0)):
+        t = torch.tensor(ops.rotation_theta(angle, center, h, w)).reshape(2, 3)
+        bx = torch.arange(w, dtype=torch.float32) + (0.5 - 0.5 * w)
+        by = torch.arange(h, dtype=torch.float32) + (0.5 - 0.5 * h)
+        gx = (bx[None, :] * t[0, 0] + by[:, None] * t[0, 1]) + t[0, 2]
+        gy = (bx[None, :] * t[1, 0] + by[:, None] * t[1, 1]) + t[1, 2]
+        ix, iy = torch.round(((gx + 1) * w - 1) / 2), torch.round(((gy + 1) * h - 1) / 2)
+        ok = (ix >= 0) & (ix <= w - 1) & (iy >= 0) & (iy <= h - 1)
+        mine = torch.where(ok, (iy * w + ix).long(), torch.full((h, w), -1, dtype=torch.long)).flatten()
+        want = O.rotate_source_index(h, w, angle, list(center))
+        assert (mine != want).float().mean().item() <= 2e-4
+
+
+def test_camera_runs_and_row_order_policy():
+    rb = torch.tensor([0, 0, 0, 2, 2, 5], dtype=torch.int32)
+    start, longest = geometry.camera_runs(rb, 6)
+    assert start.tolist() == [0, 3, 3, 5, 5, 5, 6] and longest == 3
+    start, longest = geometry.camera_runs(rb[:0], 6)
+    assert start.tolist() == [0] * 7 and longest == 0
+    enc, _ = build_pair("micro")
+    assert enc.sca_row_order == "auto"
+    with torch.no_grad():
+        assert enc.row_order() == "image"
+    assert enc.row_order() == "raster"
+    enc.sca_row_order = "image"
+    assert enc.row_order() == "image"
+    q, f, kw = S.make_inputs("micro", seed=0)
+    with torch.no_grad():
+        plan = enc.frame_plan(kw["bev_h"], kw["bev_w"], 1, kw["img_metas"], torch.device("cpu"), torch.float32)
+    assert plan.cam_start.tolist()[0] == 0 and plan.cam_start.tolist()[-1] == plan.row_batch.numel()
+    assert plan.max_cam_rows == max(plan.hits)
+    assert (plan.row_batch[1:] >= plan.row_batch[:-1]).all()          # rows grouped by camera
+
+
+def test_rows2d_views_without_copies():
+    x = torch.randn(2, 5, 64)
+    v, ld = ops._rows2d(x, 64)
+    assert v.shape == (10, 64) and ld == 64 and v.data_ptr() == x.data_ptr()
+    big = torch.randn(7, 96)
+    v, ld = ops._rows2d(big[:, 32:], 64)                              # strided rows: still a view
+    assert ld == 96 and v.data_ptr() == big[:, 32:].data_ptr()
+    v, ld = ops._rows2d(big[:, 1:65], 64)                             # misaligned offset: copied
+    assert ld == 64 and v.data_ptr() != big[:, 1:65].data_ptr()
+
+
+def test_projection_op_declines_on_cpu_and_in_native_mode():
+    x, w = torch.randn(4, 64), torch.randn(8, 64)
+    saved = ops.gemm_mode()
+    try:
+        ops.set_gemm_mode("split")
+        with torch.no_grad():
+            assert ops.linear(x, w) is None                           # CPU tensors: caller uses torch
+            torch.testing.assert_close(ops.linear_or_torch(x, w, relu=True), torch.relu(x @ w.t()))
+            assert ops.linear_gather_mean(x, torch.zeros(4, 2, dtype=torch.int32), torch.ones(4), w) is None
+    finally:
+        ops.set_gemm_mode(saved)
