@@ -59,9 +59,23 @@ class FFN(BaseModule):
             y = torch.addmm(fc.bias, h, fc.weight.t())
         return y.view(*lead, fc.out_features)
 
+    def _dropout_inactive(self):
+        return not self.training or all(m.p == 0 for m in self.layers.modules() if isinstance(m, nn.Dropout))
+
+    def _layers_autograd(self, x):
+        """``self.layers`` with dropout inactive, Linear layers through ``ops.linear_or_torch``
+        (MFMA kernel inside an autograd Function; fc1's ReLU in its epilogue)."""
+        h = x
+        for blk in list(self.layers)[:-2]:
+            h = ops.linear_or_torch(h, blk[0].weight, blk[0].bias, relu=True, tag="ffn_fc1")
+        fc = self.layers[-2]
+        return ops.linear_or_torch(h, fc.weight, fc.bias, tag="ffn_fc2")
+
     def forward(self, x, identity=None, defer_residual=False):
         if not self.training and not torch.is_grad_enabled():
             out = self._layers_inference(x)
+        elif self._dropout_inactive() and x.is_cuda:
+            out = self._layers_autograd(x)
         else:
             out = self.layers(x)
         if not self.add_identity:

@@ -20,7 +20,6 @@ import warnings
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..registry import ATTENTION, BaseModule, constant_, xavier_uniform_
@@ -173,7 +172,7 @@ class TemporalSelfAttention(BaseModule):
         if proj is None:
             if self.batch_first and query_pos is not None:
                 query = query + query_pos
-            proj = F.linear(torch.cat([first, query], -1), w, b)
+            proj = ops.linear_or_torch(torch.cat([first, query], -1), w, b, tag="tsa_offs_attn")
         out = None
         if reference_points.shape[-1] == 2 and self.batch_first and key_padding_mask is None \
                 and ops.fused_wanted(proj, v):

@@ -374,7 +374,7 @@ def _rows2d(t, K):
 
 
 def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, groups=1,
-           out_dtype=torch.float32, tag="linear"):
+           out_dtype=torch.float32, tag="linear", _inside_autograd=False):
     """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
     ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
     covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
@@ -383,8 +383,8 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     ``groups = G > 1``: ``weight`` is the row-wise concatenation of G Linear layers that share
     the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x."""
     mode = _GEMM["mode"]
-    if mode == "native" or not x.is_cuda or x.dtype != torch.float32 \
-            or weight.dtype != torch.float32 or not fused_wanted(x, weight, bias, x_add, x2, x2_add):
+    if mode == "native" or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
+            or not (_inside_autograd or fused_wanted(x, weight, bias, x_add, x2, x2_add)):
         return None
     K0 = x.shape[-1]
     K1 = x2.shape[-1] if x2 is not None else 0
@@ -493,13 +493,74 @@ def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
     return y
 
 
+def transposed_weight(weight):
+    """Contiguous ``weight.t()`` cached on the tensor until it is written to: the operand of the
+    input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""
+    key = (weight._version, weight.data_ptr(), tuple(weight.shape))
+    hit = getattr(weight, "_bevmsda_wt", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        wt = weight.detach().t().contiguous()
+    try:
+        weight._bevmsda_wt = (key, wt)
+    except AttributeError:
+        pass
+    return wt
+
+
+class _LinearFunction(Function):
+    """``act(x @ weight.T + bias)`` on the MFMA kernel under autograd: forward and the input
+    gradient (``grad_y @ weight``: the same kernel over the transposed weight) run on K3, the
+    weight gradient (a reduction over the rows: a TN GEMM) on hipBLASLt."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, tag):
+        y = linear(x.detach(), weight.detach(), None if bias is None else bias.detach(), relu=relu, tag=tag,
+                   _inside_autograd=True)
+        if y is None:                      # shape not covered after all: plain torch, no custom backward
+            raise RuntimeError("bevmsda: _LinearFunction called on a shape the MFMA kernel does not cover")
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.tag = tag
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            gy = gy * (y > 0).to(gy.dtype)
+        K = x.shape[-1]
+        g2 = gy.reshape(-1, gy.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(g2, transposed_weight(weight), None, tag=ctx.tag + "_dx", _inside_autograd=True)
+            if gx is None:
+                gx = g2 @ weight
+            gx = gx.view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = g2.t() @ x.reshape(-1, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb, None, None
+
+
 def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
-    """``linear`` with the torch statement as the not-covered path (single-source form)."""
+    """``linear`` with the torch statement as the not-covered path (single-source form).  Under
+    autograd (GEMM mode not ``native``) the MFMA kernel runs inside ``_LinearFunction``."""
     y = linear(x, weight, bias, relu=relu, tag=tag)
-    if y is None:
-        y = torch.nn.functional.linear(x, weight, bias)
-        if relu:
-            y = torch.relu_(y)
+    if y is not None:
+        return y
+    if _GEMM["mode"] != "native" and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 \
+            and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] % 32 == 0 \
+            and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1] \
+            and (x.requires_grad or weight.requires_grad):
+        return _LinearFunction.apply(x, weight, bias, relu, tag)
+    y = torch.nn.functional.linear(x, weight, bias)
+    if relu:
+        y = torch.relu_(y)
     return y
 
 

@@ -205,3 +205,26 @@ def test_linear_bf16_output_is_the_rounded_fp32_result(gemm_mode, variant):
     ops.set_gemm_variant(2)                 # dword-row epilogue: no bf16 packing -> not covered
     with torch.no_grad():
         assert ops.linear(x, w, b, out_dtype=torch.bfloat16) is None
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_autograd_function_matches_torch(gemm_mode, relu):
+    """Under autograd ``linear_or_torch`` runs the MFMA kernel inside an autograd Function:
+    forward, input gradient (same kernel over the transposed weight), weight / bias gradients."""
+    gemm_mode("split")
+    x = _rand(3, 70, 128, seed=51).requires_grad_(True)
+    w = (_rand(96, 128, seed=52) * 0.1).requires_grad_(True)
+    b = _rand(96, seed=53).requires_grad_(True)
+    g = _rand(3, 70, 96, seed=54)
+    y = ops.linear_or_torch(x, w, b, relu=relu)
+    assert y.grad_fn is not None and "LinearFunction" in type(y.grad_fn).__name__
+    y.backward(g)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(g)
+    torch.testing.assert_close(y.detach(), yr.detach(), rtol=1e-4, atol=1e-4)
+    for got, want, what in ((x.grad, xr.grad, "dx"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        assert err < 1e-4, f"{what}: {err:.2e}"
