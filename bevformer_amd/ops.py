@@ -302,7 +302,9 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
          # (include/bevmsda.h, bevmsda_linear_desc.reserved[0]); v >= 4 uses the pre-split weight image
          "variant": (int(os.environ["BEVMSDA_GEMM_VARIANT"]) if os.environ.get("BEVMSDA_GEMM_VARIANT")
                      else None),
-         "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1"}
+         "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1",
+         # autograd path: forward projections on the MFMA kernel too (see _LinearFunction)
+         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "0") == "1"}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -510,14 +512,26 @@ def transposed_weight(weight):
 
 
 class _LinearFunction(Function):
-    """``act(x @ weight.T + bias)`` on the MFMA kernel under autograd: forward and the input
-    gradient (``grad_y @ weight``: the same kernel over the transposed weight) run on K3, the
-    weight gradient (a reduction over the rows: a TN GEMM) on hipBLASLt."""
+    """``act(x @ weight.T + bias)`` under autograd with the input gradient (``grad_y @ weight``:
+    the projection kernel over the transposed weight) on the MFMA kernel; the weight gradient
+    (a reduction over the rows: a TN GEMM) runs on hipBLASLt.
+
+    The FORWARD stays on hipBLASLt fp32 by default: the gradient of bilinear sampling w.r.t. the
+    sampling location is piecewise constant — discontinuous at pixel boundaries — so the 4e-6
+    (instead of 1e-6) forward round-off of the split-bf16 kernel moves a few more sampling points
+    across a boundary than the library GEMM does and the *gradients* then differ from the fp32
+    oracle by up to 1e-2 of their scale although the forward output agrees to 7e-6 (measured:
+    tools/dbg_bwd.py).  ``BEVMSDA_TRAIN_FWD_MFMA=1`` puts the forward on the kernel as well
+    (76.9 vs 81.9 ms per base frame fwd + bwd) for users who accept that."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, tag):
-        y = linear(x.detach(), weight.detach(), None if bias is None else bias.detach(), relu=relu, tag=tag,
-                   _inside_autograd=True)
+        if _GEMM["train_forward_mfma"]:
+            y = linear(x.detach(), weight.detach(), None if bias is None else bias.detach(), relu=relu, tag=tag,
+                       _inside_autograd=True)
+        else:
+            y = torch.nn.functional.linear(x.detach(), weight.detach(), None if bias is None else bias.detach())
+            y = torch.relu_(y) if relu else y
         if y is None:                      # shape not covered after all: plain torch, no custom backward
             raise RuntimeError("bevmsda: _LinearFunction called on a shape the MFMA kernel does not cover")
         ctx.relu = bool(relu)

@@ -209,8 +209,8 @@ def test_linear_bf16_output_is_the_rounded_fp32_result(gemm_mode, variant):
 
 @pytest.mark.parametrize("relu", [False, True])
 def test_linear_autograd_function_matches_torch(gemm_mode, relu):
-    """Under autograd ``linear_or_torch`` runs the MFMA kernel inside an autograd Function:
-    forward, input gradient (same kernel over the transposed weight), weight / bias gradients."""
+    """Under autograd ``linear_or_torch`` is an autograd Function: input gradient on the MFMA
+    kernel (over the transposed weight), forward on the library GEMM or (knob) on the kernel."""
     gemm_mode("split")
     x = _rand(3, 70, 128, seed=51).requires_grad_(True)
     w = (_rand(96, 128, seed=52) * 0.1).requires_grad_(True)
