@@ -50,15 +50,16 @@ def _worker(rank, world, port, name, temporal, bs, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,temporal,bs", [("micro", True, 1), ("micro", False, 1),
-                                              ("micro4", True, 2)])
-def test_two_rank_tiling_matches_single(name, temporal, bs):
+@pytest.mark.parametrize("name,temporal,bs,world", [("micro", True, 1, 2), ("micro", False, 1, 2),
+                                                    ("micro4", True, 2, 2), ("micro", True, 1, 5)])
+def test_two_rank_tiling_matches_single(name, temporal, bs, world):
+    """world 2 (even row blocks) and world 5 (12 BEV rows -> blocks of 3, 3, 2, 2, 2: padded shards
+    in the all-gather)."""
     from bevformer_amd import synthetic as S
     try:
         S.make_inputs(name, seed=0, temporal=temporal, bs=bs)
     except TypeError:
         pytest.skip("synthetic.make_inputs has no bs argument")
-    world = 2
     port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
