@@ -46,6 +46,10 @@ def parse():
                          "kernel, sampled by the 16-byte-lane bf16 kernel; arithmetic stays fp32)")
     ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
                     help="SCA sampling kernel with the coarsest level staged in LDS (default: package default)")
+    ap.add_argument("--queue", type=int, default=0,
+                    help="N > 0: a step is N consecutive frames through PerceptionTransformer.get_bev_features "
+                         "(ego-motion shift, prev-BEV rotation, can-bus MLP, flatten + embeddings, encoder), each "
+                         "frame's BEV being the next frame's history (BASELINE configs[4] style; eager launches)")
     ap.add_argument("--backward", action="store_true",
                     help="time forward + backward of the encoder (autograd path: unfused operator with its "
                          "backward kernels, hipBLASLt fp32 GEMMs; eager launches; BASELINE configs[2] style)")
@@ -221,11 +225,24 @@ def main():
     ops.set_kernel_timer(timer)
     ops.set_gemm_timer(timer.gemm)
 
+    if args.queue > 0:
+        tr = bevformer_amd.build_transformer(S.transformer_cfg(args.workload)).eval()
+        tr.init_weights()
+        tr.encoder = enc                       # the encoder above (trained-like weights, tiling if enabled)
+        tr = tr.to(dev)
+        mlvl, bq, tkw = S.make_transformer_inputs(args.workload, seed=0, temporal=False, device=dev)
+        tkw.pop("prev_bev")
     if args.backward:
         g_out = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
         qg, fg = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
 
     def step():
+        if args.queue > 0:      # frame i's BEV is frame i+1's history; frame 0 has none
+            with torch.no_grad():
+                prev = None
+                for _ in range(args.queue):
+                    prev = tr.get_bev_features(mlvl, bq, prev_bev=prev, **tkw)
+            return prev
         if args.backward:       # fwd + bwd w.r.t. parameters, BEV queries and camera features
             enc.zero_grad(set_to_none=True)
             qg.grad = fg.grad = None
@@ -250,7 +267,7 @@ def main():
     # around every sampling / GEMM launch of two eager steps right before; or (--graph off, or
     # a failed capture) eager launches with the events recorded inside the timed region.
     graph = None
-    use_graph = args.graph in ("on", "auto") and not args.backward
+    use_graph = args.graph in ("on", "auto") and not args.backward and args.queue == 0
     graph_note = "eager"
     if use_graph:
         timer.enabled = True            # kernel durations from an eager pass (events cannot
@@ -319,13 +336,15 @@ def main():
         line = {
             "metric": "BEV-encoder queries/sec (200x200 BEV, 6 cams, 4 lvls)" if args.workload == "base"
             else f"BEV-encoder queries/sec ({args.workload})",
-            "value": Q * args.steps / dt, "unit": "BEV queries/s", "n_gpus": world,
+            "value": Q * max(1, args.queue) * args.steps / dt, "unit": "BEV queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             # arithmetic type of the path: fp32 accumulation / sampling / softmax / LayerNorm always;
             # "bf16" when the GEMM operands are rounded to bf16 (--gemm bf16)
             "dtype": "bf16" if ops.gemm_mode() == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"bevformer_{args.workload} BEV encoder {'forward + backward' if args.backward else 'forward'}, 1 frame/step, "
+            "config": {"workload": f"bevformer_{args.workload} BEV encoder {'forward + backward' if args.backward else 'forward'}, "
+                                   f"{args.queue if args.queue else 1} frame{'s' if args.queue > 1 else ''}/step"
+                                   f"{' through get_bev_features with a rolling history BEV' if args.queue else ''}, "
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
                                    f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
                        "sca_row_order": enc.row_order() if not args.backward else ("raster" if enc.sca_row_order == "auto" else enc.sca_row_order),
