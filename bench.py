@@ -346,7 +346,9 @@ def main():
                                    f"{args.queue if args.queue else 1} frame{'s' if args.queue > 1 else ''}/step"
                                    f"{' through get_bev_features with a rolling history BEV' if args.queue else ''}, "
                                    f"{w['bev_h']}x{w['bev_w']} queries, 6 cams, {len(w['shapes'])} levels, "
-                                   f"{w['layers']} layers, {'first frame (no history)' if args.first_frame else 'with history BEV'}",
+                                   f"{w['layers']} layers, " + ("frame 0 without history, frames 1.. with the previous frame's BEV"
+                                                           if args.queue else
+                                                           ('first frame (no history)' if args.first_frame else 'with history BEV')),
                        "sca_row_order": enc.row_order() if not args.backward else ("raster" if enc.sca_row_order == "auto" else enc.sca_row_order),
                        "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "value_storage": args.value_storage,
