@@ -333,6 +333,10 @@ def main():
                 traffic = json.load(open(args.traffic_json)).get(args.workload, {}).get("sca_fwd")
             except Exception:
                 traffic = None
+        # what the timed steps used: the encoder picks the row order by grad mode
+        with torch.set_grad_enabled(args.backward):
+            row_order_used = enc.row_order()
+            rows_per_frame = int(sum(enc.frame_plan(w['bev_h'], w['bev_w'], 1, kw['img_metas'], dev, torch.float32).hits))
         line = {
             "metric": "BEV-encoder queries/sec (200x200 BEV, 6 cams, 4 lvls)" if args.workload == "base"
             else f"BEV-encoder queries/sec ({args.workload})",
@@ -349,7 +353,7 @@ def main():
                                    f"{w['layers']} layers, " + ("frame 0 without history, frames 1.. with the previous frame's BEV"
                                                            if args.queue else
                                                            ('first frame (no history)' if args.first_frame else 'with history BEV')),
-                       "sca_row_order": enc.row_order() if not args.backward else ("raster" if enc.sca_row_order == "auto" else enc.sca_row_order),
+                       "sca_row_order": row_order_used,
                        "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "value_storage": args.value_storage,
                        "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
@@ -357,7 +361,7 @@ def main():
                                 "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",
                                 "native": "hipBLASLt fp32 (torch.nn.functional.linear)"}[ops.gemm_mode()],
                        "global_batch": 1, "parallelism": f"bev-row-tiles x{world}" if world > 1 else "single GPU",
-                       "sca_rows_per_frame": int(sum(enc.frame_plan(w['bev_h'], w['bev_w'], 1, kw['img_metas'], dev, torch.float32).hits))},
+                       "sca_rows_per_frame": rows_per_frame},
             "roofline": {"kernel": "msda_fwd (SCA sampling, ragged rows)", "bound": "hbm",
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
