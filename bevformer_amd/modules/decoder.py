@@ -19,7 +19,9 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..registry import ATTENTION, TRANSFORMER_LAYER_SEQUENCE, BaseModule, constant_, xavier_uniform_
+from ..registry import (ATTENTION, HAVE_MMCV, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, BaseModule,
+                        constant_, xavier_uniform_)
+from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .encoder import TransformerLayerSequence
 from .temporal_self_attention import _direction_grid, _is_power_of_2
 
@@ -161,3 +163,86 @@ class CustomMSDeformableAttention(BaseModule):
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         return self.dropout(out) + identity
+
+
+# ---------------------------------------------------------------------------
+# The two third-party classes the reference's decoder config names
+# (bevformer_base.py:110-127): mmcv's ``MultiheadAttention`` wrapper and mmdet's
+# ``DetrTransformerDecoderLayer``.  Neither lives in the reference tree (mmcv-full 1.4.0 /
+# mmdet 2.14.0, docs/install.md:27,33); when those packages are installed their own classes are
+# used and nothing below is registered.  Without them, these restatements — from the published
+# behaviour of the two classes, NOT pinned against their source (third-party, absent) — let the
+# reference's decoder config build and ``PerceptionTransformer.forward`` run stand-alone.
+# ---------------------------------------------------------------------------
+
+class MultiheadAttention(BaseModule):
+    """``identity + dropout(proj_drop(nn.MultiheadAttention(q + q_pos, k + k_pos, v)))`` with
+    mmcv's defaults: key = query, value = key, identity = query, key_pos = query_pos when the
+    shapes agree; parameters under ``attn.*`` (``in_proj_weight``, ``in_proj_bias``,
+    ``out_proj.{weight,bias}``)."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0,
+                 dropout_layer=dict(type="Dropout", drop_prob=0.0), init_cfg=None, batch_first=False,
+                 **kwargs):
+        super().__init__(init_cfg)
+        dropout_layer = dict(dropout_layer) if dropout_layer else None
+        if "dropout" in kwargs:             # deprecated spelling used by the BEVFormer configs
+            attn_drop = kwargs["dropout"]
+            if dropout_layer is not None:
+                dropout_layer["drop_prob"] = kwargs.pop("dropout")
+            else:
+                kwargs.pop("dropout")
+        self.embed_dims = embed_dims
+        self.num_heads = num_heads
+        self.batch_first = batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+        self.proj_drop = nn.Dropout(proj_drop)
+        p = dropout_layer.get("drop_prob", 0.0) if dropout_layer else 0.0
+        self.dropout_layer = nn.Dropout(p) if dropout_layer else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
+                attn_mask=None, key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None and query_pos is not None:
+            if query_pos.shape == key.shape:
+                key_pos = query_pos
+            else:
+                warnings.warn(f"position encoding of key is missing in {self.__class__.__name__}.")
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        if self.batch_first:
+            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask,
+                        key_padding_mask=key_padding_mask)[0]
+        if self.batch_first:
+            out = out.transpose(0, 1)
+        return identity + self.dropout_layer(self.proj_drop(out))
+
+
+class DetrTransformerDecoderLayer(MyCustomBaseTransformerLayer):
+    """mmdet's decoder layer: the generic op-order layer with ``batch_first=False`` and the
+    six-operation order (self_attn, norm, cross_attn, norm, ffn, norm)."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN"), ffn_num_fcs=2,
+                 **kwargs):
+        kwargs.setdefault("batch_first", False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                             ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
+                             norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        assert len(operation_order) == 6
+        assert set(operation_order) == set(["self_attn", "norm", "cross_attn", "ffn"])
+
+
+if not HAVE_MMCV:
+    ATTENTION.register_module(name="MultiheadAttention", module=MultiheadAttention)
+    TRANSFORMER_LAYER.register_module(name="DetrTransformerDecoderLayer", module=DetrTransformerDecoderLayer)

@@ -149,6 +149,20 @@ def decoder_cfg(num_layers=2, num_levels=1):
             operation_order=("cross_attn", "norm", "ffn", "norm")))
 
 
+def reference_decoder_cfg(num_layers=6):
+    """The ``decoder=dict(...)`` block of projects/configs/bevformer/bevformer_base.py:106-127
+    verbatim (third-party layer types: built by mmcv / mmdet when installed, by this package's
+    restatements otherwise)."""
+    return dict(
+        type="DetectionTransformerDecoder", num_layers=num_layers, return_intermediate=True,
+        transformerlayers=dict(
+            type="DetrTransformerDecoderLayer",
+            attn_cfgs=[dict(type="MultiheadAttention", embed_dims=EMBED_DIMS, num_heads=8, dropout=0.1),
+                       dict(type="CustomMSDeformableAttention", embed_dims=EMBED_DIMS, num_levels=1)],
+            feedforward_channels=EMBED_DIMS * 2, ffn_dropout=0.1,
+            operation_order=("self_attn", "norm", "cross_attn", "norm", "ffn", "norm")))
+
+
 def make_decoder_inputs(bev_h, bev_w, num_query=37, bs=2, seed=0, device="cpu"):
     """query / query_pos (nq, bs, C), value = bev_embed (Q, bs, C), reference_points
     (bs, nq, 3) in (0, 1), the (1, 2) / (1,) BEV level tensors (transformer.py:274-284)."""
