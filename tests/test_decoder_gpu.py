@@ -91,3 +91,27 @@ def test_attention_backward_matches_oracle_autograd():
     close(vd.grad.cpu(), vc.grad, "value grad")
     for name, p in mod.named_parameters():
         close(p.grad.cpu(), sdg["a." + name].grad, name)
+
+
+def test_full_transformer_forward_gpu_matches_cpu_path():
+    """PerceptionTransformer.forward built from the reference's transformer config (encoder +
+    prologue + 2-layer decoder with self-attention): the GPU product path against the same module
+    on CPU with every kernel routed through the oracle."""
+    from helpers import oracle_ops
+    cfg = S.transformer_cfg("micro")
+    cfg["decoder"] = S.reference_decoder_cfg(num_layers=2)
+    torch.manual_seed(0)
+    t = bevformer_amd.build_transformer(cfg).eval()
+    t.init_weights()
+    sd = _trained(t.state_dict(), seed=9)
+    t.load_state_dict(sd)
+    mlvl, bq, kw = S.make_transformer_inputs("micro", seed=0, bs=1, temporal=True)
+    oqe = torch.randn(13, 512, generator=torch.Generator().manual_seed(1))
+    reg = _Reg(2)
+    with torch.no_grad():
+        with oracle_ops():
+            want = t(mlvl, bq, oqe, reg_branches=reg, **kw)
+        kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        got = t.to(DEV)([f.to(DEV) for f in mlvl], bq.to(DEV), oqe.to(DEV), reg_branches=reg.to(DEV), **kwd)
+    for g, w_, tol in zip(got, want, (1e-3, 2e-3, 1e-5, 1e-3)):
+        torch.testing.assert_close(g.cpu(), w_, rtol=tol, atol=tol)
