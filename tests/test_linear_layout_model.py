@@ -114,3 +114,63 @@ def test_lds_image_is_conflict_free_for_b128_fragment_reads():
             for d in range(4):
                 banks.add((byte // 4 + d) % 64)
         assert len(banks) == 64
+
+
+# -- packed weight image, transposed-tile epilogue and grouped output (same lane-level style) --------
+
+def _pack_weight(w):
+    """lin_pack_weight_kernel's index arithmetic: blob[(n/128 * K/32 + k/32) * 2 * PLANE + plane * PLANE
+    + (n % 128) * ROW + k % 32] (rows >= N and the 8-element row pad are zero; one plane modelled)."""
+    N, K = w.shape
+    nt, kc = (N + 127) // 128, K // 32
+    blob = np.zeros(nt * kc * 2 * PLANE)
+    for n in range(N):
+        for k in range(K):
+            blob[((n // 128) * kc + k // 32) * 2 * PLANE + (n % 128) * ROW + k % 32] = w[n, k]
+    return blob
+
+
+def test_packed_weight_chunk_is_the_lds_image_the_fragments_read():
+    """WMODE 3: chunk (nt, c) of the blob is copied verbatim into the W area; the B fragment of lane l
+    for tile j, k-step ks must be W[n0 + wn*64 + j*32 + (l & 31), kc + ks*16 + 8*(l >> 5) .. + 7]."""
+    rng = np.random.default_rng(1)
+    N, K = 200, 96
+    w = rng.standard_normal((N, K))
+    blob = _pack_weight(w)
+    kcn = K // 32
+    for nt in range(2):
+        for c in range(kcn):
+            chunk = blob[(nt * kcn + c) * 2 * PLANE:(nt * kcn + c) * 2 * PLANE + PLANE]     # hi plane = LDS image
+            for wn in range(2):
+                for j in range(2):
+                    for ks in range(2):
+                        for lane in (0, 5, 31, 32, 47, 63):
+                            bo = (wn * 64 + (lane & 31)) * ROW + (lane >> 5) * 8 + j * 32 * ROW + ks * 16
+                            n = nt * 128 + wn * 64 + j * 32 + (lane & 31)
+                            k = c * 32 + ks * 16 + (lane >> 5) * 8
+                            want = w[n, k:k + 8] if n < N else np.zeros(8)
+                            np.testing.assert_array_equal(chunk[bo:bo + 8], want)
+
+
+def test_transposed_tile_epilogue_and_grouped_output_cover_every_element_once():
+    """SWAP epilogue: the MFMA computes D[n][m] (W fragment as the A operand), so lane l holds output
+    row m = l & 31 and, in registers 4g .. 4g+3, columns nb + 8g .. +3 with nb = 4 (l >> 5): one
+    16-byte store per g.  With group_cols the column n lands in matrix n / group_cols."""
+    M, N, gc = 150, 512, 256
+    groups = N // gc
+    seen = np.zeros((groups, M, gc), dtype=int)
+    for m0 in range(0, M, BM):
+        for n0 in range(0, N, BN):
+            grp, ncol0 = n0 // gc, (n0 // gc) * gc
+            for wave in range(4):
+                wm, wn = wave >> 1, wave & 1
+                for lane in range(64):
+                    for i in range(2):
+                        m = m0 + wm * 64 + i * 32 + (lane & 31)
+                        for j in range(2):
+                            nb = n0 + wn * 64 + j * 32 + 4 * (lane >> 5)
+                            for g in range(4):
+                                n = nb + 8 * g
+                                if m < M and n < N:
+                                    seen[grp, m, n - ncol0:n - ncol0 + 4] += 1
+    assert (seen == 1).all()
