@@ -1,27 +1,38 @@
 """BEV-encoder throughput bench (driver contract).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base] [--dtype fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one forward pass of the whole BEV encoder (all layers: TSA -> LN ->
-SCA -> LN -> FFN -> LN, including the per-frame geometry plan lookup) over one
-synthetic frame of the workload (default ``base`` = bevformer_base: 200x200 BEV
-queries, 6 cameras, 4 feature levels, 6 layers) with a history BEV
-(``prev_bev``) present, inputs resident in HBM.  ``value`` = BEV queries / s for
-the whole job.  With N > 1 the ONE frame is tiled over the N GPUs by BEV rows
-(strong scaling) and reassembled with an RCCL all-gather inside the timed step.
+One "step" = one forward pass of the whole BEV encoder (per-frame geometry: camera
+projection, visibility, ragged row lists — then all layers: TSA -> LN -> SCA -> LN ->
+FFN -> LN) over one synthetic frame of the workload (default ``base`` =
+bevformer_base: 200x200 BEV queries, 6 cameras, 4 feature levels, 6 layers) with a
+history BEV (``prev_bev``) present, inputs resident in HBM.  Every step gets NEW camera
+matrices (a seeded ego-pose jitter of the synthetic rig, as nuScenes rebuilds
+``lidar2img`` per sample), so the frame plan is rebuilt inside the timed region.
+``value`` = BEV queries / s for the whole job.  With N > 1 the ONE frame is tiled over the
+N GPUs by BEV rows (strong scaling) and reassembled with an RCCL all-gather inside the
+timed step.
 
-Prints one JSON line on rank 0 with the extra objects ``roofline`` (dominant
-hand-written kernel: the SCA deformable-sampling forward, timed live with HIP
-events on its launch stream) and ``cpu_baseline`` (the oracle's pure-PyTorch
-CPU port of the same encoder, timed on the host cores, N = 1 only).
+Prints one JSON line on rank 0.  Besides the contract keys it carries
+  ``roofline``      the dominant hand-written HBM-bound kernel (SCA deformable-sampling
+                    forward), timed live with HIP events on its launch stream;
+  ``cpu_baseline``  the oracle's pure-PyTorch CPU port of the same encoder on the host
+                    cores (1 warm-up + 3 runs, median; N = 1 only);
+  ``parity``        the GPU output of the benched configuration against that oracle run
+                    (the run FAILS when it is outside the stated tolerance);
+  ``windows``       the K-step window repeated, min / median;
+  ``variants``      the same step in the other arithmetic modes (strict-fp32 GEMMs, the bf16
+                    configuration) and forward + backward (base and small4), N = 1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+ENC_TOL = 2e-4         # encoder-level fp32 tolerance (tests/test_encoder_gpu.py uses the same)
+N_RIGS = 8             # distinct camera-matrix sets cycled through by the steps
 
 
 def parse():
@@ -36,8 +49,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5, help="how many times the K-step window is timed")
     ap.add_argument("--workload", default="base")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32"])
     ap.add_argument("--gemm", default=None, choices=["split", "bf16", "native"],
                     help="how the Linear layers run (bevformer_amd.ops.set_gemm_mode); default: the "
                          "package default / BEVMSDA_GEMM")
@@ -45,32 +58,37 @@ def parse():
                     help="storage of the projected value tensors (bf16: written by the projection "
                          "kernel, sampled by the 16-byte-lane bf16 kernel; arithmetic stays fp32)")
     ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
-                    help="SCA sampling kernel with the coarsest level staged in LDS (default: package default)")
+                    help="SCA sampling kernel with the coarsest level staged in LDS (host-built plans only)")
     ap.add_argument("--queue", type=int, default=0,
                     help="N > 0: a step is N consecutive frames through PerceptionTransformer.get_bev_features "
                          "(ego-motion shift, prev-BEV rotation, can-bus MLP, flatten + embeddings, encoder), each "
                          "frame's BEV being the next frame's history (BASELINE configs[4] style; eager launches)")
     ap.add_argument("--backward", action="store_true",
-                    help="time forward + backward of the encoder (autograd path: unfused operator with its "
-                         "backward kernels, hipBLASLt fp32 GEMMs; eager launches; BASELINE configs[2] style)")
+                    help="time forward + backward of the encoder (autograd path; eager launches; "
+                         "BASELINE configs[2] style)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
+    ap.add_argument("--static-rig", action="store_true",
+                    help="same camera matrices every step (the frame plan is then built once)")
+    ap.add_argument("--host-plans", action="store_true",
+                    help="frame plans from the torch-op builder with its host syncs instead of the HIP kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra configurations (variants)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph in the timed region "
                          "(auto = on, falling back to eager launches if the capture fails; the "
                          "per-kernel HIP-event timings come from an eager pass right before)")
     ap.add_argument("--force-tiling", action="store_true",
                     help="run the multi-GPU schedule (row blocks + RCCL all-gather) even on 1 rank")
-    ap.add_argument("--row-order", default=None, choices=["raster", "image"],
+    ap.add_argument("--row-order", default=None, choices=["raster", "image", "polar"],
                     help="order of the ragged SCA rows inside a camera (default: the encoder's)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
-                    help="PMC-derived HBM bytes per launch of the roofline kernel (optional)")
+                    help="PMC-derived HBM bytes per launch of the roofline kernel from an earlier profile run")
     return ap.parse_args()
 
 
 class KernelTimer:
-    """HIP-event timing of the sampling-kernel launches inside the timed
-    region, recorded on the stream the kernel is launched on."""
+    """HIP-event timing of the sampling-kernel / GEMM / frame-plan launches, recorded on the
+    stream the kernels are launched on."""
 
     def __init__(self):
         self.events = []   # (tag, start, end, alg_bytes)
@@ -98,17 +116,21 @@ class KernelTimer:
         """Same bracket for the projection GEMM launches (ops.set_gemm_timer)."""
         return self("gemm:" + tag, (flops, nbytes))
 
-    def summary(self):
+    def summary(self, rows):
+        """``rows``: the frame's actual ragged row count (device-side plans report their
+        algorithmic bytes as (fixed, per row))."""
         agg = {}
         for tag, s, e, b in self.events:
             if tag.startswith("gemm:"):
                 continue
+            if isinstance(b, tuple):
+                b = b[1] + b[2] * rows
             a = agg.setdefault(tag, [0.0, 0, 0])
             a[0] += s.elapsed_time(e) * 1e-3
             a[1] += 1
             a[2] += b
         return {t: dict(avg_us=a[0] / a[1] * 1e6, launches=a[1], alg_bytes=a[2] / a[1],
-                        GBs=a[2] / a[0] / 1e9) for t, a in agg.items()}
+                        GBs=(a[2] / a[0] / 1e9) if a[2] else None) for t, a in agg.items()}
 
     def gemm_summary(self):
         agg = {}
@@ -154,9 +176,11 @@ def _pick_cpu_threads(cores):
     return best, seen
 
 
-def cpu_baseline(workload, sd, first_frame):
-    """The oracle's CPU port of the encoder on the host cores (bounded sample:
-    ONE frame of the same workload; fp32, no_grad; thread count picked by a probe)."""
+def cpu_baseline(workload, sd, first_frame, runs=3):
+    """The oracle's CPU port of the encoder on the host cores (bounded sample: frames of the
+    same workload; fp32, no_grad; thread count picked by a probe; BASELINE.md §2 protocol: one
+    warm-up run, then ``runs`` timed runs, median).  Returns (json object, oracle output of the
+    frame) — the output is what ``parity`` checks the GPU step against."""
     from bevformer_amd import synthetic as S
     from oracle import bevformer_cpu as O
     cores = os.cpu_count() or 1
@@ -164,18 +188,183 @@ def cpu_baseline(workload, sd, first_frame):
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in sd.items()}
     w = S.WORKLOADS[workload]
+    times = []
     with torch.no_grad():
         q, f, kw = S.make_inputs(workload, seed=0, temporal=not first_frame)
-        t0 = time.perf_counter()
-        O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
-        dt = time.perf_counter() - t0
+        for i in range(1 + runs):
+            t0 = time.perf_counter()
+            out = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+            if i:
+                times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     Q = w["bev_h"] * w["bev_w"]
     return dict(value=Q / dt, unit="BEV queries/s", cores=threads, kind="port",
-                seconds=dt, host_cpus=cores,
-                thread_probe_tiny_frame_s={str(k): round(v, 3) for k, v in probe.items()},
+                seconds=dt, runs_s=[round(t, 3) for t in times], protocol="1 warm-up + 3 runs, median",
+                host_cpus=cores, thread_probe_tiny_frame_s={str(k): round(v, 3) for k, v in probe.items()},
                 sample=f"1 frame of {workload} ({w['layers']} layers, {Q} queries, "
                        f"{'no ' if first_frame else ''}history BEV) through oracle/bevformer_cpu.py "
-                       "(pure-PyTorch CPU fallback path of the reference, fp32, no_grad)")
+                       "(pure-PyTorch CPU fallback path of the reference, fp32, no_grad)"), out
+
+
+def jittered_rigs(workload, n, device):
+    """(n, Nc, 4, 4) fp32 device tensor of camera matrices: entry 0 is the synthetic rig of
+    SURVEY §8d, the others the same rig under a small seeded ego-pose change (yaw ~ 0.6 deg,
+    translation ~ 0.2 m) — nuScenes rebuilds lidar2img per sample from per-sample
+    sensor2lidar transforms (datasets/nuscenes_dataset.py:126-139)."""
+    from bevformer_amd import synthetic as S
+    import math
+    base = np.asarray(S.make_img_metas(workload)[0]["lidar2img"])
+    rng = np.random.default_rng(12)
+    out = [base]
+    for _ in range(n - 1):
+        yaw = rng.normal(0, 0.01)
+        T = np.eye(4)
+        T[:2, :2] = [[math.cos(yaw), -math.sin(yaw)], [math.sin(yaw), math.cos(yaw)]]
+        T[:3, 3] = rng.normal(0, 0.2, 3)
+        out.append(base @ T)
+    return torch.tensor(np.stack(out), dtype=torch.float32, device=device)
+
+
+def parity_report(got, want, tol):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    diff = (got - want).abs()
+    lim = tol + tol * want.abs()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+    return dict(max_abs=diff.max().item(), mean_abs=diff.mean().item(), cos=cos, rtol=tol, atol=tol,
+                worst_ratio=(diff / lim).max().item(), ok=bool((diff <= lim).all().item()),
+                against="oracle/bevformer_cpu.py on the same weights and frame (rig 0)")
+
+
+class Config:
+    """One encoder + inputs + step function of a (workload, arithmetic mode, direction)."""
+
+    def __init__(self, args, dev, workload, gemm, storage, backward, first_frame, world, tiling):
+        import bevformer_amd
+        from bevformer_amd import bev_tiling, ops
+        from bevformer_amd import synthetic as S
+        self.ops, self.S = ops, S
+        self.workload, self.gemm, self.storage, self.backward = workload, gemm, storage, backward
+        self.args, self.dev, self.world = args, dev, world
+        w = self.w = S.WORKLOADS[workload]
+        self.Q = w["bev_h"] * w["bev_w"]
+        torch.manual_seed(0)
+        enc = bevformer_amd.build_transformer_layer_sequence(S.encoder_cfg(workload)).eval()
+        self.sd = S.trained_like_({k: v.clone() for k, v in enc.state_dict().items()}, seed=3)
+        enc.load_state_dict(self.sd)
+        self.enc = enc.to(dev)
+        if args.row_order:
+            self.enc.sca_row_order = args.row_order
+        self.enc.device_plans = not args.host_plans
+        if tiling:
+            bev_tiling.enable_bev_tiling(self.enc)
+        self.q, self.f, self.kw = S.make_inputs(workload, seed=0, temporal=not first_frame, device=dev)
+        self.metas0 = self.kw["img_metas"]
+        self.rigs = jittered_rigs(workload, N_RIGS, dev)
+        self.l2i = self.rigs[0].clone()          # the matrices of the CURRENT frame (graph replays read it)
+        self.fresh = not args.static_rig and not args.host_plans
+        if self.fresh:
+            self.kw = dict(self.kw, img_metas=[dict(lidar2img=self.l2i, img_shape=self.metas0[0]["img_shape"])])
+        self.frame = 0
+        if backward:
+            self.g_out = torch.randn(1, self.Q, 256, device=dev,
+                                     generator=torch.Generator(device=dev).manual_seed(1))
+            self.qg, self.fg = self.q.clone().requires_grad_(True), self.f.clone().requires_grad_(True)
+
+    def modes(self):
+        self.ops.set_gemm_mode(self.gemm)
+        self.ops.set_value_storage(torch.bfloat16 if self.storage == "bf16" else torch.float32)
+
+    def next_rig(self):
+        """New camera matrices for the next frame (device -> device copy on the launch stream)."""
+        if self.fresh:
+            self.frame += 1
+            self.l2i.copy_(self.rigs[self.frame % N_RIGS])
+
+    def set_rig(self, i):
+        self.l2i.copy_(self.rigs[i])
+
+    def encoder_step(self):
+        if self.backward:       # fwd + bwd w.r.t. parameters, BEV queries and camera features
+            self.enc.zero_grad(set_to_none=True)
+            self.qg.grad = self.fg.grad = None
+            out = self.enc(self.qg, self.fg, self.fg, **self.kw)
+            out.backward(self.g_out)
+            return out.detach()
+        with torch.no_grad():
+            return self.enc(self.q, self.f, self.f, **self.kw)
+
+    def rows(self):
+        """Ragged SCA rows of the current frame (one device read; after the timed region)."""
+        with torch.set_grad_enabled(self.backward):
+            plan = self.enc.frame_plan(self.w["bev_h"], self.w["bev_w"], 1, self.kw["img_metas"], self.dev,
+                                       torch.float32)
+        if plan.dynamic:
+            return int(plan.nrows_dev.item())
+        return int(plan.row_batch.numel())
+
+
+def timed_windows(cfg, step, fence, steps, windows, graph):
+    """``windows`` x (``steps`` steps between fences) -> list of seconds."""
+    out = []
+    for _ in range(windows):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cfg.next_rig()
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+        fence()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def capture(step, fence):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                  # allocator warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    fence()
+    graph = torch.cuda.CUDAGraph()
+    # thread_local: the RCCL watchdog thread keeps polling events of earlier eager
+    # collectives; in the default "global" mode its hipEventQuery during our capture
+    # aborts the process ("operation not permitted when stream is capturing")
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out = step()
+    graph.replay()
+    fence()
+    return graph, out
+
+
+def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, windows, want=None, tol=None):
+    """A secondary configuration on the same line: ms per step (graph replay for forward, eager
+    for forward + backward), fresh geometry per step as in the main run."""
+    cfg = Config(args, dev, workload, gemm, storage, backward, args.first_frame, 1, False)
+    cfg.modes()
+    for _ in range(2):
+        cfg.encoder_step()
+    fence()
+    graph, note = None, "eager"
+    if not backward and args.graph != "off":
+        try:
+            graph, _ = capture(cfg.encoder_step, fence)
+            note = "hip graph replay"
+        except Exception as e:      # noqa: BLE001
+            graph, note = None, f"eager (capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
+    ts = timed_windows(cfg, cfg.encoder_step, fence, steps, windows, graph)
+    per = [t / steps * 1e3 for t in ts]
+    res = dict(workload=workload, gemm=gemm, value_storage=storage, direction="fwd+bwd" if backward else "fwd",
+               ms_per_step=statistics.median(per), ms_per_step_min=min(per), steps=steps, windows=windows,
+               queries_per_s=cfg.Q / (statistics.median(per) * 1e-3), launch_mode=note)
+    if want is not None:
+        cfg.set_rig(0)
+        res["parity"] = parity_report(cfg.encoder_step(), want, tol)
+    del cfg, graph
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -197,44 +386,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    tiling = world > 1 or args.force_tiling
 
     import bevformer_amd
-    from bevformer_amd import bev_tiling, ops
+    from bevformer_amd import ops
     from bevformer_amd import synthetic as S
 
-    torch.manual_seed(0)
-    enc = bevformer_amd.build_transformer_layer_sequence(S.encoder_cfg(args.workload)).eval()
-    sd = S.trained_like_({k: v.clone() for k, v in enc.state_dict().items()}, seed=3)
-    enc.load_state_dict(sd)
-    enc = enc.to(dev)
-    if args.row_order:
-        enc.sca_row_order = args.row_order
-    if world > 1 or args.force_tiling:
-        bev_tiling.enable_bev_tiling(enc)
-    q, f, kw = S.make_inputs(args.workload, seed=0, temporal=not args.first_frame, device=dev)
-    w = S.WORKLOADS[args.workload]
-    Q = w["bev_h"] * w["bev_w"]
-
-    if args.gemm:
-        ops.set_gemm_mode(args.gemm)
+    gemm = args.gemm or ops.gemm_mode()
+    cfg = Config(args, dev, args.workload, gemm, args.value_storage, args.backward, args.first_frame, world, tiling)
+    cfg.modes()
     if args.sca_lds:
         ops.set_sca_lds_level(args.sca_lds == "on")
-    if args.value_storage == "bf16":
-        ops.set_value_storage(torch.bfloat16)
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
     ops.set_gemm_timer(timer.gemm)
+    w, Q = cfg.w, cfg.Q
 
     if args.queue > 0:
         tr = bevformer_amd.build_transformer(S.transformer_cfg(args.workload)).eval()
         tr.init_weights()
-        tr.encoder = enc                       # the encoder above (trained-like weights, tiling if enabled)
+        tr.encoder = cfg.enc                   # the encoder above (trained-like weights, tiling if enabled)
         tr = tr.to(dev)
         mlvl, bq, tkw = S.make_transformer_inputs(args.workload, seed=0, temporal=False, device=dev)
         tkw.pop("prev_bev")
-    if args.backward:
-        g_out = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-        qg, fg = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
 
     def step():
         if args.queue > 0:      # frame i's BEV is frame i+1's history; frame 0 has none
@@ -243,27 +417,21 @@ def main():
                 for _ in range(args.queue):
                     prev = tr.get_bev_features(mlvl, bq, prev_bev=prev, **tkw)
             return prev
-        if args.backward:       # fwd + bwd w.r.t. parameters, BEV queries and camera features
-            enc.zero_grad(set_to_none=True)
-            qg.grad = fg.grad = None
-            out = enc(qg, fg, fg, **kw)
-            out.backward(g_out)
-            return out.detach()
-        with torch.no_grad():
-            return enc(q, f, f, **kw)
+        return cfg.encoder_step()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1 or args.force_tiling:
+        if tiling:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
+        cfg.next_rig()
         step()
     fence()
 
-    # Timed region: replays of ONE captured HIP graph of the whole step (~100 launches per
-    # step; with N > 1 the collective is captured too), per-kernel durations from HIP events
+    # Timed region: replays of ONE captured HIP graph of the whole step (frame plan + ~100 launches;
+    # with N > 1 the collective is captured too), per-kernel durations from HIP events
     # around every sampling / GEMM launch of two eager steps right before; or (--graph off, or
     # a failed capture) eager launches with the events recorded inside the timed region.
     graph = None
@@ -272,24 +440,12 @@ def main():
     if use_graph:
         timer.enabled = True            # kernel durations from an eager pass (events cannot
         for _ in range(2):              # bracket nodes inside a graph replay)
+            cfg.next_rig()
             step()
         fence()
         timer.enabled = False
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()                  # allocator warm-up on the capture stream
-            torch.cuda.current_stream().wait_stream(side)
-            fence()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread keeps polling events of earlier eager
-            # collectives; in the default "global" mode its hipEventQuery during our capture
-            # aborts the process ("operation not permitted when stream is capturing")
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                g_out = step()
-            graph.replay()
-            fence()
+            graph, g_out = capture(step, fence)
             graph_note = "hip graph replay"
         except Exception as e:          # noqa: BLE001 — any capture problem: measure eagerly
             graph = None
@@ -297,55 +453,67 @@ def main():
             torch.cuda.synchronize()
     if graph is None:
         timer.enabled = not timer.events
-    fence()
-    t0 = time.perf_counter()
-    if graph is not None:
-        for _ in range(args.steps):
-            graph.replay()
-        out = g_out
-    else:
-        for _ in range(args.steps):
-            out = step()
-    fence()
-    dt = time.perf_counter() - t0
+    ts = timed_windows(cfg, step, fence, args.steps, 1, graph)       # window 0 carries the in-region events
     timer.enabled = False
+    ts += timed_windows(cfg, step, fence, args.steps, max(0, args.windows - 1), graph)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor(ts, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        ts = [float(v) for v in t.tolist()]
+    dt = statistics.median(ts)
+    out = g_out if graph is not None else step()
     assert torch.isfinite(out).all()
 
+    # geometry alone: the frame plan (camera-matrix copy + the two plan kernels), HIP events
+    geometry_ms = None
+    if cfg.fresh and args.queue == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.no_grad():
+            fence()
+            ev[0].record()
+            for _ in range(10):
+                cfg.next_rig()
+                cfg.enc.frame_plan(w["bev_h"], w["bev_w"], 1, cfg.kw["img_metas"], dev, torch.float32)
+            ev[1].record()
+            fence()
+        geometry_ms = ev[0].elapsed_time(ev[1]) / 10
+
     if rank == 0:
-        ks = timer.summary()
+        rows_per_frame = cfg.rows()
+        ks = timer.summary(rows_per_frame)
         gs = timer.gemm_summary()
         if gs is not None:
             steps_timed = max(1, ks.get("sca_fwd", {"launches": w["layers"]})["launches"] // w["layers"])
             gs["total_us_per_step"] = gs.pop("seconds") / steps_timed * 1e6
-            # fractions of the two MFMA peaks (MI355X_MICROARCH.md): the split kernel issues 3 bf16
-            # products per algorithmic product -> its matrix-core utilisation is 3 * TFLOPs / bf16 peak
-            gs["frac_of_f32_mfma_peak_157"] = gs["TFLOPs"] / 157.3
+            # matrix-core utilisation: the split kernel issues 3 bf16 MFMA products per algorithmic product
             if ops.gemm_mode() != "native":
                 gs["frac_of_bf16_mfma_peak_2500"] = gs["TFLOPs"] * (3 if ops.gemm_mode() == "split" else 1) / 2500.0
         dom = ks.get("sca_fwd") or next(iter(ks.values()))
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(args.traffic_json)).get(args.workload, {}).get("sca_fwd")
-            except Exception:
+                tj = json.load(open(args.traffic_json))
+                traffic = dict(bytes_per_launch=tj.get(args.workload, {}).get("sca_fwd"), source=tj.get("_source"),
+                               note="rocprofv3 PMC passes of an EARLIER run of this bench (not this run)")
+            except Exception:       # noqa: BLE001
                 traffic = None
-        # what the timed steps used: the encoder picks the row order by grad mode
-        with torch.set_grad_enabled(args.backward):
-            row_order_used = enc.row_order()
-            rows_per_frame = int(sum(enc.frame_plan(w['bev_h'], w['bev_w'], 1, kw['img_metas'], dev, torch.float32).hits))
+        row_order_used = cfg.enc.row_order(device_plan=cfg.enc.device_plans)
+        per = [t / args.steps * 1e3 for t in ts]
+        gemm_desc = {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
+                              "3 bf16 MFMA products per fp32 product, fp32 accumulate",
+                     "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",
+                     "native": "hipBLASLt fp32 (torch.nn.functional.linear)"}[ops.gemm_mode()]
         line = {
             "metric": "BEV-encoder queries/sec (200x200 BEV, 6 cams, 4 lvls)" if args.workload == "base"
             else f"BEV-encoder queries/sec ({args.workload})",
             "value": Q * max(1, args.queue) * args.steps / dt, "unit": "BEV queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            # arithmetic type of the path: fp32 accumulation / sampling / softmax / LayerNorm always;
-            # "bf16" when the GEMM operands are rounded to bf16 (--gemm bf16)
-            "dtype": "bf16" if ops.gemm_mode() == "bf16" else "f32", "data": "synthetic",
+            # arithmetic of the path: fp32 storage / sampling / softmax / LayerNorm / accumulation always;
+            # GEMM products from bf16x3-split fp32 operands ("f32/bf16x3"), bf16-rounded operands ("bf16")
+            # or hipBLASLt fp32 ("f32")
+            "dtype": {"split": "f32/bf16x3", "bf16": "bf16", "native": "f32"}[ops.gemm_mode()],
+            "data": "synthetic",
             "config": {"workload": f"bevformer_{args.workload} BEV encoder {'forward + backward' if args.backward else 'forward'}, "
                                    f"{args.queue if args.queue else 1} frame{'s' if args.queue > 1 else ''}/step"
                                    f"{' through get_bev_features with a rolling history BEV' if args.queue else ''}, "
@@ -353,32 +521,58 @@ def main():
                                    f"{w['layers']} layers, " + ("frame 0 without history, frames 1.. with the previous frame's BEV"
                                                            if args.queue else
                                                            ('first frame (no history)' if args.first_frame else 'with history BEV')),
+                       "geometry": ("new camera matrices every step: frame plan (projection, visibility, ragged rows) "
+                                    "rebuilt by the HIP plan kernels inside the timed step" if cfg.fresh else
+                                    "same camera matrices every step: frame plan built once (static rig)"),
                        "sca_row_order": row_order_used,
                        "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "value_storage": args.value_storage,
-                       "gemm": {"split": "hand-written MFMA kernel, fp32 operands split into 2 bf16 terms, "
-                                         "3 bf16 MFMA products per fp32 product, fp32 accumulate",
-                                "bf16": "hand-written MFMA kernel, operands rounded to bf16, fp32 accumulate",
-                                "native": "hipBLASLt fp32 (torch.nn.functional.linear)"}[ops.gemm_mode()],
+                       "gemm": gemm_desc,
                        "global_batch": 1, "parallelism": f"bev-row-tiles x{world}" if world > 1 else "single GPU",
                        "sca_rows_per_frame": rows_per_frame},
+            "windows": {"ms_per_step": [round(p, 4) for p in per], "min": min(per), "median": statistics.median(per),
+                        "n": len(per), "note": "ms_per_step / value = the median window"},
+            "geometry_ms": geometry_ms,
             "roofline": {"kernel": "msda_fwd (SCA sampling, ragged rows)", "bound": "hbm",
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_from_profile": traffic,
                          "avg_us": dom["avg_us"], "alg_bytes": dom["alg_bytes"],
                          "launches_timed": dom["launches"],
                          "timing": "HIP events on the launch stream, " +
-                                   ("every launch of the timed region" if graph is None and use_graph is False
+                                   ("every launch of the first timed window" if graph is None
                                     else "eager pass right before the timed region")},
             "launch_mode": graph_note,
             "kernels": ks,
             "gemms": gs,
         }
+        ok = True
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.first_frame)
-            line["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            cb, want = cpu_baseline(args.workload, cfg.sd, args.first_frame)
+            line["cpu_baseline"] = cb
+            line["vs_cpu_baseline"] = line["value"] / cb["value"]
+            if not args.backward and args.queue == 0:
+                # what was timed is also what is checked: the benched configuration on rig 0 against
+                # the oracle output of the same frame
+                cfg.set_rig(0)
+                tol = ENC_TOL if (args.value_storage == "fp32" and ops.gemm_mode() != "bf16") else 5e-2
+                line["parity"] = parity_report(step(), want, tol)
+                ok = line["parity"]["ok"]
+            if not args.no_variants and not args.backward and args.queue == 0 and not tiling \
+                    and args.workload == "base":
+                ops.set_kernel_timer(None)
+                ops.set_gemm_timer(None)
+                v = {}
+                v["native_fp32"] = run_variant(args, dev, fence, "base", "native", "fp32", False, 10, 3, want, ENC_TOL)
+                v["bf16"] = run_variant(args, dev, fence, "base", "bf16", "bf16", False, 10, 3, want, 5e-2)
+                v["fwd_bwd_base"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3)
+                v["fwd_bwd_small4"] = run_variant(args, dev, fence, "small4", gemm, "fp32", True, 5, 3)
+                v["fwd_bwd_small4_bf16"] = run_variant(args, dev, fence, "small4", "bf16", "bf16", True, 5, 3)
+                line["variants"] = v
+                line["native_fp32_ms_per_step"] = v["native_fp32"]["ms_per_step"]
+                ok = ok and v["native_fp32"]["parity"]["ok"]
     else:
-        line = None
+        line, ok = None, True
     if world > 1 or args.force_tiling:
         dist.destroy_process_group()
     if line is not None:
@@ -391,6 +585,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if not ok:
+        raise SystemExit("bench: parity check against the oracle FAILED (see the `parity` objects)")
 
 
 if __name__ == "__main__":

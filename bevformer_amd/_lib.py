@@ -43,6 +43,14 @@ class LinearDesc(ctypes.Structure):
                 ("out_bf16", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
+class PlanDesc(ctypes.Structure):
+    """Mirror of ``struct bevmsda_plan_desc``."""
+    _fields_ = [("B", ctypes.c_int32), ("Nc", ctypes.c_int32), ("Q", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("pc_range", ctypes.c_double * 6), ("img_w", ctypes.c_float),
+                ("img_h", ctypes.c_float), ("q_lo", ctypes.c_int32), ("q_hi", ctypes.c_int32),
+                ("row_capacity", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+
+
 ERR_UNSUPPORTED = -7
 ERR_MISALIGNED = -4
 _DIMS = [_c_int] * 7
@@ -66,6 +74,14 @@ SIGNATURES = {
                                   _c_int),
     "bevmsda_fused_forward_bf16": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                    _c_int),
+    "bevmsda_fused_forward_rows_f32": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+                                       _c_int),
+    "bevmsda_fused_forward_rows_bf16": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+                                        _c_int),
+    "bevmsda_frame_plan_counters": ([_c_int, _c_int], ctypes.c_int64),
+    "bevmsda_frame_plan_f32": ([_c_void_p] * 3 + [ctypes.POINTER(PlanDesc)] + [_c_void_p] * 11, _c_int),
+    "bevmsda_fold_extra_rows_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int,
+                                     _c_void_p, _c_void_p], _c_int),
     "bevmsda_fused_forward_lds_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_int, _c_int, _c_void_p,
                                                           _c_void_p], _c_int),
     "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,

@@ -117,19 +117,30 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     tiling = encoder.bev_tiling
     group, world, rank = tiling.group, tiling.world, tiling.rank
     bs = bev_query.size(1)
-    plan = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                              bev_query.dtype)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in encoder.parameters()):
+        # all_gather_into_tensor is not differentiable: the tiled schedule is inference-only
+        raise RuntimeError("BEV tiling is an inference schedule (its all-gather has no autograd); "
+                           "call it under torch.no_grad() or disable_bev_tiling() for training")
     blocks = row_blocks(bev_h, world)
     h0, h1 = blocks[rank]
     q0, q1 = h0 * bev_w, h1 * bev_w
-    cache = getattr(plan, "_tiles", None)
-    if cache is None:
-        cache = plan._tiles = {}
-    tile = cache.get((q0, q1))
-    if tile is None:
-        tile = cache[(q0, q1)] = slice_plan(plan, q0, q1)
+    if encoder.device_plans and bev_query.is_cuda:
+        # device-side plan of my tile: rows only for queries [q0, q1), tile-local slot numbering
+        tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                  bev_query.dtype, tile=(q0, q1))
+        full_ref_2d = tile.ref_2d_full
+    else:
+        plan = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                  bev_query.dtype)
+        full_ref_2d = plan.ref_2d
+        cache = getattr(plan, "_tiles", None)
+        if cache is None:
+            cache = plan._tiles = {}
+        tile = cache.get((q0, q1))
+        if tile is None:
+            tile = cache[(q0, q1)] = slice_plan(plan, q0, q1)
 
-    ref_2d = plan.ref_2d
+    ref_2d = full_ref_2d
     shift_ref_2d = ref_2d + shift[:, None, None, :]
     full_query = bev_query.permute(1, 0, 2)
     pos_local = bev_pos.permute(1, 0, 2)[:, q0:q1]

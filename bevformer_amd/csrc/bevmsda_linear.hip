@@ -1,0 +1,167 @@
+// C ABI of libbevmsda.so, dense projections (declared in include/bevmsda.h): argument checks and
+// launches of the MFMA projection kernel (linear_mfma.h).  No torch, no allocation, no global state.
+#include "../../include/bevmsda.h"
+#include "linear_mfma.h"
+
+namespace {
+// projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
+constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
+constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
+inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+}  // namespace
+
+extern "C" {
+
+static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
+                         const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
+                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->M == 0 || d->N == 0) return BEVMSDA_OK;
+  if (d->K0 == 0 || d->K0 % bevmsda::kLinKGran != 0 || d->K1 % bevmsda::kLinKGran != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (!x0 || (!w && !wpack) || !y || (d->K1 > 0 && !x1)) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->ldx0 % 4 != 0 || (w && d->ldw % 4 != 0) || (a0 && d->lda0 % 4 != 0) ||
+      (d->K1 > 0 && (d->ldx1 % 4 != 0 || (a1 && d->lda1 % 4 != 0))))
+    return BEVMSDA_ERR_UNSUPPORTED;
+  const int gcols = d->group_cols;
+  if (gcols < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (gcols > 0 && (gcols % bevmsda::kLinBN != 0 || d->N % gcols != 0)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->ldx0 < d->K0 || (w && d->ldw < d->K0 + d->K1) || d->ldy < (gcols > 0 ? gcols : d->N) ||
+      (d->K1 > 0 && d->ldx1 < d->K1))
+    return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(x0) || (w && misaligned(w)) || (wpack && misaligned(wpack)) ||
+      (reinterpret_cast<uintptr_t>(y) & 3u) != 0 || (a0 && misaligned(a0)) ||
+      (d->K1 > 0 && (misaligned(x1) || (a1 && misaligned(a1)))))
+    return BEVMSDA_ERR_MISALIGNED;
+  bevmsda::LinArgs a;
+  a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
+  a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
+  a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
+  a.gidx = gidx; a.gscale = gscale;
+  a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
+  a.group_cols = gcols;
+  a.out_bf16 = d->out_bf16 ? 1 : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool add = a.a0 != nullptr || a.a1 != nullptr || gidx != nullptr;
+  // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
+  //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
+  //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
+  //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
+  //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
+  //   bit 5: fragments-first schedule (copy mode 3, 128-column tiles): see linear_mfma.h FRAGS
+  //   bit 6: 64-row block tiles, 5 blocks / CU (copy mode 3, 128-column tiles): see linear_mfma.h BM
+  int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
+  // 256-column tiles (2 blocks / CU) and the fragments-first schedule (3 blocks / CU) stay opt-in: both
+  // measured within noise of, or behind, the 4-blocks-per-CU default on every layer shape (r1j / r1l
+  // sweeps; the hoisted N = 1536 projection got 11 % slower with 256-column tiles, r1k vs r1i)
+  if (v < 0 || v > 127) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 112) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 112) != 0 && (v & 112) != 16 && (v & 112) != 32 && (v & 112) != 64) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 16) && (d->N % 256 != 0 || gcols % 256 != 0)) v &= ~16;
+  const int bn = (v & 16) ? 256 : bevmsda::kLinBN;
+  const int wmode = (v >> 2) & 3;
+  const int bm = (v & 64) ? 64 : bevmsda::kLinBM;
+  const long long nbm = (d->M + bm - 1) / bm;
+  const long long nbn = (d->N + bn - 1) / bn;
+  const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+  if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+  a.nblk_m = static_cast<int>(nbm);
+  a.nblk_n = static_cast<int>(nbn);
+  const dim3 g(static_cast<unsigned>(grid)), b(256);
+  if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;
+  if (wmode > 0 && (v & 1)) return BEVMSDA_ERR_BAD_OPTION;
+  if ((v & 1) && ((d->K0 + d->K1) % 64 != 0 || (d->K1 > 0 && d->K0 % 64 != 0))) v &= ~1;
+  // bf16 output: only the transposed-tile epilogue packs it (4 consecutive columns per lane)
+  if (d->out_bf16 && ((v & 2) || d->N % 4 != 0 || d->ldy % 4 != 0 || (gcols % 4) != 0 ||
+                      (reinterpret_cast<uintptr_t>(y) & 7u) != 0 || (bias && misaligned(bias))))
+    return BEVMSDA_ERR_UNSUPPORTED;
+#define BEVMSDA_LIN3(NP_, BK_, SW_, WM_, BN_)                                                                      \
+  do {                                                                                                             \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_, BN_>), g, b, 0, st, a);   \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_, BN_>), g, b, 0, st, a);      \
+  } while (0)
+#define BEVMSDA_LIN2(NP_, BK_, SW_, WM_) BEVMSDA_LIN3(NP_, BK_, SW_, WM_, 128)
+#define BEVMSDA_LIN5(NP_, SW_)                                                                                               \
+  do {                                                                                                                       \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);     \
+  } while (0)
+#define BEVMSDA_LIN4(NP_, SW_)                                                                                          \
+  do {                                                                                                                  \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, true>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, true>), g, b, 0, st, a);     \
+  } while (0)
+#define BEVMSDA_LIN1(NP_)                                                       \
+  switch (v) {                                                                  \
+    case 0: BEVMSDA_LIN2(NP_, 32, true, 0); break;                              \
+    case 1: BEVMSDA_LIN2(NP_, 64, true, 0); break;                              \
+    case 2: BEVMSDA_LIN2(NP_, 32, false, 0); break;                             \
+    case 3: BEVMSDA_LIN2(NP_, 64, false, 0); break;                             \
+    case 4: BEVMSDA_LIN2(NP_, 32, true, 1); break;                              \
+    case 6: BEVMSDA_LIN2(NP_, 32, false, 1); break;                             \
+    case 8: BEVMSDA_LIN2(NP_, 32, true, 2); break;                              \
+    case 10: BEVMSDA_LIN2(NP_, 32, false, 2); break;                            \
+    case 12: BEVMSDA_LIN2(NP_, 32, true, 3); break;                             \
+    case 14: BEVMSDA_LIN2(NP_, 32, false, 3); break;                            \
+    case 28: BEVMSDA_LIN3(NP_, 32, true, 3, 256); break;                        \
+    case 30: BEVMSDA_LIN3(NP_, 32, false, 3, 256); break;                       \
+    case 44: BEVMSDA_LIN4(NP_, true); break;                                    \
+    case 76: BEVMSDA_LIN5(NP_, true); break;                                    \
+    case 78: BEVMSDA_LIN5(NP_, false); break;                                   \
+    case 46: BEVMSDA_LIN4(NP_, false); break;                                   \
+    default: return BEVMSDA_ERR_BAD_OPTION;                                     \
+  }
+  if (d->precision == 0) { BEVMSDA_LIN1(3) } else { BEVMSDA_LIN1(1) }
+#undef BEVMSDA_LIN1
+#undef BEVMSDA_LIN2
+#undef BEVMSDA_LIN3
+#undef BEVMSDA_LIN4
+#undef BEVMSDA_LIN5
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
+                       const float *bias, const bevmsda_linear_desc *d, float *y, void *stream) {
+  if (!w) return BEVMSDA_ERR_NULL_POINTER;
+  return linear_launch(x0, a0, x1, a1, w, nullptr, bias, d, y, stream);
+}
+
+int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                              const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
+                              void *stream) {
+  if (!wpack) return BEVMSDA_ERR_NULL_POINTER;
+  return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream);
+}
+
+int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx, const float *scale,
+                                     const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d,
+                                     float *y, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (!wpack || !idx || !scale) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->K1 != 0) return BEVMSDA_ERR_BAD_SHAPE;
+  bevmsda_linear_desc dd = *d;
+  dd.ldx0 = ld_rows;
+  return linear_launch(rows, nullptr, nullptr, nullptr, nullptr, wpack, bias, &dd, y, stream, idx, scale);
+}
+
+int64_t bevmsda_linear_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return static_cast<int64_t>((N + 127) / 128) * (K / 32) * 2 * 128 * 40 * 2;
+}
+
+int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream) {
+  if (N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (K % 32 != 0 || ldw % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldw < K) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!w || !blob) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(w) || misaligned(blob)) return BEVMSDA_ERR_MISALIGNED;
+  const long long threads = static_cast<long long>((N + 127) / 128) * 128 * (K / 8);
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -218,7 +218,25 @@ struct FusedArgs {
   float out_scale;      // 1 / K
   int out_f32;          // bf16-storage kernels only: write the output rows as fp32 (the consumer is the
                         // fp32 output projection) instead of bf16
+  const int32_t *nrows; // optional DEVICE row count (frame_plan.h: counters[0]): when set, k.NQ is only the
+                        // capacity of the row arrays; the launch is a fixed-size grid that strides over the
+                        // logical blocks of the actual count, so one captured launch serves every frame
 };
+
+// Logical blocks of a launch whose row count lives on the device (DYN kernels).
+struct DynRows {
+  long NQ;
+  int nblocks, per;
+};
+__device__ __forceinline__ DynRows dyn_rows(const FusedArgs &f) {
+  DynRows d;
+  const long n = *f.nrows;
+  d.NQ = n < f.k.NQ ? n : f.k.NQ;
+  const long tiles = (d.NQ + f.k.qtile - 1) / f.k.qtile;
+  d.nblocks = static_cast<int>((tiles * f.k.qtile * f.k.M + 31) / 32);
+  d.per = (d.nblocks + 7) >> 3;
+  return d;
+}
 
 template <int X>
 __device__ __forceinline__ float xor8(float v) {   // value of lane ^ X (X < 8)
@@ -242,18 +260,17 @@ __device__ __forceinline__ float lanes_sum(float v) {
 // owned by the lanes of the group: lane j -> queue entry j / PT, point j % PT.  With
 // KT = 2 (TemporalSelfAttention: PT = 4) both queue entries are sampled in the same
 // round and summed into the same accumulator (their mean is the output).
-template <typename T, int PT, int KT, int WPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-msda_fused_d32_kernel(const FusedArgs f) {
+template <typename T, int PT, int KT>
+__device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblock, long NQ) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
   const int lig = threadIdx.x & 7;
-  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  const long G = static_cast<long>(lblock) * GPB + (threadIdx.x >> 3);
   long r; int m;
   map_group(G, a, r, m);
-  const bool active = r < a.NQ;
-  if (!active) r = a.NQ - 1;
+  const bool active = r < NQ;
+  if (!active) r = NQ - 1;
   const int L = a.L;                                    // 1..4 (host-checked)
   const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
   const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
@@ -312,6 +329,23 @@ msda_fused_d32_kernel(const FusedArgs f) {
       *reinterpret_cast<uint2 *>(op) = t;
     }
   }
+}
+
+template <typename T, int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_kernel(const FusedArgs f) {
+  msda_fused_d32_body<T, PT, KT>(f, logical_block(f.k), f.k.NQ);
+}
+
+// Same kernel over a device-side row count: fixed grid (a multiple of 8), every workgroup strides over
+// the logical blocks of the frame's actual row count with the same XCD-contiguous block map.
+template <typename T, int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_dyn_kernel(const FusedArgs f) {
+  const DynRows d = dyn_rows(f);
+  if (d.NQ <= 0) return;
+  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x)
+    msda_fused_d32_body<T, PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ);
 }
 
 // ------------------------------------------------------------------ coarse level from LDS
@@ -492,19 +526,18 @@ __device__ __forceinline__ void sample_points_b8(const PointParams &p, __amdgpu_
   }
 }
 
-template <int PT, int KT, int WPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
+template <int PT, int KT>
+__device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, int lblock, long NQ) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
   const int lig = threadIdx.x & 7;
   const bool upper = lig >= 4;                           // this lane's taps: x0 + 1
-  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  const long G = static_cast<long>(lblock) * GPB + (threadIdx.x >> 3);
   long r; int m;
   map_group(G, a, r, m);
-  const bool active = r < a.NQ;
-  if (!active) r = a.NQ - 1;
+  const bool active = r < NQ;
+  if (!active) r = NQ - 1;
   const int L = a.L;
   const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
   const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * 2;
@@ -567,6 +600,21 @@ msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
     t.w = f32_to_bf16(acc[6] * sc) | (f32_to_bf16(acc[7] * sc) << 16);
     *reinterpret_cast<uint4 *>(op) = t;
   }
+}
+
+template <int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
+  msda_fused_d32_bf16x8_body<PT, KT>(f, logical_block(f.k), f.k.NQ);
+}
+
+template <int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_bf16x8_dyn_kernel(const FusedArgs f) {
+  const DynRows d = dyn_rows(f);
+  if (d.NQ <= 0) return;
+  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x)
+    msda_fused_d32_bf16x8_body<PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ);
 }
 
 }  // namespace bevmsda

@@ -66,6 +66,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # 99.6 ms fwd+bwd, profiles/r1/r1t_*), or "auto": image under no_grad, raster under autograd
         self.sca_row_order = "auto"
         self.bev_tiling = None          # set by bev_tiling.enable_bev_tiling()
+        # GPU tensors: plans come from the HIP frame-plan kernels (geometry.DevicePlanner: no host
+        # sync, row count on the device); False keeps the torch-op builder with its host syncs
+        self.device_plans = True
+        self._planners = {}
 
     # kept as static/instance methods with the reference's names and outputs
     get_reference_points = staticmethod(geometry.get_reference_points)
@@ -74,12 +78,33 @@ class BEVFormerEncoder(TransformerLayerSequence):
     def point_sampling(self, reference_points, pc_range, img_metas):
         return geometry.point_sampling(reference_points, pc_range, img_metas)
 
-    def row_order(self):
+    def row_order(self, device_plan=False):
         if self.sca_row_order != "auto":
             return self.sca_row_order
-        return "raster" if torch.is_grad_enabled() else "image"
+        if torch.is_grad_enabled():
+            return "raster"
+        return "polar" if device_plan else "image"
 
-    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype):
+    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None):
+        """The per-frame geometry.  On a GPU: two kernel launches into the planner's buffers, no
+        host synchronisation (under autograd the plan is then materialised: one read of the row
+        count, the torch statements of that path need sizes).  ``tile = (q0, q1)``: rows only for
+        those BEV queries (bev_tiling)."""
+        device = torch.device(device)
+        order = self.row_order(device_plan=True)
+        if self.device_plans and device.type == "cuda" and order in ("polar", "raster"):
+            num_cams = len(img_metas[0]["lidar2img"])
+            key = (bev_h, bev_w, bs, str(device), order, tile, num_cams, self.num_points_in_pillar)
+            planner = self._planners.get(key)
+            if planner is None:
+                if len(self._planners) >= 8:
+                    self._planners.pop(next(iter(self._planners)))
+                planner = self._planners[key] = geometry.DevicePlanner(
+                    bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar, num_cams, device,
+                    row_order=order, tile=tile)
+            plan = planner.plan(img_metas)
+            return plan.materialize() if torch.is_grad_enabled() else plan
+        assert tile is None, "tiles of a host-built plan come from bev_tiling.slice_plan"
         order = self.row_order()
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
                                 img_metas, device, dtype) + (order,)
@@ -229,7 +254,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         # inference fast path: "+ identity" of an attention / FFN step is folded into the
         # LayerNorm that follows it (one pass over the grid instead of two launches)
         order = self.operation_order
-        fuse_norm = (not self.training) and (not torch.is_grad_enabled())
+        # (post-norm orders only: with a leading norm the "+ identity" of a step feeds the NEXT
+        # step's residual, not the norm that follows)
+        fuse_norm = (not self.training) and (not torch.is_grad_enabled()) and not self.pre_norm
         pending = None                          # (branch output, identity) awaiting its norm
 
         def _defer(i):

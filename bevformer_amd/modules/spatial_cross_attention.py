@@ -147,7 +147,9 @@ class MSDeformableAttention3D(BaseModule):
         w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
         proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
         lds = {}
-        if ops._FUSED["lds_level"] and frame_plan is not None and frame_plan.cam_start is not None:
+        if frame_plan is not None and frame_plan.dynamic:
+            lds = dict(nrows=frame_plan.nrows_dev)      # row count on the device (geometry.DevicePlanner)
+        elif ops._FUSED["lds_level"] and frame_plan is not None and frame_plan.cam_start is not None:
             px = getattr(frame_plan, "_last_level_pixels", None)
             if px is None:                      # one host read per plan (shapes live on the device)
                 px = frame_plan._last_level_pixels = int(spatial_shapes[-1].prod().item())
@@ -252,6 +254,10 @@ class SpatialCrossAttention(BaseModule):
                 query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
                 frame_plan.row_query32, spatial_shapes, level_start_index, frame_plan=frame_plan)
             if out_rows is not None:
+                if frame_plan.dynamic:
+                    # slots seen by more than two cameras (rare; known to the device only): fold their
+                    # third.. rows into the first so the two-row gather below sums all of them
+                    ops.fold_extra_rows(out_rows, frame_plan.q_rows_all, frame_plan.n_extra_dev)
                 # camera mean + output projection in one kernel where the GEMM kernel is in use
                 proj = ops.linear_gather_mean(out_rows, frame_plan.q_rows, inv_count,
                                               self.output_proj.weight, self.output_proj.bias,
@@ -261,6 +267,10 @@ class SpatialCrossAttention(BaseModule):
                 else:
                     slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
         if slots is None:
+            if frame_plan is not None and frame_plan.dynamic:
+                # the unfused statements need the row count on the host: one read of the plan's counters
+                fp = frame_plan.materialize()
+                row_query, row_batch, row_ref = fp.row_query, fp.row_batch, fp.row_ref
             q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
             out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
                                          spatial_shapes, level_start_index)

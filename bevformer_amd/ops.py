@@ -119,7 +119,8 @@ class _RaggedFunction(Function):
                     N, S, M, D, L, R, P, _ptr(out), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "msda_ragged forward")
         ctx.save_for_backward(value, shapes, start, loc, attn, row_batch)
-        return out.to(ctx.in_dtype)
+        # rows go on to fp32 Linear layers: never hand the (bf16) STORAGE dtype downstream
+        return out.to(torch.float32 if ctx.in_dtype == torch.bfloat16 else ctx.in_dtype)
 
     @staticmethod
     @once_differentiable
@@ -177,7 +178,7 @@ def fused_wanted(*tensors):
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0):
+               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0, nrows=None):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -186,7 +187,11 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     logits; ref (R,K,A,2); row_batch (R,) int32 or None; row_src (R,) int32 or
     None: projection row read by output row r (proj then has one row per BEV
     query instead of one per output row).  Returns (R, M*32), or ``None`` when
-    the shape is not covered (caller falls back to the unfused path)."""
+    the shape is not covered (caller falls back to the unfused path).
+
+    ``nrows`` ((1,) int32 device tensor, from a device-side frame plan): the ACTUAL number of
+    rows; R above is then the capacity of the row arrays and the returned tensor has that many
+    rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``)."""
     _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
     store = _STORAGE["dtype"]
     value = value.to(store)
@@ -223,6 +228,8 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
         # algorithmic bytes: value + raw projection row (offsets 8 B + logit 4 B per point) + out
         alg = value.numel() * value.element_size() + R * M * K * L * P * 12 \
             + R * M * D * out.element_size()
+        if nrows is not None:       # the row count is on the device: (fixed bytes, bytes per row), resolved by the hook's owner
+            alg = ("per_row", value.numel() * value.element_size(), M * K * L * P * 12 + M * D * out.element_size())
         cb = _TIMER["cb"]
         ctx = cb(tag, alg) if cb is not None else _NoTimer()
         rc = _lib.ERR_UNSUPPORTED
@@ -240,13 +247,41 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                 _lib.check(rc, "msda_fused forward (LDS level)")
             ctx = cb(tag, alg) if cb is not None else _NoTimer()
         with ctx:
-            rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
-                    logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
-                    _ptr(row_src) if row_src is not None else None, ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
+            if nrows is not None:
+                _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
+                     "bevmsda: nrows must be an int32 device tensor")
+                fnr = lib.bevmsda_fused_forward_rows_f32 if store == torch.float32 \
+                    else lib.bevmsda_fused_forward_rows_bf16
+                rc = fnr(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
+                         logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
+                         _ptr(row_src) if row_src is not None else None, nrows.data_ptr(),
+                         ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
+                        logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
+                        _ptr(row_src) if row_src is not None else None, ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "msda_fused forward")
     return out
+
+
+def fold_extra_rows(rows, q_rows_all, n_extra):
+    """In place: rows[q_rows_all[s, 0]] += sum_{j >= 2} rows[q_rows_all[s, j]] for the slots more
+    than two cameras see (``bevmsda_fold_extra_rows_f32``; a no-op launch when the device counter
+    ``n_extra`` is 0), so that the two-row gather of ``linear_gather_mean`` covers every camera."""
+    _req(rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1,
+         "bevmsda: rows must be a float32 (R, C) GPU matrix")
+    J = q_rows_all.shape[1]
+    if J <= 2:
+        return rows
+    lib = _lib.load()
+    with torch.cuda.device(rows.device):
+        rc = lib.bevmsda_fold_extra_rows_f32(_ptr(rows), rows.stride(0), _ptr(q_rows_all), q_rows_all.shape[0],
+                                             J, rows.shape[1], n_extra.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "fold_extra_rows")
+    return rows
 
 
 def add_layernorm(x, res, weight, bias, eps):
@@ -525,10 +560,12 @@ class _LinearFunction(Function):
     (76.9 vs 81.9 ms per base frame fwd + bwd) for users who accept that."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias, relu, tag):
         if _GEMM["train_forward_mfma"]:
-            y = linear(x.detach(), weight.detach(), None if bias is None else bias.detach(), relu=relu, tag=tag,
-                       _inside_autograd=True)
+            # `weight` itself (not a detached temporary): the packed-weight cache lives on the parameter
+            with torch.no_grad():
+                y = linear(x, weight, bias, relu=relu, tag=tag, _inside_autograd=True)
         else:
             y = torch.nn.functional.linear(x.detach(), weight.detach(), None if bias is None else bias.detach())
             y = torch.relu_(y) if relu else y
@@ -542,8 +579,10 @@ class _LinearFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
+        gy = gy.float()
         if ctx.relu:
             gy = gy * (y > 0).to(gy.dtype)
         K = x.shape[-1]
@@ -567,7 +606,8 @@ def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
     y = linear(x, weight, bias, relu=relu, tag=tag)
     if y is not None:
         return y
-    if _GEMM["mode"] != "native" and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 \
+    if _GEMM["mode"] != "native" and torch.is_grad_enabled() and not torch.is_autocast_enabled() \
+            and x.is_cuda and x.dtype == torch.float32 \
             and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] % 32 == 0 \
             and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1] \
             and (x.requires_grad or weight.requires_grad):
@@ -623,10 +663,22 @@ def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
     """prev_bev (Q, bs, C) -> a new tensor whose batch entry i is rotated by ``angles_deg[i]``
     about ``center`` (nearest, zero fill): ``bevmsda_rotate_bev_f32`` (transformer.py:146-156).
     The argument is not written to (the reference overwrites it in place)."""
-    _req(prev_bev.is_cuda and prev_bev.dtype == torch.float32 and prev_bev.dim() == 3,
-         "bevmsda: prev_bev must be a float32 (Q, bs, C) GPU tensor")
+    _req(prev_bev.is_cuda and prev_bev.dim() == 3, "bevmsda: prev_bev must be a (Q, bs, C) GPU tensor")
     Q, bs, C = prev_bev.shape
     _req(Q == bev_h * bev_w, "bevmsda: prev_bev rows != bev_h * bev_w")
+    if prev_bev.dtype != torch.float32 or (torch.is_grad_enabled() and prev_bev.requires_grad):
+        # differentiable / half-precision history: the same nearest-neighbour map as a torch gather
+        # (the kernel is fp32, forward only)
+        cols = []
+        for i in range(bs):
+            th = torch.tensor(rotation_theta(float(angles_deg[i]), center, bev_h, bev_w),
+                              dtype=torch.float32, device=prev_bev.device).view(1, 2, 3)
+            grid = torch.nn.functional.affine_grid(th, (1, 1, bev_h, bev_w), align_corners=False)
+            img = prev_bev[:, i].reshape(bev_h, bev_w, C).permute(2, 0, 1)[None]
+            rot = torch.nn.functional.grid_sample(img.float(), grid, mode="nearest", padding_mode="zeros",
+                                                  align_corners=False)
+            cols.append(rot[0].permute(1, 2, 0).reshape(Q, C).to(prev_bev.dtype))
+        return torch.stack(cols, 1)
     src = prev_bev.contiguous()
     out = torch.empty_like(src)
     lib = _lib.load()
@@ -640,12 +692,36 @@ def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
     return out
 
 
+def _flatten_feats_torch(mlvl_feats, cams_embeds, level_embeds):
+    """transformer.py:165-184 in torch ops (autograd / any dtype)."""
+    flat, shapes = [], []
+    for lvl, feat in enumerate(mlvl_feats):
+        h, w = feat.shape[3:]
+        feat = feat.flatten(3).permute(1, 0, 3, 2)
+        if cams_embeds is not None:
+            feat = feat + cams_embeds[:, None, None, :].to(feat.dtype)
+        feat = feat + level_embeds[None, None, lvl:lvl + 1, :].to(feat.dtype)
+        shapes.append((int(h), int(w)))
+        flat.append(feat)
+    out = torch.cat(flat, 2).permute(0, 2, 1, 3)
+    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=out.device)
+    level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+    return out, spatial_shapes, level_start_index
+
+
 def flatten_feats(mlvl_feats, cams_embeds, level_embeds):
     """list of (bs, Nc, C, h, w) -> feat_flatten (Nc, S, bs, C) with ``+ cams_embeds[cam]``
     (or None) ``+ level_embeds[lvl]``, plus spatial_shapes (L, 2) and level_start_index (L,)
     int64 device tensors (transformer.py:165-184): ``bevmsda_flatten_feats_f32``."""
     f0 = mlvl_feats[0]
-    _req(f0.is_cuda and f0.dtype == torch.float32, "bevmsda: camera features must be float32 GPU tensors")
+    _req(f0.is_cuda, "bevmsda: camera features must be GPU tensors (there is no CPU path)")
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (*mlvl_feats, cams_embeds, level_embeds))
+    if needs_grad or any(f.dtype != torch.float32 for f in mlvl_feats) or torch.is_autocast_enabled():
+        # training (gradients flow to the backbone features and both embeddings) or mixed precision:
+        # the reference's differentiable torch statements (transformer.py:165-184); the kernel below
+        # writes into a fresh buffer and has no autograd graph
+        return _flatten_feats_torch(mlvl_feats, cams_embeds, level_embeds)
     bs, Nc, C = f0.shape[:3]
     shapes = [(int(f.shape[3]), int(f.shape[4])) for f in mlvl_feats]
     S = sum(h * w for h, w in shapes)

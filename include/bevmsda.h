@@ -180,6 +180,21 @@ int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const int32_t *row_src, const bevmsda_fused_desc *desc,
                                uint16_t *out, void *stream);
 
+/* The same entry points with the ROW COUNT in device memory: desc->R is the capacity of the row
+ * arrays (row_batch, row_src, ref, out), `nrows` points to the actual count (int32, DEVICE memory,
+ * e.g. counters[0] of bevmsda_frame_plan_f32), read by the kernel when it runs.  The launch
+ * geometry depends on the capacity only, so one captured HIP graph serves every frame. */
+int bevmsda_fused_forward_rows_f32(const float *value, const int64_t *spatial_shapes,
+                                   const int64_t *level_start, const float *offs, const float *logits,
+                                   const float *ref, const int32_t *row_batch, const int32_t *row_src,
+                                   const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
+                                   void *stream);
+int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                    const int64_t *level_start, const float *offs, const float *logits,
+                                    const float *ref, const int32_t *row_batch, const int32_t *row_src,
+                                    const int32_t *nrows, const bevmsda_fused_desc *desc, uint16_t *out,
+                                    void *stream);
+
 /* bevmsda_fused_forward_f32 for SpatialCrossAttention with the LAST feature level staged in
  * LDS: rows must be grouped by camera (value batch entry), cam_start (N + 1) int32 holds the
  * first row of every camera's run, lds_pixels = H * W of the last level (<= 512: 64 KB of LDS
@@ -275,6 +290,45 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
 int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx,
                                      const float *scale, const uint16_t *wpack, const float *bias,
                                      const bevmsda_linear_desc *desc, float *y, void *stream);
+
+/* Per-frame geometry of the encoder on the device (csrc/frame_plan.h): camera projection of the
+ * pillar anchors + visibility (BEVFormerEncoder.point_sampling, encoder.py:88-149), the visible
+ * (camera, query) pairs of SpatialCrossAttention as a ragged row list (spatial_cross_attention.py:
+ * 136-153, without its per-camera nonzero() host syncs) and 1 / max(#cameras seeing a query, 1)
+ * (ibid. :169-172).  Two launches, no host synchronisation; the row count stays on the device.
+ *
+ *   lidar2img (B, Nc, 4, 4) fp32;  ref_3d (B, D, Q, 3) normalised anchors (encoder.py:62-71);
+ *   order (Q,) int32: position -> BEV query, the row order inside a camera
+ * outputs (caller-owned, all DEVICE memory):
+ *   ref_cam (Nc, B, Q, D, 2), bev_mask (Nc, B, Q, D) bytes 0/1, inv_count (B, Q),
+ *   slot (Nc, Q) scratch bytes, row_query / row_batch (row_capacity,) int32 (tile-local slot
+ *   j*Qt + q - q_lo with Qt = q_hi - q_lo; value batch entry j*Nc + cam), row_ref (row_capacity, D, 2),
+ *   q_rows (B*Qt, Nc) / q_rows2 (B*Qt, 2) int32 rows of every slot (-1 = none),
+ *   counters (bevmsda_frame_plan_counters(B, Nc) int32): [0] rows, [1] rows dropped because
+ *   row_capacity was too small, [2] slots seen by more than two cameras, [3] rows of one batch
+ *   element, [4 ...] first row of every (j, cam) run (+ the end).
+ * As in the reference the visible set of a camera is taken from batch element 0.  Only queries in
+ * [q_lo, q_hi) produce rows (BEV tiling over GPUs); ref_cam / bev_mask / inv_count cover all. */
+typedef struct bevmsda_plan_desc {
+  int32_t B, Nc, Q, D;
+  double pc_range[6];
+  float img_w, img_h;
+  int32_t q_lo, q_hi;
+  int32_t row_capacity;
+  int32_t reserved[5];
+} bevmsda_plan_desc;
+
+int64_t bevmsda_frame_plan_counters(int B, int Nc);
+int bevmsda_frame_plan_f32(const float *lidar2img, const float *ref_3d, const int32_t *order,
+                           const bevmsda_plan_desc *desc, float *ref_cam, uint8_t *bev_mask,
+                           float *inv_count, uint8_t *slot, int32_t *row_query, int32_t *row_batch,
+                           float *row_ref, int32_t *q_rows, int32_t *q_rows2, int32_t *counters,
+                           void *stream);
+/* rows[q_rows[s, 0]] += sum_{j >= 2} rows[q_rows[s, j]] for slots seen by more than two cameras, so
+ * that the two-row gather of bevmsda_linear_gather_packed_f32 sums over all of them; n_extra
+ * (DEVICE, counters[2] above) = 0 makes the launch a no-op. */
+int bevmsda_fold_extra_rows_f32(float *rows, int64_t ld_rows, const int32_t *q_rows, int64_t slots, int J,
+                                int C, const int32_t *n_extra, void *stream);
 
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *

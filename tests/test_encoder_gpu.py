@@ -2,9 +2,10 @@
 
 Tolerance: fp32 everywhere; the product re-associates the module math (merged
 GEMMs, rocBLAS/hipBLASLt summation order, reciprocal camera count, fused
-sampling order) so agreement is to rounding: rtol/atol 1e-3 on O(1)
-LayerNorm-ed activations after 2-3 layers, gradients rtol 2e-3 / atol 2e-3
-relative to their scale (atomic accumulation order in grad_value)."""
+sampling order) so agreement is to rounding: rtol = atol = 2e-4 on O(1)
+LayerNorm-ed activations (the one encoder-level number: DESIGN.md §2, bench.py,
+tests/test_baseline_configs_gpu.py), gradients 2e-3 of each tensor's max
+(atomic accumulation order in grad_value)."""
 import pytest
 import torch
 
@@ -16,7 +17,7 @@ from helpers import build_pair
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
-TOL = dict(rtol=1e-3, atol=1e-3)
+TOL = dict(rtol=2e-4, atol=2e-4)      # encoder-level fp32 tolerance (bench.py ENC_TOL)
 
 
 @pytest.fixture(params=["split", "native"])
@@ -121,14 +122,17 @@ def test_encoder_backward(temporal):
         close(p.grad.cpu(), sdg[name].grad, name)
 
 
-def test_plan_cache_makes_steady_state_sync_free():
+@pytest.mark.parametrize("device_plans", [True, False])
+def test_plan_cache_makes_steady_state_sync_free(device_plans):
+    """Same camera matrices twice: one planner / one cached host plan, identical output."""
     enc, _ = build_pair("tiny", device=DEV)
+    enc.device_plans = device_plans
     q, f, kw = S.make_inputs("tiny", seed=0, temporal=True, device=DEV)
     with torch.no_grad():
         a = enc(q, f, f, **kw)
-        assert len(enc._plan_cache) == 1
         b = enc(q, f, f, **kw)
-        assert len(enc._plan_cache) == 1
+    assert len(enc._plan_cache) == (0 if device_plans else 1)
+    assert len(enc._planners) == (1 if device_plans else 0)
     torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
 
 
@@ -138,6 +142,7 @@ def test_sca_coarse_level_from_lds_is_identical(name, bs):
     coefficients and accumulates in the same order as the default kernel: identical encoder
     output (4 levels, 1 level, bs = 2 exercises the per-entry camera runs)."""
     enc, sd = build_pair(name, device=DEV)
+    enc.device_plans = False            # the LDS-level launch is sized from the host-side camera runs
     q, f, kw = S.make_inputs(name, seed=0, bs=bs, temporal=True)
     args = (q.to(DEV), f.to(DEV), f.to(DEV))
     try:

@@ -1,0 +1,214 @@
+"""GPU: the device-side frame plan (csrc/frame_plan.h, ``bevmsda_frame_plan_f32``) against the
+torch statements of the same geometry evaluated on the CPU (``geometry.build_frame_plan``, itself
+parity-tested against the oracle / the reference in tests/test_host_logic_cpu.py and
+tests/test_oracle_vs_reference.py), and the encoder running on device plans against the oracle.
+
+Bar: index work (rows, row tables, masks, counts) bit-exact; projected coordinates bit-exact
+(same IEEE operations in the same order — no FMA contraction in the kernel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from bevformer_amd import synthetic as S
+from bevformer_amd.modules import geometry as G
+from oracle import bevformer_cpu as O
+
+from helpers import build_pair
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _perturbed_metas(name, bs, seed):
+    """img_metas whose camera matrices differ per batch element (ego pose jitter)."""
+    metas = S.make_img_metas(name, bs=bs)
+    rng = np.random.default_rng(seed)
+    for j, m in enumerate(metas):
+        if j == 0 and seed == 0:
+            continue
+        yaw = rng.normal(0, 0.02)
+        T = np.eye(4)
+        T[:2, :2] = [[math.cos(yaw), -math.sin(yaw)], [math.sin(yaw), math.cos(yaw)]]
+        T[:3, 3] = rng.normal(0, 0.3, 3)
+        m["lidar2img"] = [mat @ T for mat in m["lidar2img"]]
+    return metas
+
+
+def _host_plan(name, bs, metas, order="raster"):
+    w = S.WORKLOADS[name]
+    return G.build_frame_plan(w["bev_h"], w["bev_w"], bs, S.PC_RANGE, 4, metas, "cpu", torch.float32,
+                              row_order=order)
+
+
+def _device_plan(name, bs, metas, order="raster", tile=None, cap=None):
+    w = S.WORKLOADS[name]
+    pl = G.DevicePlanner(w["bev_h"], w["bev_w"], bs, S.PC_RANGE, 4, S.NUM_CAMS, DEV, row_order=order,
+                         tile=tile, row_capacity=cap)
+    return pl, pl.plan(metas)
+
+
+@pytest.mark.parametrize("name,bs", [("micro", 1), ("micro4", 2), ("tiny", 1), ("base", 1)])
+def test_device_plan_equals_host_plan_raster(name, bs):
+    metas = _perturbed_metas(name, bs, seed=1 if bs > 1 else 0)
+    want = _host_plan(name, bs, metas)
+    _, dyn = _device_plan(name, bs, metas)
+    got = dyn.materialize()
+    assert torch.equal(got.bev_mask.cpu(), want.bev_mask)
+    assert torch.equal(got.reference_points_cam.cpu(), want.reference_points_cam), \
+        (got.reference_points_cam.cpu() - want.reference_points_cam).abs().max()
+    assert torch.equal(got.inv_count.cpu(), want.inv_count)
+    assert got.hits == want.hits
+    assert torch.equal(got.row_query.cpu(), want.row_query)
+    assert torch.equal(got.row_batch.cpu(), want.row_batch)
+    assert torch.equal(got.row_ref.cpu(), want.row_ref)
+    J = want.q_rows.shape[1]
+    assert torch.equal(got.q_rows.cpu()[:, :J], want.q_rows)
+    assert (got.q_rows.cpu()[:, J:] == -1).all()
+    assert torch.equal(got.cam_start.cpu()[:want.cam_start.numel()], want.cam_start)
+    assert int(dyn.nrows_dev.item()) == want.row_query.numel()
+
+
+@pytest.mark.parametrize("name", ["micro4", "tiny", "base"])
+def test_device_plan_polar_order_is_a_permutation_inside_cameras(name):
+    metas = S.make_img_metas(name)
+    want = _host_plan(name, 1, metas)
+    _, dyn = _device_plan(name, 1, metas, order="polar")
+    got = dyn.materialize()
+    assert got.hits == want.hits
+    assert torch.equal(got.row_batch.cpu(), want.row_batch)           # rows stay grouped by camera
+    key_w = want.row_batch.long() * 10 ** 6 + want.row_query
+    key_g = got.row_batch.cpu().long() * 10 ** 6 + got.row_query.cpu()
+    assert torch.equal(key_g.sort().values, key_w)                    # same (camera, query) pairs
+    # each row carries its own anchors and the row table points back at it
+    rq, rb = got.row_query.cpu(), got.row_batch.cpu().long()
+    assert torch.equal(got.row_ref.cpu(), want.reference_points_cam[rb, 0, rq])
+    qr = got.q_rows.cpu()
+    for col in range(qr.shape[1]):
+        sel = qr[:, col] >= 0
+        assert torch.equal(rq[qr[sel, col].long()], torch.nonzero(sel).squeeze(-1))
+
+
+@pytest.mark.parametrize("q0,q1", [(0, 60), (60, 120), (30, 90)])
+def test_device_plan_of_a_tile_equals_the_sliced_host_plan(q0, q1):
+    from bevformer_amd.bev_tiling import slice_plan
+    metas = _perturbed_metas("micro4", 2, seed=3)
+    want = slice_plan(_host_plan("micro4", 2, metas), q0, q1)
+    _, dyn = _device_plan("micro4", 2, metas, tile=(q0, q1))
+    got = dyn.materialize()
+    assert torch.equal(got.row_query.cpu(), want.row_query)
+    assert torch.equal(got.row_batch.cpu(), want.row_batch)
+    assert torch.equal(got.row_ref.cpu(), want.row_ref)
+    assert torch.equal(got.inv_count.cpu(), want.inv_count)
+    J = want.q_rows.shape[1]
+    assert torch.equal(got.q_rows.cpu()[:, :J], want.q_rows)
+    assert torch.equal(got.bev_mask.cpu(), want.bev_mask)
+
+
+def test_row_capacity_overflow_is_counted_not_written():
+    metas = S.make_img_metas("tiny")
+    want = _host_plan("tiny", 1, metas)
+    R = want.row_query.numel()
+    pl, dyn = _device_plan("tiny", 1, metas, cap=R - 7)
+    c = dyn.counters.cpu().tolist()
+    assert c[0] == R - 7 and c[1] == 7 and c[3] == R
+    with pytest.raises(RuntimeError, match="row capacity"):
+        dyn.materialize()
+
+
+def test_plan_buffers_are_reused_and_follow_new_matrices():
+    """Frame t + 1 overwrites frame t's plan in place (graph-capturable) and reflects the new rig."""
+    m0 = S.make_img_metas("tiny")
+    m1 = _perturbed_metas("tiny", 1, seed=5)
+    pl, p0 = _device_plan("tiny", 1, m0, order="polar")
+    r0 = int(p0.nrows_dev.item())
+    ptr = p0.row_ref.data_ptr()
+    p1 = pl.plan(m1)
+    assert p1.row_ref.data_ptr() == ptr
+    want = _host_plan("tiny", 1, m1)
+    assert int(p1.nrows_dev.item()) == want.row_query.numel()
+    assert torch.equal(p1.bev_mask.cpu(), want.bev_mask)
+    assert r0 == _host_plan("tiny", 1, m0).row_query.numel()
+    # device-resident matrices (the bench's graph mode) give the same plan
+    m2 = [dict(lidar2img=torch.tensor(np.asarray(m1[0]["lidar2img"]), dtype=torch.float32, device=DEV),
+               img_shape=m1[0]["img_shape"])]
+    p2 = pl.plan(m2)
+    assert int(p2.nrows_dev.item()) == want.row_query.numel()
+    assert torch.equal(p2.reference_points_cam.cpu(), want.reference_points_cam)
+
+
+def _overlapping_metas(name):
+    """A rig whose cameras 0, 1, 2 look the same way: three cameras per visible query."""
+    metas = S.make_img_metas(name)
+    mats = metas[0]["lidar2img"]
+    metas[0]["lidar2img"] = [mats[0], mats[0].copy(), mats[0].copy(), mats[3], mats[4], mats[5]]
+    return metas
+
+
+@pytest.mark.parametrize("name,temporal", [("micro4", True), ("micro", False)])
+def test_encoder_on_device_plans_with_three_cameras_per_query(name, temporal):
+    """fold_extra_rows: queries seen by more than two cameras (the output projection gathers two
+    rows; the third is folded into the first beforehand) — against the oracle."""
+    enc, sd = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=temporal)
+    kw["img_metas"] = _overlapping_metas(name)
+    want_plan = _host_plan(name, 1, kw["img_metas"])
+    assert want_plan.q_rows.shape[1] >= 3
+    with torch.no_grad():
+        got = enc(q.to(DEV), f.to(DEV), f.to(DEV),
+                  **{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}).cpu()
+        want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,bs", [("micro4", 2), ("tiny", 1)])
+def test_encoder_device_plans_equal_host_plans(name, bs):
+    """Same frames through the torch-op plan builder (host syncs) and the device planner: the row
+    order differs (image Z-order vs static polar order), the rows and therefore the output do not
+    (sums of at most two camera rows commute)."""
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=2, bs=bs, temporal=True)
+    kw["img_metas"] = _perturbed_metas(name, bs, seed=4)
+    kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    with torch.no_grad():
+        enc.device_plans = True
+        a = enc(q.to(DEV), f.to(DEV), f.to(DEV), **kwd)
+        enc.device_plans = False
+        b = enc(q.to(DEV), f.to(DEV), f.to(DEV), **kwd)
+        enc.device_plans = True
+    torch.testing.assert_close(a, b, rtol=0, atol=1e-6)
+
+
+def test_device_plan_runs_without_host_sync():
+    """The inference step on device plans must not synchronise with the host: it has to run under
+    HIP-graph capture (a sync there raises) and the replay must follow new camera matrices."""
+    enc, sd = build_pair("micro4", device=DEV)
+    q, f, kw = S.make_inputs("micro4", seed=0, temporal=True)
+    metas = [_perturbed_metas("micro4", 1, seed=s) for s in (0, 11)]
+    l2i = torch.zeros(S.NUM_CAMS, 4, 4, device=DEV)
+    kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    kwd["img_metas"] = [dict(lidar2img=l2i, img_shape=metas[0][0]["img_shape"])]
+    qd, fd = q.to(DEV), f.to(DEV)
+
+    def load(m):
+        l2i.copy_(torch.tensor(np.asarray(m[0]["lidar2img"]), dtype=torch.float32))
+
+    load(metas[0])
+    with torch.no_grad():
+        enc(qd, fd, fd, **kwd)                       # planner + weight caches before the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            enc(qd, fd, fd, **kwd)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = enc(qd, fd, fd, **kwd)
+        for m in metas[::-1]:
+            load(m)
+            graph.replay()
+            kw["img_metas"] = m
+            want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+            torch.testing.assert_close(out.cpu(), want, rtol=2e-4, atol=2e-4)

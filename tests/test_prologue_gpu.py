@@ -95,4 +95,58 @@ def test_v2_bev_encoder_client_matches_oracle():
                                  img_metas=kw["img_metas"], pc_range=S.PC_RANGE)
         got = mine.to(DEV)([f.to(DEV) for f in mlvl], bq.to(DEV), kw["bev_h"], kw["bev_w"],
                            bev_pos=kw["bev_pos"].to(DEV), img_metas=kw["img_metas"]).cpu()
-    torch.testing.assert_close(got, want, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_get_bev_features_gradients_reach_features_and_embeddings():
+    """Training path: gradients must flow through the prologue to the backbone features,
+    ``cams_embeds`` and ``level_embeds`` (the flatten kernel has no autograd graph, so under
+    autograd the reference's torch statements run) — against autograd through the oracle."""
+    name = "micro4"
+    t, sd = build_transformer_pair(name, device=DEV)
+    mlvl, bq, kw = S.make_transformer_inputs(name, seed=2, bs=1, temporal=False)
+    own, enc = split_transformer_sd(sd)
+    w = S.WORKLOADS[name]
+    g = torch.Generator().manual_seed(9)
+    gout = torch.randn(1, w["bev_h"] * w["bev_w"], 256, generator=g)
+    # oracle: leaves on the CPU
+    own_c = {k: v.clone().requires_grad_(k in ("cams_embeds", "level_embeds")) for k, v in own.items()}
+    mlvl_c = [f.clone().requires_grad_(True) for f in mlvl]
+    want = O.get_bev_features(own_c, enc, mlvl_c, bq, kw["bev_h"], kw["bev_w"], bev_pos=kw["bev_pos"],
+                              img_metas=kw["img_metas"], pc_range=S.PC_RANGE, grid_length=kw["grid_length"],
+                              prev_bev=None, rotate_center=(w["bev_w"] // 2, w["bev_h"] // 2))
+    want.backward(gout)
+    # product
+    mlvl_d = [f.to(DEV).requires_grad_(True) for f in mlvl]
+    kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    t.train(False)
+    for p in t.parameters():
+        p.requires_grad_(True)
+    got = t.get_bev_features(mlvl_d, bq.to(DEV), **kwd)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=2e-4, atol=2e-4)
+    for a, b in zip(mlvl_d, mlvl_c):
+        assert a.grad is not None
+        scale = b.grad.abs().max().item()
+        assert (a.grad.cpu() - b.grad).abs().max().item() < 5e-3 * scale
+    for name_ in ("cams_embeds", "level_embeds"):
+        gp = getattr(t, name_).grad
+        assert gp is not None, name_
+        scale = own_c[name_].grad.abs().max().item()
+        assert (gp.cpu() - own_c[name_].grad).abs().max().item() < 5e-3 * scale, name_
+
+
+def test_linear_function_under_autocast():
+    """Mixed precision (the reference's *_fp16 configs): the projection autograd Function keeps
+    fp32 inside (custom_fwd / custom_bwd) and its backward runs without a dtype mismatch."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 256, generator=g).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(256, 128).to(DEV)
+    want = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = ops.linear_or_torch(x, lin.weight, lin.bias)
+        yf = ops._LinearFunction.apply(x, lin.weight, lin.bias, False, "t")
+    assert yf.dtype == torch.float32
+    torch.testing.assert_close(yf, want, rtol=1e-4, atol=1e-4)
+    (y.float().sum() + yf.sum()).backward()
+    assert x.grad is not None and lin.weight.grad is not None and torch.isfinite(x.grad).all()
