@@ -79,7 +79,8 @@ SIGNATURES = {
     "bevmsda_fused_forward_rows_bf16": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                         _c_int),
     "bevmsda_frame_plan_counters": ([_c_int, _c_int], ctypes.c_int64),
-    "bevmsda_frame_plan_f32": ([_c_void_p] * 3 + [ctypes.POINTER(PlanDesc)] + [_c_void_p] * 11, _c_int),
+    "bevmsda_frame_plan_scratch": ([_c_int, _c_int], ctypes.c_int64),
+    "bevmsda_frame_plan_f32": ([_c_void_p] * 3 + [ctypes.POINTER(PlanDesc)] + [_c_void_p] * 12, _c_int),
     "bevmsda_fold_extra_rows_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int,
                                      _c_void_p, _c_void_p], _c_int),
     "bevmsda_fused_forward_lds_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_int, _c_int, _c_void_p,

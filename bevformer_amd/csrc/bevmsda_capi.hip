@@ -263,27 +263,42 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   a.nblocks = static_cast<int>(nb);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nrows) {
-    // device-side row count (frame_plan.h): d->R is the capacity of the row arrays; fixed grid of at most
-    // kDynGridBlocks workgroups striding over the logical blocks of the actual count
+    // device-side row count (frame_plan.h): d->R is the capacity of the row arrays, desc->reserved[3] the
+    // caller's hint of the count (0: none).  Head launch: one workgroup per logical block of the hint;
+    // tail launch: a small grid striding over rows beyond the hint (msda_d32.h, DynRows).
+    if (d->R >= (1LL << 27)) return BEVMSDA_ERR_TOO_LARGE;
     f.nrows = nrows;
-    const long padded = ((nb + 7) / 8) * 8;
-    const dim3 dgrid(static_cast<unsigned>(padded < kDynGridBlocks ? padded : kDynGridBlocks));
+    long long hint = d->reserved[3];
+    if (hint < 0) return BEVMSDA_ERR_BAD_OPTION;
+    if (hint > d->R) hint = d->R;
+    f.launch_rows = static_cast<int>(hint);
+    const long htiles = (hint + a.qtile - 1) / a.qtile;
+    const long hnb = (htiles * a.qtile * a.M + 31) / 32;
+    const dim3 hgrid(static_cast<unsigned>(((hnb + 7) / 8) * 8));
+    const long rest = ((nb - hnb + 7) / 8) * 8;
+    const dim3 tgrid(static_cast<unsigned>(rest < 8 ? 8 : (rest < kDynGridBlocks ? rest : kDynGridBlocks)));
+#define BEVMSDA_DYN(HEAD_, TAIL_)                                                                          \
+  do {                                                                                                     \
+    if (hint > 0) hipLaunchKernelGGL(HEAD_, hgrid, dim3(256), 0, st, f);                                   \
+    if (hint < d->R) hipLaunchKernelGGL(TAIL_, tgrid, dim3(256), 0, st, f);                                \
+  } while (0)
     if constexpr (sizeof(T) == 2) {
       if (d->reserved[1] != 0 || d->reserved[0] != 0) return BEVMSDA_ERR_BAD_OPTION;
-      if (d->P == 8) hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_dyn_kernel<8, 1, 4>), dgrid, dim3(256), 0, st, f);
-      else if (d->K == 2) hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 2, 4>), dgrid, dim3(256), 0, st, f);
-      else hipLaunchKernelGGL((bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 1, 4>), dgrid, dim3(256), 0, st, f);
+      if (d->P == 8) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<8, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<8, 1, 4>));
+      else if (d->K == 2) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<4, 2, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 2, 4>));
+      else BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<4, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 1, 4>));
     } else {
       if (d->reserved[0] != 0) return BEVMSDA_ERR_BAD_OPTION;
       if (d->P == 8) {
-        if (d->L > 1) hipLaunchKernelGGL((bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>), dgrid, dim3(256), 0, st, f);
-        else hipLaunchKernelGGL((bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 8>), dgrid, dim3(256), 0, st, f);
+        if (d->L > 1) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>));
+        else BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 8>));
       } else if (d->K == 2) {
-        hipLaunchKernelGGL((bevmsda::msda_fused_d32_dyn_kernel<T, 4, 2, 8>), dgrid, dim3(256), 0, st, f);
+        BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 4, 2, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 4, 2, 8>));
       } else {
-        hipLaunchKernelGGL((bevmsda::msda_fused_d32_dyn_kernel<T, 4, 1, 8>), dgrid, dim3(256), 0, st, f);
+        BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 4, 1, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 4, 1, 8>));
       }
     }
+#undef BEVMSDA_DYN
     return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
   }
   const dim3 grid(static_cast<unsigned>(((nb + 7) / 8) * 8));

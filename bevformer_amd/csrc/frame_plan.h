@@ -7,13 +7,13 @@
 //   * SpatialCrossAttention.forward (spatial_cross_attention.py:136-153): per camera
 //     `mask_per_img[0].sum(-1).nonzero()` (a host sync per camera and per layer), padded rebatch;
 //   * ibid. :169-172: number of cameras that see a query, clamped to >= 1.
-// Here: two launches per frame.  plan_project_kernel does the projection for one BEV query and
-// all cameras per thread (in the SAME fp32 operation order as geometry.point_sampling: every
+// Here: three small launches per frame.  plan_project_kernel does the projection for one BEV query
+// and all cameras per thread (in the SAME fp32 operation order as geometry.point_sampling: every
 // product and sum rounded separately, no fused multiply-add), writes reference_points_cam,
-// bev_mask, 1 / camera count and a per-(camera, position) visibility byte; plan_compact_kernel
-// (one workgroup) turns the visibility bytes into the ragged row list — row_query, row_batch,
-// row_ref, the per-query row table — by a prefix sum per camera, and leaves the row COUNT in
-// device memory: the sampling kernel reads it there (FusedArgs::nrows), so a frame with new
+// bev_mask, 1 / camera count, a per-(camera, position) visibility byte and per-block visible
+// counts; plan_scan_kernel + plan_rows_kernel turn those into the ragged row list — row_query,
+// row_batch, row_ref, the per-query row table — by a prefix sum per camera, and leave the row
+// COUNT in device memory: the sampling kernel reads it there (FusedArgs::nrows), so a frame with new
 // camera matrices needs no `.item()` / `nonzero()` and a captured HIP graph of the step stays
 // valid when the number of rows changes (everything is sized by `row_capacity`).
 //
@@ -40,6 +40,8 @@ struct PlanArgs {
   float *row_ref;         // (cap, D, 2)
   int32_t *q_rows;        // (B * Qt, Nc) rows of every tile-local slot, increasing, -1 padded
   int32_t *q_rows2;       // (B * Qt, 2)  first two entries of the above (A-load of the output projection)
+  int32_t *block_counts;  // (Nc, nblk) visible positions of every block of 256 positions (scratch)
+  int32_t *block_base;    // (Nc, nblk) first row (batch element 0) of every block (scratch)
   int32_t *counters;      // [0] rows R, [1] rows dropped (capacity), [2] (j, q) with more than two cameras,
                           // [3] rows of one batch element, [4 .. 4 + B * Nc] first row of every (j, cam) run
   float sx, ox, sy, oy, sz, oz;   // de-normalisation: x = p * sx + ox (pc_range, encoder.py:102-107)
@@ -52,20 +54,20 @@ struct PlanArgs {
 constexpr int kPlanMaxCams = 16;
 constexpr int kPlanMaxAnchors = 8;
 
-__global__ void __launch_bounds__(256) plan_project_kernel(const PlanArgs a) {
+__device__ __forceinline__ void plan_project_one(const PlanArgs &a, int i, int q, int *cnt) {
 #pragma clang fp contract(off)
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.Q) return;
-  const int q = a.order[i];
   const bool mine = q >= a.q_lo && q < a.q_hi;
   const float eps = 1e-5f;
   for (int j = 0; j < a.B; ++j) {
     float px[kPlanMaxAnchors], py[kPlanMaxAnchors], pz[kPlanMaxAnchors];
     for (int d = 0; d < a.D; ++d) {
       const float *p = a.ref3d + (static_cast<long>(j * a.D + d) * a.Q + q) * 3;
-      px[d] = __fadd_rn(__fmul_rn(p[0], a.sx), a.ox);
-      py[d] = __fadd_rn(__fmul_rn(p[1], a.sy), a.oy);
-      pz[d] = __fadd_rn(__fmul_rn(p[2], a.sz), a.oz);
+      // plain operators under `fp contract(off)`: every product and sum is rounded on its own (the
+      // __fmul_rn / __fadd_rn wrappers are inlined WITH their own contract flags and fuse into FMAs)
+      const float tx = p[0] * a.sx, ty = p[1] * a.sy, tz = p[2] * a.sz;
+      px[d] = tx + a.ox;
+      py[d] = ty + a.oy;
+      pz[d] = tz + a.oz;
     }
     int seen = 0;
     for (int cam = 0; cam < a.Nc; ++cam) {
@@ -77,14 +79,15 @@ __global__ void __launch_bounds__(256) plan_project_kernel(const PlanArgs a) {
         float c[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          float s = __fadd_rn(__fmul_rn(m[r * 4 + 0], px[d]), __fmul_rn(m[r * 4 + 1], py[d]));
-          s = __fadd_rn(s, __fmul_rn(m[r * 4 + 2], pz[d]));
-          c[r] = __fadd_rn(s, m[r * 4 + 3]);
+          const float t0 = m[r * 4 + 0] * px[d], t1 = m[r * 4 + 1] * py[d], t2 = m[r * 4 + 2] * pz[d];
+          float s = t0 + t1;
+          s = s + t2;
+          c[r] = s + m[r * 4 + 3];
         }
         const float depth = c[2];
         const float den = (depth > eps || depth != depth) ? depth : eps;   // torch.clamp(min=eps), NaN kept
-        const float u = __fdiv_rn(__fdiv_rn(c[0], den), a.img_w);
-        const float v = __fdiv_rn(__fdiv_rn(c[1], den), a.img_h);
+        const float u = (c[0] / den) / a.img_w;       // IEEE division (hipcc's default: correctly rounded)
+        const float v = (c[1] / den) / a.img_h;
         const bool ok = depth > eps && v > 0.f && v < 1.f && u < 1.f && u > 0.f;
         rc[2 * d] = u;
         rc[2 * d + 1] = v;
@@ -93,10 +96,11 @@ __global__ void __launch_bounds__(256) plan_project_kernel(const PlanArgs a) {
       }
       if (j == 0) {       // the visible set of a camera comes from batch element 0 (spatial_cross_attention.py:139)
         a.slot[static_cast<long>(cam) * a.Q + i] = (any && mine) ? static_cast<uint8_t>(1 + seen) : 0;
+        if (any && mine) atomicAdd(&cnt[cam], 1);
       }
       seen += any ? 1 : 0;
     }
-    a.inv_count[static_cast<long>(j) * a.Q + q] = __fdiv_rn(1.0f, static_cast<float>(seen > 1 ? seen : 1));
+    a.inv_count[static_cast<long>(j) * a.Q + q] = 1.0f / static_cast<float>(seen > 1 ? seen : 1);
     if (mine) {
       const long sl = static_cast<long>(j) * (a.q_hi - a.q_lo) + (q - a.q_lo);
       int32_t *qr = a.q_rows + sl * a.Nc;
@@ -107,52 +111,53 @@ __global__ void __launch_bounds__(256) plan_project_kernel(const PlanArgs a) {
   }
 }
 
-// exclusive scan of one int per thread over a 1024-thread workgroup; returns the exclusive prefix, *total = sum
-__device__ __forceinline__ int block_scan_1024(int v, int *lds /* >= 17 ints */, int *total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int s = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(s, o, 64);
-    if (lane >= o) s += t;
-  }
-  __syncthreads();                      // lds free from the previous use
-  if (lane == 63) lds[wave] = s;
+__global__ void __launch_bounds__(256) plan_project_kernel(const PlanArgs a) {
+#pragma clang fp contract(off)
+  __shared__ int cnt[kPlanMaxCams];
+  if (threadIdx.x < kPlanMaxCams) cnt[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int w = 0; w < 16; ++w) { const int t = lds[w]; lds[w] = run; run += t; }
-    lds[16] = run;
-  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.Q;
+  const int q = live ? a.order[i] : 0;
+  if (live) plan_project_one(a, i, q, cnt);
   __syncthreads();
-  *total = lds[16];
-  return lds[wave] + s - v;
+  if (threadIdx.x < a.Nc) a.block_counts[threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(1024) plan_compact_kernel(const PlanArgs a) {
-  __shared__ int lds[17];
-  __shared__ int cam_rows[kPlanMaxCams + 1];
+// plan_project_kernel also leaves, per camera and per block of 256 positions, the number of visible
+// queries (block_counts[cam * nblk + blk]); plan_scan_kernel (one small workgroup) turns them into the
+// first row of every (camera, block) and the counters; plan_rows_kernel (one thread per camera and
+// position) writes the rows: position i of camera c goes to row block_base[c, i / 256] + (visible
+// positions before i inside its block), times the batch entries.
+__global__ void __launch_bounds__(256) plan_scan_kernel(const PlanArgs a, int nblk) {
+  __shared__ int lds[256];
+  __shared__ int cam_first[kPlanMaxCams + 1];
   const int tid = threadIdx.x;
-  const int chunk = (a.Q + 1023) / 1024;
-  const int i0 = tid * chunk < a.Q ? tid * chunk : a.Q;
-  const int i1 = i0 + chunk < a.Q ? i0 + chunk : a.Q;
-  // pass A: rows per camera (batch element 0's visible set)
   int run = 0;
   for (int cam = 0; cam < a.Nc; ++cam) {
-    const uint8_t *fl = a.slot + static_cast<long>(cam) * a.Q;
-    int c = 0;
-    for (int i = i0; i < i1; ++i) c += fl[i] != 0;
-    int tot;
-    block_scan_1024(c, lds, &tot);
-    if (tid == 0) cam_rows[cam] = run;
-    run += tot;
+    if (tid == 0) cam_first[cam] = run;
+    // exclusive scan of this camera's nblk block counts, 256 at a time
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+      const int b = b0 + tid;
+      const int v = b < nblk ? a.block_counts[cam * nblk + b] : 0;
+      __syncthreads();
+      lds[tid] = v;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        const int t = tid >= o ? lds[tid - o] : 0;
+        __syncthreads();
+        lds[tid] += t;
+        __syncthreads();
+      }
+      if (b < nblk) a.block_base[cam * nblk + b] = run + lds[tid] - v;
+      run += lds[255];
+    }
   }
   const int R0 = run;
   if (tid == 0) {
-    cam_rows[a.Nc] = R0;
+    cam_first[a.Nc] = R0;
     const long Rl = static_cast<long>(R0) * a.B;
-    const int R = Rl < a.cap ? static_cast<int>(Rl) : a.cap;
-    a.counters[0] = R;
+    a.counters[0] = Rl < a.cap ? static_cast<int>(Rl) : a.cap;
     a.counters[1] = Rl > a.cap ? static_cast<int>(Rl - a.cap) : 0;
     a.counters[3] = R0;
   }
@@ -160,39 +165,41 @@ __global__ void __launch_bounds__(1024) plan_compact_kernel(const PlanArgs a) {
   if (tid <= a.Nc) {
     for (int j = 0; j < a.B; ++j)
       if (tid < a.Nc || j == a.B - 1) {
-        const long v = static_cast<long>(j) * R0 + cam_rows[tid];
+        const long v = static_cast<long>(j) * R0 + cam_first[tid];
         a.counters[4 + j * a.Nc + tid] = v < a.cap ? static_cast<int>(v) : a.cap;
       }
   }
-  // pass B: scan again and write the rows
-  int extra = 0;
-  for (int cam = 0; cam < a.Nc; ++cam) {
-    const uint8_t *fl = a.slot + static_cast<long>(cam) * a.Q;
-    int c = 0;
-    for (int i = i0; i < i1; ++i) c += fl[i] != 0;
-    int tot;
-    int r = cam_rows[cam] + block_scan_1024(c, lds, &tot);
-    for (int i = i0; i < i1; ++i) {
-      const int s = fl[i];
-      if (!s) continue;
-      const int q = a.order[i];
-      for (int j = 0; j < a.B; ++j) {
-        const long rr = static_cast<long>(j) * R0 + r;
-        if (rr >= a.cap) continue;
-        const long sl = static_cast<long>(j) * (a.q_hi - a.q_lo) + (q - a.q_lo);
-        a.row_query[rr] = static_cast<int>(sl);
-        a.row_batch[rr] = j * a.Nc + cam;
-        const float *src = a.ref_cam + ((static_cast<long>(cam) * a.B + j) * a.Q + q) * a.D * 2;
-        float *dst = a.row_ref + rr * a.D * 2;
-        for (int d = 0; d < a.D * 2; ++d) dst[d] = src[d];
-        a.q_rows[sl * a.Nc + (s - 1)] = static_cast<int>(rr);
-        if (s <= 2) a.q_rows2[sl * 2 + (s - 1)] = static_cast<int>(rr);
-        if (s == 3) ++extra;
-      }
-      ++r;
-    }
+}
+
+__global__ void __launch_bounds__(256) plan_rows_kernel(const PlanArgs a, int nblk) {
+  __shared__ int wave_cnt[4];
+  const int cam = blockIdx.x / nblk, blk = blockIdx.x - cam * nblk;
+  const int i = blk * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = i < a.Q ? a.slot[static_cast<long>(cam) * a.Q + i] : 0;
+  const unsigned long long bal = __ballot(s != 0);
+  const int before = __popcll(bal & ((1ULL << lane) - 1ULL));
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int off = before;
+  for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+  if (!s) return;
+  const int R0 = a.counters[3];
+  const int r = a.block_base[cam * nblk + blk] + off;
+  const int q = a.order[i];
+  for (int j = 0; j < a.B; ++j) {
+    const long rr = static_cast<long>(j) * R0 + r;
+    if (rr >= a.cap) continue;
+    const long sl = static_cast<long>(j) * (a.q_hi - a.q_lo) + (q - a.q_lo);
+    a.row_query[rr] = static_cast<int>(sl);
+    a.row_batch[rr] = j * a.Nc + cam;
+    const float *src = a.ref_cam + ((static_cast<long>(cam) * a.B + j) * a.Q + q) * a.D * 2;
+    float *dst = a.row_ref + rr * a.D * 2;
+    for (int d = 0; d < a.D * 2; ++d) dst[d] = src[d];
+    a.q_rows[sl * a.Nc + (s - 1)] = static_cast<int>(rr);
+    if (s <= 2) a.q_rows2[sl * 2 + (s - 1)] = static_cast<int>(rr);
+    if (s == 3) atomicAdd(&a.counters[2], 1);
   }
-  if (extra) atomicAdd(&a.counters[2], extra);
 }
 
 // rows[q_rows[s, 0]] += sum_{j >= 2} rows[q_rows[s, j]] for the (rare) slots seen by more than two

@@ -219,21 +219,34 @@ struct FusedArgs {
   int out_f32;          // bf16-storage kernels only: write the output rows as fp32 (the consumer is the
                         // fp32 output projection) instead of bf16
   const int32_t *nrows; // optional DEVICE row count (frame_plan.h: counters[0]): when set, k.NQ is only the
-                        // capacity of the row arrays; the launch is a fixed-size grid that strides over the
-                        // logical blocks of the actual count, so one captured launch serves every frame
+                        // capacity of the row arrays and the launch geometry comes from `launch_rows`
+                        // (see DynRows), so one captured launch serves every frame
+  int launch_rows;      // host hint of the row count (<= capacity)
 };
 
-// Logical blocks of a launch whose row count lives on the device (DYN kernels).
+// Launches whose row count lives on the device.  Two kernels cover the rows:
+//   * head: rows [0, min(count, launch_rows)) — one workgroup per logical block like the fixed-count
+//     kernel, the block map (XCD-contiguous ranges) computed from the clamped count; `launch_rows` is
+//     the host's HINT of the count (frame plan of an earlier frame + margin), it sizes the grid;
+//   * tail: rows [launch_rows, count) — a small fixed grid striding over whatever the hint missed
+//     (normally nothing: the launch exits at once).  Correct for any count <= capacity; only speed
+//     depends on the hint.
 struct DynRows {
-  long NQ;
+  long NQ;        // rows in all (clamped to the capacity)
+  long row0;      // first row of this launch's share
   int nblocks, per;
 };
-__device__ __forceinline__ DynRows dyn_rows(const FusedArgs &f) {
+__device__ __forceinline__ DynRows dyn_rows(const FusedArgs &f, bool tail) {
   DynRows d;
-  const long n = *f.nrows;
-  d.NQ = n < f.k.NQ ? n : f.k.NQ;
-  const long tiles = (d.NQ + f.k.qtile - 1) / f.k.qtile;
-  d.nblocks = static_cast<int>((tiles * f.k.qtile * f.k.M + 31) / 32);
+  const int n = *f.nrows;
+  const int cap = static_cast<int>(f.k.NQ), hint = f.launch_rows;
+  const int total = n < cap ? n : cap;
+  const int head = total < hint ? total : hint;
+  d.NQ = tail ? total : head;
+  d.row0 = tail ? head : 0;
+  const int mine = tail ? total - head : head;
+  const int tiles = (mine + f.k.qtile - 1) / f.k.qtile;
+  d.nblocks = (tiles * f.k.qtile * f.k.M + 31) / 32;
   d.per = (d.nblocks + 7) >> 3;
   return d;
 }
@@ -261,14 +274,15 @@ __device__ __forceinline__ float lanes_sum(float v) {
 // KT = 2 (TemporalSelfAttention: PT = 4) both queue entries are sampled in the same
 // round and summed into the same accumulator (their mean is the output).
 template <typename T, int PT, int KT>
-__device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblock, long NQ) {
+__device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblock, long NQ, int tid, long row0 = 0) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
-  const int lig = threadIdx.x & 7;
-  const long G = static_cast<long>(lblock) * GPB + (threadIdx.x >> 3);
+  const int lig = tid & 7;
+  const long G = static_cast<long>(lblock) * GPB + (tid >> 3);
   long r; int m;
   map_group(G, a, r, m);
+  r += row0;
   const bool active = r < NQ;
   if (!active) r = NQ - 1;
   const int L = a.L;                                    // 1..4 (host-checked)
@@ -334,18 +348,31 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
 template <typename T, int PT, int KT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_kernel(const FusedArgs f) {
-  msda_fused_d32_body<T, PT, KT>(f, logical_block(f.k), f.k.NQ);
+  msda_fused_d32_body<T, PT, KT>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
 }
 
-// Same kernel over a device-side row count: fixed grid (a multiple of 8), every workgroup strides over
-// the logical blocks of the frame's actual row count with the same XCD-contiguous block map.
+// The same kernel over a device-side row count (DynRows): head = one workgroup per logical block of
+// the hinted count, tail = a small strided grid for rows beyond the hint.
+template <typename T, int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_head_kernel(const FusedArgs f) {
+  const DynRows d = dyn_rows(f, false);
+  const int b = blockIdx.x;
+  if ((b >> 3) >= d.per) return;
+  msda_fused_d32_body<T, PT, KT>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
+}
+
 template <typename T, int PT, int KT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_dyn_kernel(const FusedArgs f) {
-  const DynRows d = dyn_rows(f);
-  if (d.NQ <= 0) return;
-  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x)
-    msda_fused_d32_body<T, PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ);
+  const DynRows d = dyn_rows(f, true);
+  if (d.nblocks <= 0) return;
+#pragma nounroll
+  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    msda_fused_d32_body<T, PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
+  }
 }
 
 // ------------------------------------------------------------------ coarse level from LDS
@@ -527,15 +554,16 @@ __device__ __forceinline__ void sample_points_b8(const PointParams &p, __amdgpu_
 }
 
 template <int PT, int KT>
-__device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, int lblock, long NQ) {
+__device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, int lblock, long NQ, int tid, long row0 = 0) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
-  const int lig = threadIdx.x & 7;
+  const int lig = tid & 7;
   const bool upper = lig >= 4;                           // this lane's taps: x0 + 1
-  const long G = static_cast<long>(lblock) * GPB + (threadIdx.x >> 3);
+  const long G = static_cast<long>(lblock) * GPB + (tid >> 3);
   long r; int m;
   map_group(G, a, r, m);
+  r += row0;
   const bool active = r < NQ;
   if (!active) r = NQ - 1;
   const int L = a.L;
@@ -605,16 +633,29 @@ __device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, i
 template <int PT, int KT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
-  msda_fused_d32_bf16x8_body<PT, KT>(f, logical_block(f.k), f.k.NQ);
+  msda_fused_d32_bf16x8_body<PT, KT>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
+}
+
+template <int PT, int KT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_bf16x8_head_kernel(const FusedArgs f) {
+  const DynRows d = dyn_rows(f, false);
+  const int b = blockIdx.x;
+  if ((b >> 3) >= d.per) return;
+  msda_fused_d32_bf16x8_body<PT, KT>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
 }
 
 template <int PT, int KT, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_bf16x8_dyn_kernel(const FusedArgs f) {
-  const DynRows d = dyn_rows(f);
-  if (d.NQ <= 0) return;
-  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x)
-    msda_fused_d32_bf16x8_body<PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ);
+  const DynRows d = dyn_rows(f, true);
+  if (d.nblocks <= 0) return;
+#pragma nounroll
+  for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    msda_fused_d32_bf16x8_body<PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
+  }
 }
 
 }  // namespace bevmsda

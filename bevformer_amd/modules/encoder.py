@@ -78,12 +78,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
     def point_sampling(self, reference_points, pc_range, img_metas):
         return geometry.point_sampling(reference_points, pc_range, img_metas)
 
-    def row_order(self, device_plan=False):
+    def row_order(self):
         if self.sca_row_order != "auto":
             return self.sca_row_order
-        if torch.is_grad_enabled():
-            return "raster"
-        return "polar" if device_plan else "image"
+        return "raster" if torch.is_grad_enabled() else "image"
 
     def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None):
         """The per-frame geometry.  On a GPU: two kernel launches into the planner's buffers, no
@@ -91,8 +89,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         count, the torch statements of that path need sizes).  ``tile = (q0, q1)``: rows only for
         those BEV queries (bev_tiling)."""
         device = torch.device(device)
-        order = self.row_order(device_plan=True)
-        if self.device_plans and device.type == "cuda" and order in ("polar", "raster"):
+        order = self.row_order()
+        if self.device_plans and device.type == "cuda":
             num_cams = len(img_metas[0]["lidar2img"])
             key = (bev_h, bev_w, bs, str(device), order, tile, num_cams, self.num_points_in_pillar)
             planner = self._planners.get(key)
@@ -105,7 +103,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             plan = planner.plan(img_metas)
             return plan.materialize() if torch.is_grad_enabled() else plan
         assert tile is None, "tiles of a host-built plan come from bev_tiling.slice_plan"
-        order = self.row_order()
+        assert order in geometry.ROW_ORDERS, f"host-built plans know the row orders {geometry.ROW_ORDERS}"
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
                                 img_metas, device, dtype) + (order,)
         plan = self._plan_cache.get(key)

@@ -101,6 +101,7 @@ class FramePlan:
     # lives in ``nrows_dev`` (a (1,) int32 device view); nothing on the host knows it until
     # ``materialize()`` is called (the one host sync of the autograd path)
     nrows_dev: Optional[torch.Tensor] = None
+    launch_rows: int = 0              # host HINT of the row count (sizes the sampling launch; any count is correct)
     n_extra_dev: Optional[torch.Tensor] = None   # (1,) int32: slots seen by more than two cameras
     q_rows_all: Optional[torch.Tensor] = None    # (bs*Q, Nc) int32 (q_rows holds the first two columns)
     counters: Optional[torch.Tensor] = None
@@ -268,6 +269,34 @@ def polar_order(bev_h, bev_w, pc_range, az_bits=10, rg_bits=7):
     return np.argsort(key, kind="stable").astype(np.int32)
 
 
+def calibrated_image_order(bev_h, bev_w, pc_range, num_points_in_pillar, img_metas):
+    """Static row order calibrated on ONE rig (the first frame a planner sees): every query is
+    keyed by (first camera that sees it, Z-order of its projected pillar in that camera's image) —
+    the per-camera image Z-order of ``build_sca_rows`` — and queries no camera sees go last.  Later
+    frames reuse the table: ego-pose changes move the projections by a few pixels, which does not
+    disturb which rows are neighbours.  CPU torch ops, once per planner.  -> (Q,) int32."""
+    metas = []
+    for m in img_metas[:1]:
+        l2i = m["lidar2img"]
+        if torch.is_tensor(l2i):
+            l2i = [x for x in l2i.detach().double().cpu().numpy()]
+        metas.append(dict(lidar2img=l2i, img_shape=m["img_shape"]))
+    ref_3d = get_reference_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar,
+                                  dim="3d", bs=1, device="cpu", dtype=torch.float32)
+    ref_cam, mask = point_sampling(ref_3d, pc_range, metas)             # (Nc,1,Q,D,2), (Nc,1,Q,D)
+    Nc, _, Q, D = mask.shape
+    m = mask[:, 0].float()
+    vis = mask[:, 0].any(-1)                                             # (Nc,Q)
+    cnt = m.sum(-1).clamp(min=1.0)
+    u = (ref_cam[:, 0, :, :, 0] * m).sum(-1) / cnt
+    v = (ref_cam[:, 0, :, :, 1] * m).sum(-1) / cnt
+    first = torch.where(vis.any(0), vis.float().argmax(0), torch.full((Q,), Nc, dtype=torch.long))
+    qi = torch.arange(Q)
+    fc = first.clamp(max=Nc - 1)
+    key = first * (1 << 14) + _morton_key(u[fc, qi], v[fc, qi])
+    return torch.argsort(key, stable=True).to(torch.int32).numpy()
+
+
 class DevicePlanner:
     """Per-frame plans from the HIP frame-plan kernels (csrc/frame_plan.h,
     ``bevmsda_frame_plan_f32``): no ``nonzero()``, no ``.item()``, no sort.  One planner per
@@ -286,17 +315,22 @@ class DevicePlanner:
         self.q_lo, self.q_hi = (0, Q) if tile is None else tile
         Qt = self.q_hi - self.q_lo
         self.cap = int(row_capacity) if row_capacity else bs * num_cams * Qt
+        # static per grid: computed once ON THE CPU (torch.linspace rounds differently on the GPU; the
+        # reference's values on its CPU path are the oracle's) and uploaded
         self.ref_3d = get_reference_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar,
-                                           dim="3d", bs=bs, device=device, dtype=torch.float32)
-        self.ref_2d = get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device=device, dtype=torch.float32)
+                                           dim="3d", bs=bs, device="cpu", dtype=torch.float32).to(device)
+        self.ref_2d = get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device="cpu",
+                                           dtype=torch.float32).to(device)
         if row_order == "polar":
             order = polar_order(bev_h, bev_w, self.pc_range)
         elif row_order == "raster":
             order = np.arange(Q, dtype=np.int32)
+        elif row_order == "image":
+            order = None                        # calibrated on the first rig, in plan()
         else:
-            raise ValueError(f"device plans know the row orders 'polar' and 'raster', not {row_order!r}")
+            raise ValueError(f"device plans know the row orders 'image', 'polar' and 'raster', not {row_order!r}")
         self.row_order = row_order
-        self.order = torch.from_numpy(order).to(device)
+        self.order = torch.from_numpy(order).to(device) if order is not None else None
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         self.l2i = torch.zeros(bs, num_cams, 4, 4, dtype=f32, device=device)
         self.ref_cam = torch.empty(num_cams, bs, Q, self.D, 2, dtype=f32, device=device)
@@ -310,9 +344,12 @@ class DevicePlanner:
         self.q_rows2 = torch.empty(bs * Qt, 2, dtype=i32, device=device)
         n = int(_lib.load().bevmsda_frame_plan_counters(bs, num_cams))
         self.counters = torch.zeros(n, dtype=i32, device=device)
+        self.block_scratch = torch.zeros(int(_lib.load().bevmsda_frame_plan_scratch(num_cams, Q)), dtype=i32,
+                                         device=device)
         self.bev_shapes = torch.tensor([[bev_h, bev_w]], device=device)
         self.bev_start = torch.zeros(1, dtype=torch.long, device=device)
         self._last = None               # (host key of the camera matrices, plan) of the latest launch
+        self.launch_rows = 0            # row-count hint: the first frame's count + 12.5 % (one host read, once)
 
     def plan(self, img_metas):
         """Upload the camera matrices (the only per-frame host input) and launch the two kernels.
@@ -322,6 +359,9 @@ class DevicePlanner:
         from ..ext import _ptr
         first = img_metas[0]["lidar2img"]
         shp = img_metas[0]["img_shape"][0]
+        if self.order is None:                  # one-time calibration of the static row order (host work)
+            self.order = torch.from_numpy(calibrated_image_order(
+                self.bev_h, self.bev_w, self.pc_range, self.D, img_metas)).to(self.device)
         if torch.is_tensor(first):
             self._last = None
             for j, m in enumerate(img_metas):
@@ -342,10 +382,16 @@ class DevicePlanner:
         with torch.cuda.device(self.device):
             rc = lib.bevmsda_frame_plan_f32(
                 _ptr(self.l2i), _ptr(self.ref_3d), _ptr(self.order), ctypes.byref(d), _ptr(self.ref_cam),
-                _ptr(self.bev_mask), _ptr(self.inv_count), _ptr(self.slot), _ptr(self.row_query),
+                _ptr(self.bev_mask), _ptr(self.inv_count), _ptr(self.slot), _ptr(self.block_scratch),
+                _ptr(self.row_query),
                 _ptr(self.row_batch), _ptr(self.row_ref), _ptr(self.q_rows), _ptr(self.q_rows2),
                 _ptr(self.counters), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "frame_plan")
+        if self.launch_rows == 0 and not torch.cuda.is_current_stream_capturing():
+            # once per planner: read the first frame's row count to size later sampling launches (a hint:
+            # rows beyond it are picked up by the strided tail launch, bevmsda_fused_forward_rows_*)
+            r = int(self.counters[0].item())
+            self.launch_rows = min(self.cap, ((r + r // 8 + 511) // 256) * 256)
         q0, q1 = self.q_lo, self.q_hi
         tiled = (q0, q1) != (0, self.Q)
         inv = self.inv_count if not tiled else self.inv_count[:, q0:q1].contiguous()
@@ -359,7 +405,8 @@ class DevicePlanner:
             row_query=None, row_batch=self.row_batch, row_ref=self.row_ref, inv_count=inv,
             row_query32=self.row_query, q_rows=self.q_rows2, q_rows_all=self.q_rows, hits=None,
             cam_start=self.counters[4:], max_cam_rows=0, nrows_dev=self.counters[0:1],
-            n_extra_dev=self.counters[2:3], counters=self.counters, ref_2d_full=self.ref_2d)
+            n_extra_dev=self.counters[2:3], counters=self.counters, ref_2d_full=self.ref_2d,
+            launch_rows=self.launch_rows)
         if self._last is not None:
             self._last = (self._last[0], plan)
         return plan

@@ -148,7 +148,8 @@ class MSDeformableAttention3D(BaseModule):
         proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
         lds = {}
         if frame_plan is not None and frame_plan.dynamic:
-            lds = dict(nrows=frame_plan.nrows_dev)      # row count on the device (geometry.DevicePlanner)
+            # row count on the device (geometry.DevicePlanner); launch sized by the planner's hint
+            lds = dict(nrows=frame_plan.nrows_dev, launch_rows=frame_plan.launch_rows)
         elif ops._FUSED["lds_level"] and frame_plan is not None and frame_plan.cam_start is not None:
             px = getattr(frame_plan, "_last_level_pixels", None)
             if px is None:                      # one host read per plan (shapes live on the device)

@@ -178,7 +178,7 @@ def fused_wanted(*tensors):
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0, nrows=None):
+               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0, nrows=None, launch_rows=0):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -191,7 +191,8 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
 
     ``nrows`` ((1,) int32 device tensor, from a device-side frame plan): the ACTUAL number of
     rows; R above is then the capacity of the row arrays and the returned tensor has that many
-    rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``)."""
+    rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``);
+    ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint)."""
     _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
     store = _STORAGE["dtype"]
     value = value.to(store)
@@ -250,6 +251,7 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
             if nrows is not None:
                 _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
                      "bevmsda: nrows must be an int32 device tensor")
+                desc.reserved[3] = int(max(0, min(launch_rows, R)))
                 fnr = lib.bevmsda_fused_forward_rows_f32 if store == torch.float32 \
                     else lib.bevmsda_fused_forward_rows_bf16
                 rc = fnr(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
@@ -519,7 +521,8 @@ def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
                            precision=0 if mode == "split" else 1)
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
-    ctx = cb(tag, 2.0 * Qn * N * K, 4.0 * (rows.numel() + N * K + Qn * N)) if cb is not None else _NoTimer()
+    # algorithmic bytes: at most two source rows per output row (not the capacity of `rows`)
+    ctx = cb(tag, 2.0 * Qn * N * K, 4.0 * (min(rows.shape[0], 2 * Qn) * K + N * K + Qn * N)) if cb is not None else _NoTimer()
     with torch.cuda.device(rows.device), ctx:
         rc = lib.bevmsda_linear_gather_packed_f32(_ptr(rows), rows.stride(0), _ptr(idx), _ptr(scale), _ptr(blob),
                                                   _ptr(b) if b is not None else None, ctypes.byref(desc),

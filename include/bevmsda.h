@@ -182,8 +182,12 @@ int bevmsda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_sha
 
 /* The same entry points with the ROW COUNT in device memory: desc->R is the capacity of the row
  * arrays (row_batch, row_src, ref, out), `nrows` points to the actual count (int32, DEVICE memory,
- * e.g. counters[0] of bevmsda_frame_plan_f32), read by the kernel when it runs.  The launch
- * geometry depends on the capacity only, so one captured HIP graph serves every frame. */
+ * e.g. counters[0] of bevmsda_frame_plan_f32), read by the kernels when they run.
+ * desc->reserved[3] = the caller's HINT of the count (0 = none): rows below the hint are covered by
+ * a launch with one workgroup per block of rows like the fixed-count entry point, rows beyond it by
+ * a small strided launch — any count <= desc->R is computed correctly, the hint only sizes the
+ * grids.  The launch geometry depends on (capacity, hint) only, so one captured HIP graph serves
+ * every frame. */
 int bevmsda_fused_forward_rows_f32(const float *value, const int64_t *spatial_shapes,
                                    const int64_t *level_start, const float *offs, const float *logits,
                                    const float *ref, const int32_t *row_batch, const int32_t *row_src,
@@ -295,13 +299,13 @@ int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const i
  * pillar anchors + visibility (BEVFormerEncoder.point_sampling, encoder.py:88-149), the visible
  * (camera, query) pairs of SpatialCrossAttention as a ragged row list (spatial_cross_attention.py:
  * 136-153, without its per-camera nonzero() host syncs) and 1 / max(#cameras seeing a query, 1)
- * (ibid. :169-172).  Two launches, no host synchronisation; the row count stays on the device.
+ * (ibid. :169-172).  Three small launches, no host synchronisation; the row count stays on the device.
  *
  *   lidar2img (B, Nc, 4, 4) fp32;  ref_3d (B, D, Q, 3) normalised anchors (encoder.py:62-71);
  *   order (Q,) int32: position -> BEV query, the row order inside a camera
  * outputs (caller-owned, all DEVICE memory):
  *   ref_cam (Nc, B, Q, D, 2), bev_mask (Nc, B, Q, D) bytes 0/1, inv_count (B, Q),
- *   slot (Nc, Q) scratch bytes, row_query / row_batch (row_capacity,) int32 (tile-local slot
+ *   slot (Nc, Q) scratch bytes, block_scratch (bevmsda_frame_plan_scratch(Nc, Q) int32), row_query / row_batch (row_capacity,) int32 (tile-local slot
  *   j*Qt + q - q_lo with Qt = q_hi - q_lo; value batch entry j*Nc + cam), row_ref (row_capacity, D, 2),
  *   q_rows (B*Qt, Nc) / q_rows2 (B*Qt, 2) int32 rows of every slot (-1 = none),
  *   counters (bevmsda_frame_plan_counters(B, Nc) int32): [0] rows, [1] rows dropped because
@@ -319,9 +323,11 @@ typedef struct bevmsda_plan_desc {
 } bevmsda_plan_desc;
 
 int64_t bevmsda_frame_plan_counters(int B, int Nc);
+int64_t bevmsda_frame_plan_scratch(int Nc, int Q);
 int bevmsda_frame_plan_f32(const float *lidar2img, const float *ref_3d, const int32_t *order,
                            const bevmsda_plan_desc *desc, float *ref_cam, uint8_t *bev_mask,
-                           float *inv_count, uint8_t *slot, int32_t *row_query, int32_t *row_batch,
+                           float *inv_count, uint8_t *slot, int32_t *block_scratch,
+                           int32_t *row_query, int32_t *row_batch,
                            float *row_ref, int32_t *q_rows, int32_t *q_rows2, int32_t *counters,
                            void *stream);
 /* rows[q_rows[s, 0]] += sum_{j >= 2} rows[q_rows[s, j]] for slots seen by more than two cameras, so

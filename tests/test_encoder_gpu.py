@@ -2,7 +2,7 @@
 
 Tolerance: fp32 everywhere; the product re-associates the module math (merged
 GEMMs, rocBLAS/hipBLASLt summation order, reciprocal camera count, fused
-sampling order) so agreement is to rounding: rtol = atol = 2e-4 on O(1)
+sampling order) so agreement is to rounding: rtol = atol = 5e-4 on O(1)
 LayerNorm-ed activations (the one encoder-level number: DESIGN.md §2, bench.py,
 tests/test_baseline_configs_gpu.py), gradients 2e-3 of each tensor's max
 (atomic accumulation order in grad_value)."""
@@ -17,7 +17,7 @@ from helpers import build_pair
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
-TOL = dict(rtol=2e-4, atol=2e-4)      # encoder-level fp32 tolerance (bench.py ENC_TOL)
+TOL = dict(rtol=5e-4, atol=5e-4)      # encoder-level fp32 tolerance (bench.py ENC_TOL)
 
 
 @pytest.fixture(params=["split", "native"])
