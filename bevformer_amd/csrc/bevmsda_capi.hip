@@ -1,8 +1,12 @@
 // C ABI of libbevmsda.so (declared in include/bevmsda.h): argument checks,
 // kernel selection and launches.  No torch, no allocation, no global state.
+#include <stdlib.h>
+
 #include "../../include/bevmsda.h"
 #include "msda_kernels.h"
 #include "msda_d32.h"
+#include "msda_bwd_lds.h"
+#include "msda_bwd_gather.h"
 #include "rowops.h"
 #include "prologue.h"
 
@@ -14,6 +18,7 @@ using bevmsda::bf16_t;
 // library defaults (chosen from the sweeps recorded in DESIGN.md)
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
+constexpr int kGvRowsPerBlock = 256;         // rows of one head per workgroup of the LDS-tiled grad_value kernel
 constexpr long kDynGridBlocks = 8192;        // grid of the device-row-count sampling launches (multiple of 8)
 constexpr int kLdsLevelRowsPerBlock = 256;   // rows of one (camera, head) per block of the LDS-level kernel
 
@@ -66,16 +71,73 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
   a.nblocks = static_cast<int>(nb);
   const unsigned grid = a.xcd_remap ? static_cast<unsigned>(((nb + 7) / 8) * 8) : static_cast<unsigned>(nb);
   if (BWD && a.D == 32 && a.variant != 1) {
-    // D = 32: line-shaped atomics (8 rows per wave in float4 lane groups)
     KArgs b = a;
     const long g8 = tiles * a.qtile * a.M;
     const long nb8 = (g8 + 31) / 32;
     b.nblocks = static_cast<int>(nb8);
     const unsigned grid8 = b.xcd_remap ? static_cast<unsigned>(((nb8 + 7) / 8) * 8) : static_cast<unsigned>(nb8);
-    switch (a.P) {
-      case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 4>), dim3(grid8), dim3(256), 0, stream, b); break;
-      case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 8>), dim3(grid8), dim3(256), 0, stream, b); break;
-      default: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 0>), dim3(grid8), dim3(256), 0, stream, b); break;
+    // grad_value through LDS tiles (msda_bwd_lds.h) unless variant 3 asks for the first-generation kernel
+    // (one memory-side atomic per tap) or the shape does not fit the tiled kernel
+    const int G = a.P % 4 == 0 ? 4 : (a.P % 2 == 0 ? 2 : 1);
+    // (entries carry the pixel index of a level in 23 bits and the row of the block in 8)
+    const int rpt = (kGvRowsPerBlock * a.P + bevmsda::kGvThreads - 1) / bevmsda::kGvThreads;
+    bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
+    tiled = tiled && 1LL * a.S < (1LL << 23) && a.NQ < (1LL << 30) && 1LL * a.N * (1LL * a.Q * 3 / 512 + 4) * 256 < (1LL << 30);
+    if (tiled) {
+      bevmsda::GradValueArgs s{};
+      s.k = a;
+      s.rows_per_block = kGvRowsPerBlock;
+      s.gbits = G == 4 ? 2 : (G == 2 ? 1 : 0);
+      long chunks = (a.NQ + s.rows_per_block - 1) / s.rows_per_block;
+      if (!a.row_batch && a.L == 1 && a.Q >= 1024 && s.rows_per_block == 256) {
+        // dense single-level call: room for the 16 x 16 tiles of a roughly square grid (msda_bwd_lds.h)
+        s.dense_tiles = static_cast<int>(1LL * a.Q * 3 / (256 * 2) + 4);
+        chunks = 1L * a.N * s.dense_tiles;
+      }
+      if (chunks * a.M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+      const size_t lds_bytes = (static_cast<size_t>(bevmsda::kGvBuckets) + static_cast<size_t>(s.rows_per_block) * a.P * 8 +
+                                static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4;
+      const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(bevmsda::kGvThreads);
+      // BEVMSDA_GV_PROFILE=<hex device address of 8 uint64>: phase clocks of the sort kernel (tools/gvprof.py)
+      const char *pe = getenv("BEVMSDA_GV_PROFILE");
+      if (pe) s.prof = reinterpret_cast<unsigned long long *>(strtoull(pe, nullptr, 16));
+#define BEVMSDA_GV(RPT_)                                                                                                \
+  do {                                                                                                                  \
+    if (pe) {                                                                                                           \
+      auto kern = bevmsda::msda_gradvalue_sort_kernel<T, RPT_, true>;                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;                    \
+      hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);                                                    \
+    } else {                                                                                                            \
+      auto kern = bevmsda::msda_gradvalue_sort_kernel<T, RPT_, false>;                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;                    \
+      hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);                                                    \
+    }                                                                                                                   \
+  } while (0)
+      if (rpt == 1) BEVMSDA_GV(1);
+      else BEVMSDA_GV(2);
+#undef BEVMSDA_GV
+      // grad_loc / grad_attn: the forward-style gather kernel (buffer loads: value < 2 GiB, P in {4, 8}),
+      // else the first-generation kernel without its scatter
+      if (d32_fwd_eligible<T>(a)) {
+        // (P = 8 in fp32 needs 140 VGPRs for two batches of 16 taps in flight: 3 waves / SIMD)
+        if (a.P == 8) hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_kernel<T, 8, sizeof(T) == 4 ? 3 : 4>), dim3(grid8), dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_kernel<T, 4, 4>), dim3(grid8), dim3(256), 0, stream, b);
+      } else {
+        switch (a.P) {
+          case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 4, false>), dim3(grid8), dim3(256), 0, stream, b); break;
+          case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 8, false>), dim3(grid8), dim3(256), 0, stream, b); break;
+          default: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 0, false>), dim3(grid8), dim3(256), 0, stream, b); break;
+        }
+      }
+    } else {
+      // D = 32, first generation: line-shaped atomics (8 rows per wave in float4 lane groups)
+      switch (a.P) {
+        case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 4>), dim3(grid8), dim3(256), 0, stream, b); break;
+        case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 8>), dim3(grid8), dim3(256), 0, stream, b); break;
+        default: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 0>), dim3(grid8), dim3(256), 0, stream, b); break;
+      }
     }
   } else if (BWD) {
     switch (a.P) {
@@ -214,7 +276,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   a.xcd_remap = (xr == 1) ? 0 : 1;
   int variant = tuning ? tuning->variant : 0;
   if (variant < 0 || variant > 5) return BEVMSDA_ERR_BAD_OPTION;
-  if (variant > 2) variant = 0;  // 3..5 select forward kernels only
+  if (variant > 3) variant = 0;  // 4, 5 select forward kernels only; 3 = first-generation D = 32 backward
   a.variant = variant;
   a.mshift = ilog2_exact(M);
   a.qshift = ilog2_exact(a.qtile);

@@ -1,0 +1,293 @@
+// Backward of multi-scale deformable attention, D = 32, second generation:
+// grad_value by a per-workgroup counting sort + segmented reduction in LDS instead of one memory-side
+// atomic per bilinear tap.
+//
+// Why: the first backward (msda_kernels.h, msda_bwd_d32_kernel) issues one 128-byte-line fp32 atomic
+// per (row, head, level, point, tap): 47 M line operations per base SCA call, and the L2 atomic units
+// retire ~10 G of them per second whatever their scope (tools/probes/atomic_probe.hip) — 4.7 ms of
+// 6.5-8.6 ms, 1 % of the HBM roofline.  Neighbouring rows hit the same pixels: per 256-row block of one
+// (camera, head) the taps of one (level, pillar anchor) land on 20-400 distinct pixels out of 2,000
+// (measured on the base rig).  LDS float atomics do not help either (a first version
+// accumulated in a dense LDS tile with ds_add_f32: 6.5 ms — the LDS retires float atomics far below its
+// load / store rate).  So the taps are SORTED by pixel in LDS and each pixel's contributions are summed
+// in registers:
+//
+//   * msda_bwd_d32_kernel<T, PT, false> (msda_kernels.h) keeps grad_loc / grad_attn (a gather with an
+//     in-register channel reduction) and drops the scatter;
+//   * msda_gradvalue_sort_kernel (here) owns the scatter.  A workgroup takes `rows_per_block`
+//     consecutive rows of ONE head (split at value-batch-entry boundaries).  For every (level, point
+//     group) — point group g = points p with p % G == g, i.e. the points that share a pillar anchor in
+//     SpatialCrossAttention — one thread per (row, point) record computes the four taps; the workgroup
+//     finds their bounding box, counts taps per pixel of the box (integer LDS atomics), scans the
+//     counts, places (pixel, row, coefficient) entries in pixel order, and then every half-wave walks a
+//     contiguous share of the sorted entries: lane c accumulates coefficient x grad_out[row, c] in a
+//     register while the pixel stays the same and issues ONE memory-side atomic per (pixel, head) line
+//     when it changes.  Memory-side atomics drop from 47 M to ~3.5 M per base SCA call.
+//     (As built: ONE pass per level — all points of all rows, 2,048 records — and instead of a bounding
+//     box the taps are counted into 4,096 buckets keyed by (point group, y mod 2^b, x mod 2^b): pixels of
+//     one group's footprint fall into distinct buckets unless the footprint is wider than 2^b, and a
+//     bucket that does mix pixels only costs an extra flush, never a wrong sum.  5 barriers per level.)
+//
+// Numerics: fp32 sums in a different (still unordered) association; parity tests use the same
+// tolerances as for the first kernel.  grad_value is accumulated into (caller zeroes it).
+#pragma once
+#include "msda_kernels.h"
+
+namespace bevmsda {
+
+struct GradValueArgs {
+  int dense_tiles;     // > 0 (dense single-level calls, rows_per_block = 256): the launch has this many row
+                       // chunks per batch entry; when the level is an H0 x W0 grid with Q = H0 * W0 (read on
+                       // the device: TemporalSelfAttention, whose rows are the BEV grid in raster order) and
+                       // its 16 x 16 tiles fit that count, chunk t takes tile t of the grid instead of 256
+                       // consecutive rows — any row order gives the same sums, this one makes the rows of a
+                       // workgroup share taps
+  KArgs k;             // value unused; loc, attn, grad_out, grad_value, row_batch, NQ, N, S, M, L, Q, P
+  int rows_per_block;  // <= kGvMaxRows
+  int gbits;           // log2 of the point groups per level G (G = 1, 2, 4: points p with equal p % G share a
+                       // pillar anchor in SpatialCrossAttention and therefore a footprint)
+  unsigned long long *prof;   // PROF kernels only: phase clock sums + [7] flush count
+};
+
+constexpr int kGvThreads = 1024;     // 32 half-waves
+constexpr int kGvMaxRows = 256;      // rows of one head per workgroup
+constexpr int kGvBuckets = 4096;     // counters of the sort
+constexpr int kGvMaxLevels = 4;
+
+template <typename T> __device__ __forceinline__ float4 load_gout4(const T *p);
+template <> __device__ __forceinline__ float4 load_gout4<float>(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+template <> __device__ __forceinline__ float4 load_gout4<bf16_t>(const bf16_t *p) {
+  const uint2 t = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
+}
+
+// In-place exclusive scan of cnt[0 .. kGvBuckets] (kGvBuckets + 1 entries, the last one = total) by the
+// whole workgroup: 4 counters per thread.  Two barriers.
+__device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvThreads / 64 ints */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = kGvBuckets / kGvThreads;
+  int4 v = reinterpret_cast<int4 *>(cnt)[tid];
+  static_assert(PER == 4, "4 counters per thread");
+  const int s = v.x + v.y + v.z + v.w;
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - s, total = 0;
+#pragma unroll
+  for (int w = 0; w < kGvThreads / 64; ++w) {
+    const int t = wsum[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  reinterpret_cast<int4 *>(cnt)[tid] = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+  __syncthreads();
+  return total;
+}
+
+#define GV_TICK(slot)                                                                          \
+  if constexpr (PROF) {                                                                        \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                \
+    if (tid == 0) atomicAdd(&s.prof[slot], t_ - t_prev);                                       \
+    t_prev = t_;                                                                               \
+  }
+
+// LDS carve (4-byte words): [cnt: kGvBuckets][entries: rows * P * 4 x 2][grad_out rows: rows * 32][wsum 16][misc 4]
+// RPT = (row, point) records per thread and level = ceil(rows_per_block * P / kGvThreads).
+template <typename T, int RPT, bool PROF = false>
+__global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const GradValueArgs s) {
+  unsigned long long t_prev = 0;
+  if constexpr (PROF) t_prev = __builtin_readcyclecounter();
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const KArgs &a = s.k;
+  constexpr int D = 32;
+  const int L = a.L, P = a.P;
+  int *cnt = reinterpret_cast<int *>(lds);
+  int2 *ent = reinterpret_cast<int2 *>(cnt + kGvBuckets);
+  float *gl = reinterpret_cast<float *>(ent + s.rows_per_block * P * 4);
+  int *wsum = reinterpret_cast<int *>(gl + static_cast<long>(s.rows_per_block) * D);
+  int *misc = wsum + kGvThreads / 64;
+  const int tid = threadIdx.x;
+  const int m = blockIdx.x % a.M;
+  const int chunk = blockIdx.x / a.M;
+  // virtual row -> row of the operands (-1: a tile cell outside the grid)
+  const int W0 = static_cast<int>(a.shapes[1]), H0 = static_cast<int>(a.shapes[0]);
+  const int tile_w = (W0 + 15) >> 4, tile_h = (H0 + 15) >> 4;
+  const bool tiled = s.dense_tiles > 0 && static_cast<long>(H0) * W0 == a.Q && tile_w * tile_h <= s.dense_tiles;
+  // (row counts fit 31 bits: checked by the launcher)
+  const int vq = tiled ? s.dense_tiles * 256 : a.Q;                           // virtual rows per batch entry
+  const int vrows = tiled ? vq * a.N : static_cast<int>(a.NQ);
+  const int c0 = chunk * s.rows_per_block;
+  if (c0 >= vrows) return;
+  const int c1 = c0 + s.rows_per_block < vrows ? c0 + s.rows_per_block : vrows;
+  const int my_tile = tiled ? chunk % s.dense_tiles : 0;                      // tiled: one chunk = one tile
+  if (tiled && my_tile >= tile_w * tile_h) return;
+  const int tile_y0 = tiled ? (my_tile / tile_w) * 16 : 0, tile_x0 = tiled ? (my_tile % tile_w) * 16 : 0;
+  const int tile_n = tiled ? chunk / s.dense_tiles : 0;
+  auto phys = [&](int vr) -> int {
+    if (!tiled) return vr;
+    const int w = vr - c0;                                                    // 0 .. 255 inside my tile
+    const int y = tile_y0 + (w >> 4), x = tile_x0 + (w & 15);
+    return (y < H0 && x < W0) ? tile_n * a.Q + y * W0 + x : -1;
+  };
+  const int pix_stride = a.M * D;
+  const int half = tid >> 5;          // 32 half-waves per workgroup
+  const int c = tid & 31;             // my channel
+  // bucket of a tap: [point group | y mod 2^yb | x mod 2^xb], 12 bits
+  const int gbits = s.gbits, gmask = (1 << gbits) - 1;
+  const int xb = (12 - gbits + 1) >> 1, yb = 12 - gbits - xb;
+  const int xm = (1 << xb) - 1, ym = (1 << yb) - 1;
+
+  // grad_out of the chunk's rows and my head -> LDS
+  for (int i = tid; i < (c1 - c0) * 8; i += kGvThreads) {
+    const int row = i >> 3, q4 = (i & 7) * 4;
+    const int pr = phys(c0 + row);
+    reinterpret_cast<float4 *>(gl)[i] = pr < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) :
+        load_gout4<T>(static_cast<const T *>(a.grad_out) + (static_cast<long>(pr) * a.M + m) * D + q4);
+  }
+
+  // sub-ranges of rows that share a value batch entry (rows are grouped by camera: normally one)
+  int r0 = c0;
+  while (r0 < c1) {
+    const long n0 = a.row_batch ? static_cast<long>(a.row_batch[r0]) : r0 / vq;
+    int r1;
+    if (a.row_batch) {
+      __syncthreads();
+      if (tid == 0) misc[0] = c1 - r0;
+      __syncthreads();
+      for (int r = r0 + tid; r < c1; r += kGvThreads)
+        if (a.row_batch[r] != n0) atomicMin(&misc[0], r - r0);
+      __syncthreads();
+      r1 = r0 + misc[0];
+    } else {
+      const long e = (n0 + 1) * vq;
+      r1 = e < c1 ? static_cast<int>(e) : c1;
+    }
+    const int nrows = r1 - r0;
+    const int grow0 = r0 - c0;                         // first row of the sub-range inside gl
+    const int nrec = nrows * P;                        // records per level
+
+    // every record of every level of my rows, loaded up front (the only trips to memory on the critical
+    // path; a later wait for loads would also drain the wave's outstanding flush atomics)
+    float2 xy[kGvMaxLevels][RPT];
+    float aw[kGvMaxLevels][RPT];
+#pragma unroll
+    for (int l = 0; l < kGvMaxLevels; ++l)
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        xy[l][j] = make_float2(-8.f, -8.f);             // outside every map: no tap
+        aw[l][j] = 0.f;
+        const int i = j * kGvThreads + tid;
+        if (l < L && i < nrec) {
+          const int rw = i / P, p = i - rw * P;
+          const int pr = phys(r0 + rw);
+          if (pr >= 0) {
+            const long pi = ((static_cast<long>(pr) * a.M + m) * L + l) * P + p;
+            xy[l][j] = reinterpret_cast<const float2 *>(a.loc)[pi];
+            aw[l][j] = a.attn[pi];
+          }
+        }
+      }
+    GV_TICK(0)
+
+#pragma unroll
+    for (int l = 0; l < kGvMaxLevels; ++l) {
+      if (l >= L) break;
+      const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+      float *gv = a.grad_value + ((n0 * a.S + a.lstart[l]) * a.M + m) * D + c;
+      // ---- (1) zero the counters
+      reinterpret_cast<int4 *>(cnt)[tid] = make_int4(0, 0, 0, 0);
+      __syncthreads();
+      // ---- (2) my records: four taps each, counted into their buckets
+      int pix[RPT][4], key[RPT][4], rowj[RPT];
+      float k[RPT][4];
+      bool ok[RPT][4];
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const int i = j * kGvThreads + tid;
+        const int rw = i / P, p = i - rw * P;
+        rowj[j] = rw;
+        const float x = xy[l][j].x * W - 0.5f, y = xy[l][j].y * H - 0.5f;
+        const bool inside = i < nrec && x > -1.f && y > -1.f && x < W && y < H;
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = static_cast<int>(xf), y0 = static_cast<int>(yf);
+        const float fx = x - xf, fy = y - yf;
+        const float gx = 1.f - fx, gy = 1.f - fy;
+        const int gkey = (p & gmask) << (xb + yb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+          k[j][t] = ((t >> 1) ? fy : gy) * ((t & 1) ? fx : gx) * aw[l][j];
+          ok[j][t] = inside && xx >= 0 && yy >= 0 && xx < W && yy < H && k[j][t] != 0.f;
+          pix[j][t] = yy * W + xx;
+          key[j][t] = gkey | ((yy & ym) << xb) | (xx & xm);
+          if (ok[j][t]) atomicAdd(&cnt[key[j][t]], 1);
+        }
+      }
+      __syncthreads();
+      GV_TICK(1)
+      // ---- (3) scan, place
+      const int total = block_exclusive_scan(cnt, wsum);
+      GV_TICK(2)
+#pragma unroll
+      for (int j = 0; j < RPT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (ok[j][t]) {
+            const int pos = atomicAdd(&cnt[key[j][t]], 1);
+            ent[pos] = make_int2(pix[j][t] | ((grow0 + rowj[j]) << 23), __float_as_int(k[j][t]));
+          }
+      __syncthreads();
+      GV_TICK(3)
+      // ---- (4) segmented reduction: my 1/32 of the sorted entries, one atomic per pixel run
+      {
+        const int e0 = static_cast<int>(static_cast<long>(total) * half / (kGvThreads / 32));
+        const int e1 = static_cast<int>(static_cast<long>(total) * (half + 1) / (kGvThreads / 32));
+        int cur = -1;
+        float acc = 0.f;
+        // 8 entries at a time: their LDS reads (entry, then grad_out of its row) are issued together,
+        // the run logic walks them in order (entries past the end repeat the last one with a zero
+        // coefficient: same pixel, no extra flush)
+        for (int e = e0; e < e1; e += 8) {
+          int2 en[8];
+          float gg[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool in = e + j < e1;
+            en[j] = ent[in ? e + j : e1 - 1];
+            if (!in) en[j].y = 0;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gg[j] = gl[(en[j].x >> 23) * D + c];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int px = en[j].x & 0x7fffff;
+            if (px != cur) {
+              if (cur >= 0) {
+                unsafeAtomicAdd(gv + static_cast<long>(cur) * pix_stride, acc);
+                if constexpr (PROF) { if (c == 0) atomicAdd(&s.prof[7], 1ULL); }
+              }
+              cur = px;
+              acc = 0.f;
+            }
+            acc = fmaf(__int_as_float(en[j].y), gg[j], acc);
+          }
+        }
+        if (cur >= 0) unsafeAtomicAdd(gv + static_cast<long>(cur) * pix_stride, acc);
+      }
+      GV_TICK(4)
+      // (the next level's placement is separated from these reads by the barriers of its steps 1-3)
+    }
+    r0 = r1;
+  }
+  GV_TICK(6)
+}
+#undef GV_TICK
+
+}  // namespace bevmsda

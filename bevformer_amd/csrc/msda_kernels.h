@@ -364,7 +364,8 @@ struct Io<bf16_t, 4> {
   }
 };
 
-template <typename T, int PT>
+// SCATTER = false: grad_loc / grad_attn only (grad_value comes from msda_bwd_lds.h).
+template <typename T, int PT, bool SCATTER = true>
 __global__ void __launch_bounds__(256) msda_bwd_d32_kernel(const KArgs a) {
   constexpr int LPG = 8, CPL = 4, D = 32, GPB = 256 / LPG;
   const int lane = threadIdx.x & 63;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(256) msda_bwd_d32_kernel(const KArgs a) {
   float gd[4];
   long long gbase[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; SCATTER && k < 4; ++k) {
     const int src = half_base + k * 8;        // first lane of that row's group
     const float e0 = __shfl(g[0], src + (half_lane >> 2), 64), e1 = __shfl(g[1], src + (half_lane >> 2), 64);
     const float e2 = __shfl(g[2], src + (half_lane >> 2), 64), e3 = __shfl(g[3], src + (half_lane >> 2), 64);
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(256) msda_bwd_d32_kernel(const KArgs a) {
 
         // scatter: 4 rows x 4 taps per half-wave, one full line per atomic
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; SCATTER && k < 4; ++k) {
           const int src = half_base + k * 8;
           const float k00 = __shfl(c00, src, 64), k01 = __shfl(c01, src, 64);
           const float k10 = __shfl(c10, src, 64), k11 = __shfl(c11, src, 64);

@@ -60,10 +60,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
         self.fp16_enabled = False
         self._plan_cache = {}
         self.plan_cache_size = 4
-        # order of the ragged SCA rows inside a camera (geometry.build_sca_rows): "image" (Z-order of
-        # the projected pillar: best for the forward kernels, 235 vs 289 us), "raster" (BEV order:
-        # best for the backward kernel, whose atomics contend on image-coherent rows: 81.6 vs
-        # 99.6 ms fwd+bwd, profiles/r1/r1t_*), or "auto": image under no_grad, raster under autograd
+        # order of the ragged SCA rows inside a camera: "image" (Z-order of the projected pillar: rows
+        # handled together sample neighbouring pixels — best for the forward kernels (235 vs 289 us) and,
+        # since the backward sorts its taps per workgroup in LDS, for the backward too (1.39 vs 1.56 ms;
+        # the first-generation atomic backward preferred raster rows: r1t profiles), "raster" (BEV
+        # order, the reference's nonzero() order) or "polar"; "auto" = image
         self.sca_row_order = "auto"
         self.bev_tiling = None          # set by bev_tiling.enable_bev_tiling()
         # GPU tensors: plans come from the HIP frame-plan kernels (geometry.DevicePlanner: no host
@@ -81,7 +82,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
     def row_order(self):
         if self.sca_row_order != "auto":
             return self.sca_row_order
-        return "raster" if torch.is_grad_enabled() else "image"
+        return "image"
 
     def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None):
         """The per-frame geometry.  On a GPU: two kernel launches into the planner's buffers, no

@@ -52,9 +52,10 @@ def test_camera_runs_and_row_order_policy():
     assert enc.sca_row_order == "auto"
     with torch.no_grad():
         assert enc.row_order() == "image"
+    assert enc.row_order() == "image"          # under autograd too (the LDS-sort backward likes coherent rows)
+    enc.sca_row_order = "raster"
     assert enc.row_order() == "raster"
     enc.sca_row_order = "image"
-    assert enc.row_order() == "image"
     q, f, kw = S.make_inputs("micro", seed=0)
     with torch.no_grad():
         plan = enc.frame_plan(kw["bev_h"], kw["bev_w"], 1, kw["img_metas"], torch.device("cpu"), torch.float32)

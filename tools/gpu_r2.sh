@@ -24,6 +24,6 @@ for s in $steps; do
     trace) PMC=0 timeout 400 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; head -40 "$out/prof_summary.txt" | cut -c1-170;;
     prof) PMC=1 timeout 1200 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; tail -30 "$out/prof_summary.txt" | cut -c1-170;;
     trace_bwd) PMC=0 timeout 400 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --backward --steps 2 --warmup 1 --windows 1 > "$out/prof_bwd_summary.txt" 2>&1; head -40 "$out/prof_bwd_summary.txt" | cut -c1-170;;
-    kb*) timeout 600 python tools/kbench2.py ${s#kb} > "$out/$s.log" 2>&1; tail -30 "$out/$s.log";;
+    kb*) timeout 600 python tools/kbench2.py > "$out/$s.log" 2>&1; tail -30 "$out/$s.log";;
   esac
 done
