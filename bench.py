@@ -409,14 +409,28 @@ def main():
         tr = tr.to(dev)
         mlvl, bq, tkw = S.make_transformer_inputs(args.workload, seed=0, temporal=False, device=dev)
         tkw.pop("prev_bev")
+        # one scene of `queue` frames with ABSOLUTE can-bus poses: the history driver
+        # (bevformer_amd.history.BevHistory = detectors/bevformer.py:236-269) turns them into deltas
+        from bevformer_amd.history import BevHistory
+        import copy as _copy
+        hist = BevHistory()
+        queue_metas = []
+        for i in range(args.queue):
+            m = _copy.deepcopy(tkw["img_metas"])
+            m[0]["scene_token"] = "bench-scene"
+            m[0]["can_bus"][:3] = np.array([2.0 * (i + 1), 0.5 * (i + 1), 0.0])
+            m[0]["can_bus"][-1] = 4.0 * (i + 1)
+            queue_metas.append(m)
+        tkw_rest = {k: v for k, v in tkw.items() if k != "img_metas"}
 
     def step():
-        if args.queue > 0:      # frame i's BEV is frame i+1's history; frame 0 has none
-            with torch.no_grad():
-                prev = None
-                for _ in range(args.queue):
-                    prev = tr.get_bev_features(mlvl, bq, prev_bev=prev, **tkw)
-            return prev
+        if args.queue > 0:      # frame i's BEV is frame i+1's history; frame 0 opens a scene
+            hist.reset()
+            out_q = None
+            for i in range(args.queue):
+                out_q = hist.step(lambda f, m, p: tr.get_bev_features(f, bq, prev_bev=p, img_metas=m, **tkw_rest),
+                                  mlvl, queue_metas[i])
+            return out_q
         return cfg.encoder_step()
 
     def fence():

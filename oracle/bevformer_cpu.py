@@ -469,3 +469,48 @@ def detection_decoder(layer_fns, query, reference_points, reg_branches=None,
     if return_intermediate:
         return torch.stack(inter), torch.stack(inter_ref)
     return output, reference_points
+
+
+# ---------------------------------------------------------------------------------------------
+# History-BEV queue (detector level): detectors/bevformer.py:158-177 and :236-269
+# ---------------------------------------------------------------------------------------------
+def obtain_history_bev(bev_fn, feats_queue, img_metas_list):
+    """``BEVFormer.obtain_history_bev`` (detectors/bevformer.py:158-177) with the head call
+    ``self.pts_bbox_head(img_feats, img_metas, prev_bev, only_bev=True)`` (:175-176) abstracted as
+    ``bev_fn``: frames in order, no gradients, scene reset on ``prev_bev_exists`` (:171-172)."""
+    import torch
+    with torch.no_grad():
+        prev_bev = None
+        len_queue = feats_queue[0].shape[1]
+        for i in range(len_queue):
+            img_metas = [each[i] for each in img_metas_list]
+            if not img_metas[0]["prev_bev_exists"]:
+                prev_bev = None
+            img_feats = [each_scale[:, i] for each_scale in feats_queue]
+            prev_bev = bev_fn(img_feats, img_metas, prev_bev)
+        return prev_bev
+
+
+def forward_test_step(prev_frame_info, bev_fn, mlvl_feats, img_metas, video_test_mode=True):
+    """The state update of ``BEVFormer.forward_test`` (detectors/bevformer.py:236-269) around
+    ``simple_test`` (abstracted as ``bev_fn``); like the reference it rewrites
+    ``img_metas[0]['can_bus']`` IN PLACE and mutates ``prev_frame_info``.  Returns the new BEV."""
+    import copy
+    if img_metas[0]["scene_token"] != prev_frame_info["scene_token"]:
+        prev_frame_info["prev_bev"] = None
+    prev_frame_info["scene_token"] = img_metas[0]["scene_token"]
+    if not video_test_mode:
+        prev_frame_info["prev_bev"] = None
+    tmp_pos = copy.deepcopy(img_metas[0]["can_bus"][:3])
+    tmp_angle = copy.deepcopy(img_metas[0]["can_bus"][-1])
+    if prev_frame_info["prev_bev"] is not None:
+        img_metas[0]["can_bus"][:3] -= prev_frame_info["prev_pos"]
+        img_metas[0]["can_bus"][-1] -= prev_frame_info["prev_angle"]
+    else:
+        img_metas[0]["can_bus"][-1] = 0
+        img_metas[0]["can_bus"][:3] = 0
+    new_prev_bev = bev_fn(mlvl_feats, img_metas, prev_frame_info["prev_bev"])
+    prev_frame_info["prev_pos"] = tmp_pos
+    prev_frame_info["prev_angle"] = tmp_angle
+    prev_frame_info["prev_bev"] = new_prev_bev
+    return new_prev_bev

@@ -81,3 +81,87 @@ def test_reference_function_calls_our_ext_shape():
     out = ns.MultiScaleDeformableAttnFunction_fp32.apply(value, sh, start, loc, attn, 64)
     out.sum().backward()
     assert calls == [("fwd", 5, ["im2col_step"]), ("bwd", 9, ["im2col_step"])]
+
+
+def _reference_detector_methods():
+    """``obtain_history_bev`` and ``forward_test`` of the reference detector as FREE functions: the
+    detector module itself cannot be imported here (it subclasses mmdet3d's MVXTwoStageDetector),
+    so the two method bodies are lifted out of the reference file with ``ast`` and compiled
+    unmodified; ``self`` is a stand-in object."""
+    import ast
+    import copy
+    src = open("/root/reference/projects/mmdet3d_plugin/bevformer/detectors/bevformer.py").read()
+    tree = ast.parse(src)
+    fns = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("obtain_history_bev", "forward_test"):
+            node.decorator_list = []
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = {"torch": torch, "copy": copy}
+            exec(compile(mod, "<reference detector>", "exec"), ns)
+            fns[node.name] = ns[node.name]
+    return fns
+
+
+class _FakeDetector:
+    """What the two reference methods touch on ``self``."""
+
+    def __init__(self, bev_fn, feats_by_frame):
+        self.bev_fn, self.feats_by_frame = bev_fn, feats_by_frame
+        self.prev_frame_info = {"prev_bev": None, "scene_token": None, "prev_pos": 0, "prev_angle": 0}
+        self.video_test_mode = True
+        self.calls = []
+
+    def eval(self):
+        pass
+
+    def train(self):
+        pass
+
+    def extract_feat(self, img=None, len_queue=None, img_metas=None):
+        return self.feats_by_frame           # per level (bs, len_queue, Nc, C, h, w)
+
+    def pts_bbox_head(self, img_feats, img_metas, prev_bev, only_bev=False):
+        self.calls.append(copy_metas(img_metas))
+        return self.bev_fn(img_feats, img_metas, prev_bev)
+
+    def simple_test(self, img_metas, img, prev_bev=None, **kw):
+        self.calls.append(copy_metas(img_metas))
+        return self.bev_fn(img, img_metas, prev_bev), [dict()]
+
+
+def copy_metas(m):
+    import copy
+    return copy.deepcopy(m)
+
+
+def test_history_queue_restatement_against_the_reference_detector_code():
+    """oracle.obtain_history_bev / oracle.forward_test_step == the reference's own method bodies
+    (detectors/bevformer.py:158-177, :236-269) on the same frames, BEV function and poses."""
+    from test_history_cpu import _video
+    fns = _reference_detector_methods()
+    frames = _video("micro", 4, scene_break=2)
+
+    def bev_fn(feats, metas, prev):           # any deterministic function of its inputs
+        v = feats[0].float().mean() + float(metas[0]["can_bus"][0]) + 10.0 * float(metas[0]["can_bus"][-1])
+        return (v + (0.0 if prev is None else 0.5 * prev.sum())).reshape(1, 1, 1)
+
+    # test-time state machine
+    det = _FakeDetector(bev_fn, None)
+    info = {"prev_bev": None, "scene_token": None, "prev_pos": 0, "prev_angle": 0}
+    for mlvl, metas, _, _ in frames:
+        a, b = copy_metas(metas), copy_metas(metas)
+        fns["forward_test"](det, [a], img=[mlvl])
+        want = det.prev_frame_info["prev_bev"]
+        got = O.forward_test_step(info, bev_fn, mlvl, b)
+        assert torch.equal(got, want)
+        assert (a[0]["can_bus"] == b[0]["can_bus"]).all()
+        assert (det.prev_frame_info["prev_pos"] == info["prev_pos"]).all()
+    # training-time queue
+    feats_queue = [torch.stack([f[0][lvl] for f in frames], 1) for lvl in range(len(frames[0][0]))]
+    metas_list = [{i: f[1][0] for i, f in enumerate(frames)}]
+    det = _FakeDetector(bev_fn, feats_queue)
+    imgs_queue = torch.zeros(1, len(frames), 6, 3, 4, 4)
+    want = fns["obtain_history_bev"](det, imgs_queue, copy_metas(metas_list))
+    got = O.obtain_history_bev(bev_fn, feats_queue, copy_metas(metas_list))
+    assert torch.equal(got, want)
