@@ -6,9 +6,10 @@ from .decoder import CustomMSDeformableAttention, DetectionTransformerDecoder
 from .encoder import BEVFormerEncoder, BEVFormerLayer
 from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
 from .temporal_self_attention import TemporalSelfAttention
-from .transformer import PerceptionTransformer, PerceptionTransformerBEVEncoder
+from .transformer import (PerceptionTransformer, PerceptionTransformerBEVEncoder, PerceptionTransformerV2,
+                          ResNetFusion)
 
 __all__ = ["BEVFormerEncoder", "BEVFormerLayer", "SpatialCrossAttention",
            "MSDeformableAttention3D", "TemporalSelfAttention", "MyCustomBaseTransformerLayer",
-           "FFN", "PerceptionTransformer", "PerceptionTransformerBEVEncoder", "CustomMSDeformableAttention",
+           "FFN", "PerceptionTransformer", "PerceptionTransformerBEVEncoder", "PerceptionTransformerV2", "ResNetFusion", "CustomMSDeformableAttention",
            "DetectionTransformerDecoder"]

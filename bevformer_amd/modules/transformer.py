@@ -21,6 +21,7 @@ reference plugin imported that is its ``DetectionTransformerDecoder``).
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.utils.checkpoint
 
 from .. import ops
 from ..registry import (TRANSFORMER, BaseModule, auto_fp16, build_transformer_layer_sequence,
@@ -221,3 +222,149 @@ class PerceptionTransformerBEVEncoder(BaseModule):
                 prev_bev = torch.nn.functional.grid_sample(prev_bev, grid_shift, align_corners=False)
             prev_bev = prev_bev.reshape(bs, -1, bev_h * bev_w).permute(0, 2, 1)
         return prev_bev
+
+
+class _BasicBlock(nn.Module):
+    """mmdet's ResNet ``BasicBlock`` (third party; used as it is when mmdet is installed): conv3x3 - BN -
+    ReLU - conv3x3 - BN, + identity / ``downsample``, ReLU.  Parameter names as in mmdet
+    (``conv1, bn1, conv2, bn2, downsample.{0,1}``) so that BEVFormerV2 checkpoints load."""
+
+    def __init__(self, inplanes, planes, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+def _basic_block(inplanes, planes, downsample=None):
+    try:                                            # the real one when mmdet is there
+        from mmdet.models.backbones.resnet import BasicBlock
+        return BasicBlock(inplanes, planes, stride=1, norm_cfg=dict(type="BN"), downsample=downsample)
+    except ImportError:
+        return _BasicBlock(inplanes, planes, downsample)
+
+
+class ResNetFusion(BaseModule):
+    """Temporal fusion of BEVFormerV2 (modules/transformerV2.py:16-52): the BEV maps of the frames are
+    concatenated along channels, passed through ``num_layer`` ResNet basic blocks (3 x 3 convolutions
+    over the BEV grid: MIOpen) and projected back to ``out_channels`` by Linear + LayerNorm.  Batch
+    norm here is plain ``BatchNorm2d`` (the reference asks for SyncBN: same inference arithmetic)."""
+
+    def __init__(self, in_channels, out_channels, inter_channels, num_layer, norm_cfg=dict(type="SyncBN"),
+                 with_cp=False):
+        super().__init__()
+        layers = []
+        self.inter_channels = inter_channels
+        for i in range(num_layer):
+            if i == 0 and inter_channels != in_channels:
+                downsample = nn.Sequential(nn.Conv2d(in_channels, inter_channels, 3, stride=1, padding=1, bias=False),
+                                           nn.BatchNorm2d(inter_channels))
+                layers.append(_basic_block(in_channels, inter_channels, downsample))
+            else:
+                layers.append(_basic_block(in_channels if i == 0 else inter_channels, inter_channels))
+        self.layers = nn.Sequential(*layers)
+        self.layer_norm = nn.Sequential(nn.Linear(inter_channels, out_channels), nn.LayerNorm(out_channels))
+        self.with_cp = with_cp
+
+    def forward(self, x):
+        """x: list of (bs, C, bev_h, bev_w) -> (bs, bev_h * bev_w, out_channels)."""
+        x = torch.cat(x, 1).contiguous()
+        for layer in self.layers:
+            if self.with_cp and x.requires_grad:
+                x = torch.utils.checkpoint.checkpoint(layer, x)
+            else:
+                x = layer(x)
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        lin, norm = self.layer_norm[0], self.layer_norm[1]
+        y = ops.linear_or_torch(x, lin.weight, lin.bias, tag="fusion_proj")
+        out = ops.add_layernorm(y, None, norm.weight, norm.bias, norm.eps) \
+            if not torch.is_grad_enabled() else None
+        return out if out is not None else norm(y)
+
+
+@TRANSFORMER.register_module(force=True)
+class PerceptionTransformerV2(PerceptionTransformerBEVEncoder):
+    """BEVFormerV2's transformer (modules/transformerV2.py:177-353): the BEV encoder client above, an
+    optional ``ResNetFusion`` over the BEV maps of ``frames`` and the detection decoder."""
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300, encoder=None,
+                 embed_dims=256, use_cams_embeds=True, rotate_center=[100, 100], frames=(0,), decoder=None,
+                 num_fusion=3, inter_channels=None, **kwargs):
+        super().__init__(num_feature_levels, num_cams, two_stage_num_proposals, encoder, embed_dims,
+                         use_cams_embeds, rotate_center, **kwargs)
+        self.decoder = build_transformer_layer_sequence(decoder) if decoder is not None else None
+        self.reference_points = nn.Linear(self.embed_dims, 3)
+        self.frames = frames
+        if len(self.frames) > 1:
+            self.fusion = ResNetFusion(len(self.frames) * self.embed_dims, self.embed_dims,
+                                       inter_channels if inter_channels is not None
+                                       else len(self.frames) * self.embed_dims, num_fusion)
+
+    def init_weights(self):
+        super().init_weights()
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (MSDeformableAttention3D, TemporalSelfAttention)) \
+                    or type(m).__name__ == "CustomMSDeformableAttention":
+                try:
+                    m.init_weight()
+                except AttributeError:
+                    m.init_weights()
+        nn.init.xavier_uniform_(self.reference_points.weight)
+        nn.init.constant_(self.reference_points.bias, 0.0)
+
+    def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512], bev_pos=None,
+                         prev_bev=None, **kwargs):
+        return PerceptionTransformerBEVEncoder.forward(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length,
+                                                       bev_pos, prev_bev, **kwargs)
+
+    def fuse_frames(self, bev_embed, prev_bev, bev_h, bev_w):
+        """transformerV2.py:296-313: slot of frame 0 takes the current BEV, missing earlier frames copy
+        their successor and missing later frames their predecessor (detached), then ``fusion``."""
+        cur_ind = list(self.frames).index(0)
+        assert prev_bev[cur_ind] is None and len(prev_bev) == len(self.frames)
+        prev_bev[cur_ind] = bev_embed
+        for i in range(1, cur_ind + 1):
+            if prev_bev[cur_ind - i] is None:
+                prev_bev[cur_ind - i] = prev_bev[cur_ind - i + 1].detach()
+        for i in range(cur_ind + 1, len(self.frames)):
+            if prev_bev[i] is None:
+                prev_bev[i] = prev_bev[i - 1].detach()
+        maps = [x.reshape(x.shape[0], bev_h, bev_w, x.shape[-1]).permute(0, 3, 1, 2).contiguous() for x in prev_bev]
+        return self.fusion(maps)
+
+    def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w, grid_length=[0.512, 0.512],
+                bev_pos=None, reg_branches=None, cls_branches=None, prev_bev=None, **kwargs):
+        """-> (bev_embed (Q, bs, C), inter_states, init_reference_out, inter_references_out)."""
+        if self.decoder is None:
+            raise RuntimeError("PerceptionTransformerV2.forward needs a decoder (built from the `decoder` config)")
+        bev_embed = self.get_bev_features(mlvl_feats, bev_queries, bev_h, bev_w, grid_length=grid_length,
+                                          bev_pos=bev_pos, prev_bev=None, **kwargs)
+        if len(self.frames) > 1:
+            bev_embed = self.fuse_frames(bev_embed, prev_bev, bev_h, bev_w)
+        bs = mlvl_feats[0].size(0)
+        query_pos, query = torch.split(object_query_embed, self.embed_dims, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+        query = query.permute(1, 0, 2)
+        query_pos = query_pos.permute(1, 0, 2)
+        bev_embed = bev_embed.permute(1, 0, 2)
+        inter_states, inter_references = self.decoder(
+            query=query, key=None, value=bev_embed, query_pos=query_pos, reference_points=reference_points,
+            reg_branches=reg_branches, cls_branches=cls_branches,
+            spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
+            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+        return bev_embed, inter_states, init_reference_out, inter_references

@@ -285,9 +285,43 @@ def install(ext_module=None):
     # transformerV2.py imports mmdet's ResNet blocks and mmcv's conv builder for ResNetFusion
     # (not on the encoder's path): import targets only
     mod("mmdet.models.backbones", __path__=[])
+    class BasicBlock(nn.Module):
+        """mmdet 2.14 ``mmdet.models.backbones.resnet.BasicBlock`` restated [third party, not on
+        disk: unpinned]: conv3x3 - norm - ReLU - conv3x3 - norm, + identity (or ``downsample``),
+        ReLU; attribute names ``conv1 / bn1 / conv2 / bn2 / downsample`` as in mmdet (its
+        ``norm1_name`` is ``bn1`` for BN-type configs)."""
+
+        def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch",
+                     with_cp=False, conv_cfg=None, norm_cfg=dict(type="BN"), dcn=None, plugins=None,
+                     init_cfg=None):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
+                                   bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = downsample
+
+        def forward(self, x):
+            identity = x
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            if self.downsample is not None:
+                identity = self.downsample(x)
+            return self.relu(out + identity)
+
     mod("mmdet.models.backbones.resnet", Bottleneck=type("Bottleneck", (nn.Module,), {}),
-        BasicBlock=type("BasicBlock", (nn.Module,), {}))
-    sys.modules["mmcv.cnn"].build_conv_layer = lambda *a, **k: None
+        BasicBlock=BasicBlock)
+    # mmcv's build_conv_layer(None, ...) = nn.Conv2d; build_norm_layer for BN / SyncBN = BatchNorm2d
+    sys.modules["mmcv.cnn"].build_conv_layer = lambda cfg, *a, **k: nn.Conv2d(*a, **k)
+    _ln_builder = sys.modules["mmcv.cnn"].build_norm_layer
+
+    def _norm_builder(cfg, num_features, postfix=""):
+        if cfg is not None and cfg.get("type") in ("BN", "SyncBN", "BN2d"):
+            return "bn" + str(postfix), nn.BatchNorm2d(num_features)
+        return _ln_builder(cfg, num_features, postfix) if postfix != "" else _ln_builder(cfg, num_features)
+    sys.modules["mmcv.cnn"].build_norm_layer = _norm_builder
     @regs["TRANSFORMER_LAYER_SEQUENCE"].register_module()
     class NullDecoder(_BaseModule):
         """Placeholder for ``decoder=dict(type='NullDecoder')``: get_bev_features never
@@ -381,6 +415,15 @@ def build_reference_bev_encoder_v2(encoder_cfg, ext_module=None, **kwargs):
         mod = importlib.import_module("projects.mmdet3d_plugin.bevformer.modules.transformerV2")
         t = mod.PerceptionTransformerBEVEncoder(encoder=copy.deepcopy(encoder_cfg), **kwargs)
     return t.eval()
+
+
+def load_reference_transformer_v2(ext_module=None):
+    """The reference's modules/transformerV2.py (unmodified) as a module: ``ResNetFusion``,
+    ``PerceptionTransformerV2``."""
+    load_reference(ext_module)
+    with warnings.catch_warnings(), _absent_third_party():
+        warnings.simplefilter("ignore")
+        return importlib.import_module("projects.mmdet3d_plugin.bevformer.modules.transformerV2")
 
 
 def load_reference_decoder(ext_module=None):

@@ -144,3 +144,67 @@ def test_v2_bev_encoder_matches_reference_file(aug):
         with oracle_ops():
             got = mine(mlvl, bq, kw["bev_h"], kw["bev_w"], **args)
     torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("inter", [None, 128])
+def test_resnet_fusion_matches_reference_file(inter):
+    """ResNetFusion (modules/transformerV2.py:16-52) from the reference's own file — with mmdet's
+    BasicBlock restated in the stub (third party, unpinned) — against the product class: same
+    parameter names, same output."""
+    from bevformer_amd.modules import ResNetFusion
+    v2 = mmcv_stub.load_reference_transformer_v2()
+    torch.manual_seed(0)
+    inc, outc = 2 * 64, 64
+    ref = v2.ResNetFusion(inc, outc, inter if inter is not None else inc, 2, norm_cfg=dict(type="BN")).eval()
+    mine = ResNetFusion(inc, outc, inter if inter is not None else inc, 2).eval()
+    sd = ref.state_dict()
+    for k, v in sd.items():                       # non-trivial BN statistics
+        if k.endswith("running_var"):
+            v.uniform_(0.5, 1.5)
+        elif k.endswith("running_mean"):
+            v.normal_(0, 0.2)
+    assert sorted(mine.state_dict()) == sorted(sd)
+    mine.load_state_dict(sd)
+    x = [torch.randn(2, 64, 6, 5), torch.randn(2, 64, 6, 5)]
+    with torch.no_grad():
+        torch.testing.assert_close(mine(x), ref(x), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.reference
+def test_transformer_v2_frame_filling_matches_reference_file():
+    """PerceptionTransformerV2.forward up to the decoder (transformerV2.py:284-313): current BEV in
+    the slot of frame 0, missing neighbours filled from their successor / predecessor, fusion."""
+    import bevformer_amd
+    v2 = mmcv_stub.load_reference_transformer_v2()
+    cfg = S.transformer_cfg("micro")
+    kw = dict(num_feature_levels=cfg["num_feature_levels"], encoder=cfg["encoder"], frames=(-1, 0, 1), num_fusion=1,
+              inter_channels=64)
+    torch.manual_seed(1)
+    mine = bevformer_amd.build_transformer(dict(type="PerceptionTransformerV2", **kw)).eval()
+    mine.init_weights()
+    ref = v2.PerceptionTransformerV2(decoder=dict(type="NullDecoder"), **kw).eval()
+    sd = {k: v for k, v in mine.state_dict().items()}
+    assert sorted(k for k in ref.state_dict()) == sorted(sd)
+    ref.load_state_dict(sd)
+    mlvl, bq, tkw = S.make_transformer_inputs("micro", seed=4, bs=1)
+    h, w = tkw["bev_h"], tkw["bev_w"]
+    args = dict(grid_length=tkw["grid_length"], bev_pos=tkw["bev_pos"], img_metas=tkw["img_metas"])
+    later = torch.randn(1, h * w, 256)
+    with torch.no_grad():
+        with oracle_ops():
+            bev = mine.get_bev_features(mlvl, bq, h, w, **args)
+            got = mine.fuse_frames(bev, [None, None, later.clone()], h, w)
+        bev_r = ref.get_bev_features(mlvl, bq, h, w, **args)
+        # the reference's forward body between get_bev_features and the decoder, lines 296-313
+        prev = [None, None, later.clone()]
+        cur = list(ref.frames).index(0)
+        prev[cur] = bev_r
+        for i in range(1, cur + 1):
+            if prev[cur - i] is None:
+                prev[cur - i] = prev[cur - i + 1].detach()
+        for i in range(cur + 1, len(ref.frames)):
+            if prev[i] is None:
+                prev[i] = prev[i - 1].detach()
+        want = ref.fusion([x.reshape(x.shape[0], h, w, x.shape[-1]).permute(0, 3, 1, 2).contiguous() for x in prev])
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
