@@ -43,6 +43,12 @@ class LinearDesc(ctypes.Structure):
                 ("out_bf16", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
+class LayerNormDesc(ctypes.Structure):
+    """Mirror of ``struct bevmsda_layernorm_desc``."""
+    _fields_ = [("res", ctypes.c_void_p), ("ldres", ctypes.c_int64), ("gamma", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("reserved", ctypes.c_int32 * 3)]
+
+
 class PlanDesc(ctypes.Structure):
     """Mirror of ``struct bevmsda_plan_desc``."""
     _fields_ = [("B", ctypes.c_int32), ("Nc", ctypes.c_int32), ("Q", ctypes.c_int32),
@@ -94,6 +100,8 @@ SIGNATURES = {
                                   _c_int),
     "bevmsda_linear_gather_packed_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
+    "bevmsda_linear_layernorm_packed_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
+                                                             _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                        _c_int),

@@ -2,11 +2,13 @@
 // launches of the MFMA projection kernel (linear_mfma.h).  No torch, no allocation, no global state.
 #include "../../include/bevmsda.h"
 #include "linear_mfma.h"
+#include "linear_dma.h"
 
 namespace {
 // projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
+constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 }  // namespace
 
@@ -14,7 +16,8 @@ extern "C" {
 
 static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
                          const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
-                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr) {
+                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr,
+                         const bevmsda_layernorm_desc *ln = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -39,6 +42,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
   a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
   a.gidx = gidx; a.gscale = gscale;
+  a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
   a.out_bf16 = d->out_bf16 ? 1 : 0;
@@ -51,6 +55,51 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
   //   bit 5: fragments-first schedule (copy mode 3, 128-column tiles): see linear_mfma.h FRAGS
   //   bit 6: 64-row block tiles, 5 blocks / CU (copy mode 3, 128-column tiles): see linear_mfma.h BM
+  if (ln) {
+    // y = LayerNorm(A W^T + bias + res): 128 x 256 tiles (whole rows per workgroup), packed weights
+    if (d->N != 256 || !wpack || gcols != 0 || d->relu || d->out_bf16 || d->ldy % 4 != 0 || d->variant != 0)
+      return BEVMSDA_ERR_UNSUPPORTED;
+    if (!ln->gamma || !ln->beta) return BEVMSDA_ERR_NULL_POINTER;
+    if (misaligned(ln->gamma) || misaligned(ln->beta) || misaligned(y) || (bias && misaligned(bias)) ||
+        (ln->res && (misaligned(ln->res) || ln->ldres % 4 != 0 || ln->ldres < d->N)))
+      return BEVMSDA_ERR_MISALIGNED;
+    a.res = ln->res; a.ldres = ln->ldres; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
+    // 64-row tiles (four wavefronts side by side, 64 columns each): twice the workgroups of the 128-row
+    // form — M = 40 k rows give 625 of them, which fills the chip; desc->reserved[0] = 1 selects 128 rows
+    const int bm = d->reserved[0] == 1 ? 128 : 64;
+    const long long nbm = (d->M + bm - 1) / bm;
+    if (nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+    a.nblk_m = static_cast<int>(nbm);
+    a.nblk_n = 1;
+    const dim3 g(static_cast<unsigned>(((nbm + 7) / 8) * 8)), b(256);
+#define BEVMSDA_LNK(NP_, BM_)                                                                                               \
+  do {                                                                                                                      \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, true, 3, 256, false, BM_, true>), g, b, 0, st, a);  \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, true, 3, 256, false, BM_, true>), g, b, 0, st, a);     \
+  } while (0)
+    if (d->precision == 0) { if (bm == 64) BEVMSDA_LNK(3, 64); else BEVMSDA_LNK(3, 128); }
+    else { if (bm == 64) BEVMSDA_LNK(1, 64); else BEVMSDA_LNK(1, 128); }
+#undef BEVMSDA_LNK
+    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  }
+  // second kernel (linear_dma.h): activations by LDS-DMA.  Default for the calls it covers — packed weights, no
+  // addends / gather, float4-epilogue conditions — unless desc->variant picks a variant of the first kernel;
+  // desc->variant = 129 forces it (BEVMSDA_ERR_UNSUPPORTED when not covered), desc->reserved[1] = 1 disables it
+  {
+    const bool covered = wpack && !add && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
+                         (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
+    if (d->variant == 129 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
+    if (covered && (d->variant == 129 || (d->variant == 0 && d->reserved[1] == 0 && kLinearDmaDefault))) {
+      const long long nbm = (d->M + 127) / 128, nbn = (d->N + 127) / 128;
+      const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+      if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+      a.nblk_m = static_cast<int>(nbm);
+      a.nblk_n = static_cast<int>(nbn);
+      if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_dma_kernel<3>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((bevmsda::linear_dma_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
+      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+    }
+  }
   int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
   // 256-column tiles (2 blocks / CU) and the fragments-first schedule (3 blocks / CU) stay opt-in: both
   // measured within noise of, or behind, the 4-blocks-per-CU default on every layer shape (r1j / r1l
@@ -143,6 +192,17 @@ int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const i
   bevmsda_linear_desc dd = *d;
   dd.ldx0 = ld_rows;
   return linear_launch(rows, nullptr, nullptr, nullptr, nullptr, wpack, bias, &dd, y, stream, idx, scale);
+}
+
+int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                                        const int32_t *idx, const float *scale, const uint16_t *wpack,
+                                        const float *bias, const bevmsda_linear_desc *d,
+                                        const bevmsda_layernorm_desc *ln, float *y, void *stream) {
+  if (!d || !ln) return BEVMSDA_ERR_NULL_POINTER;
+  if (!wpack) return BEVMSDA_ERR_NULL_POINTER;
+  if ((idx == nullptr) != (scale == nullptr)) return BEVMSDA_ERR_NULL_POINTER;
+  if (idx && (d->K1 != 0 || a0)) return BEVMSDA_ERR_BAD_SHAPE;
+  return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream, idx, scale, ln);
 }
 
 int64_t bevmsda_linear_packed_bytes(int N, int K) {

@@ -41,7 +41,7 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Dropout(p) if p else nn.Identity()
         self.add_identity = add_identity
 
-    def _layers_inference(self, x):
+    def _layers_inference(self, x, post_norm=None, identity=None):
         """Same math as ``self.layers`` with dropout inactive: the hidden
         Linear+ReLU pairs run with the bias+ReLU epilogue of the MFMA kernel
         (``ops.linear``; hipBLASLt's ``torch._addmm_activation`` in ``native`` GEMM mode)
@@ -54,6 +54,10 @@ class FFN(BaseModule):
             h = y if y is not None else \
                 torch._addmm_activation(fc.bias, h, fc.weight.t(), use_gelu=False)
         fc = self.layers[-2]
+        if post_norm is not None:       # "+ identity" and the layer's norm in the epilogue of fc2
+            y = ops.linear_layernorm(h, fc.weight, fc.bias, identity, post_norm, tag="ffn_fc2")
+            if y is not None:
+                return ops.Normed(y.view(*lead, fc.out_features))
         y = ops.linear(h, fc.weight, fc.bias, tag="ffn_fc2")
         if y is None:
             y = torch.addmm(fc.bias, h, fc.weight.t())
@@ -71,9 +75,14 @@ class FFN(BaseModule):
         fc = self.layers[-2]
         return ops.linear_or_torch(h, fc.weight, fc.bias, tag="ffn_fc2")
 
-    def forward(self, x, identity=None, defer_residual=False):
+    def forward(self, x, identity=None, defer_residual=False, post_norm=None):
+        """``post_norm`` (inference): the LayerNorm that follows this step in the layer — the result is
+        then ``ops.Normed(norm(identity + ffn(x)))`` when the fused kernel covers the shape."""
         if not self.training and not torch.is_grad_enabled():
-            out = self._layers_inference(x)
+            fuse = post_norm is not None and self.add_identity
+            out = self._layers_inference(x, post_norm if fuse else None, x if identity is None else identity)
+            if isinstance(out, ops.Normed):
+                return out
         elif self._dropout_inactive() and x.is_cuda:
             out = self._layers_autograd(x)
         else:

@@ -262,6 +262,11 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             return fuse_norm and i + 1 < len(order) and order[i + 1] == "norm" \
                 and isinstance(self.norms[norm_i], torch.nn.LayerNorm)
 
+        def _post_norm(i):
+            """The LayerNorm the step at ``i`` may fold into its last projection (inference fast path)."""
+            return self.norms[norm_i] if _defer(i) else None
+
+        skip_norm = False                       # the previous step returned ops.Normed
         for i, op in enumerate(order):
             if op == "self_attn":
                 query = self.attentions[attn_i](
@@ -269,15 +274,19 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_i],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                     spatial_shapes=bev_shapes, level_start_index=bev_start,
-                    defer_residual=_defer(i), **kwargs)
+                    defer_residual=_defer(i), post_norm=_post_norm(i), **kwargs)
                 attn_i += 1
-                if isinstance(query, tuple):
+                if isinstance(query, ops.Normed):
+                    query, skip_norm = query.t, True
+                elif isinstance(query, tuple):
                     pending, query = query, None
                 else:
                     identity = query
             elif op == "norm":
                 norm = self.norms[norm_i]
-                if pending is not None:
+                if skip_norm:
+                    skip_norm = False
+                elif pending is not None:
                     branch, res = pending
                     pending = None
                     query = ops.add_layernorm(branch, res, norm.weight, norm.bias, norm.eps)
@@ -293,19 +302,24 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     reference_points_cam=reference_points_cam, mask=mask,
                     attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
                     spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                    frame_plan=frame_plan, defer_residual=_defer(i), **kwargs)
+                    frame_plan=frame_plan, defer_residual=_defer(i), post_norm=_post_norm(i), **kwargs)
                 attn_i += 1
-                if isinstance(query, tuple):
+                if isinstance(query, ops.Normed):
+                    query, skip_norm = query.t, True
+                elif isinstance(query, tuple):
                     pending, query = query, None
                 else:
                     identity = query
             elif op == "ffn":
                 ffn = self.ffns[ffn_i]
                 if _defer(i) and isinstance(ffn, FFN):
-                    query = ffn(query, identity if self.pre_norm else None, defer_residual=True)
+                    query = ffn(query, identity if self.pre_norm else None, defer_residual=True,
+                                post_norm=_post_norm(i))
                 else:
                     query = ffn(query, identity if self.pre_norm else None)
                 ffn_i += 1
-                if isinstance(query, tuple):
+                if isinstance(query, ops.Normed):
+                    query, skip_norm = query.t, True
+                elif isinstance(query, tuple):
                     pending, query = query, None
         return query

@@ -213,7 +213,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
-                projected_value=None, defer_residual=False, **kwargs):
+                projected_value=None, defer_residual=False, post_norm=None, **kwargs):
         """query (bs, Q, C); key/value (Nc, S, bs, C); reference_points_cam
         (Nc, bs, Q, Dz, 2); bev_mask (Nc, bs, Q, Dz) -> (bs, Q, C).
 
@@ -259,6 +259,13 @@ class SpatialCrossAttention(BaseModule):
                     # slots seen by more than two cameras (rare; known to the device only): fold their
                     # third.. rows into the first so the two-row gather below sums all of them
                     ops.fold_extra_rows(out_rows, frame_plan.q_rows_all, frame_plan.n_extra_dev)
+                if post_norm is not None and not (self.training and self.dropout.p > 0):
+                    # camera mean + output projection + "+ residual" + the layer's norm in one kernel
+                    fused = ops.linear_layernorm(out_rows, self.output_proj.weight, self.output_proj.bias,
+                                                 inp_residual, post_norm, gather=(frame_plan.q_rows, inv_count),
+                                                 tag="sca_output_proj")
+                    if fused is not None:
+                        return ops.Normed(fused.view(bs, Q, C))
                 # camera mean + output projection in one kernel where the GEMM kernel is in use
                 proj = ops.linear_gather_mean(out_rows, frame_plan.q_rows, inv_count,
                                               self.output_proj.weight, self.output_proj.bias,

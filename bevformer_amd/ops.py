@@ -341,7 +341,10 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
                      else None),
          "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1",
          # autograd path: forward projections on the MFMA kernel too (see _LinearFunction)
-         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "0") == "1"}
+         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "0") == "1",
+         # second projection kernel (csrc/linear_dma.h: activations by LDS-DMA, one barrier per chunk) for the
+         # calls it covers (packed weights, no addend / gather); None = library default
+         "dma": {"1": True, "0": False}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -395,6 +398,11 @@ def packed_weight(weight):
     except AttributeError:
         pass
     return blob
+
+
+def set_gemm_dma(flag):
+    """True / False: use / avoid the LDS-DMA projection kernel where it applies; None: library default."""
+    _GEMM["dma"] = flag
 
 
 def set_gemm_timer(cb):
@@ -471,6 +479,11 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
+    elif _GEMM["dma"] is not None and blob is not None:
+        if _GEMM["dma"] and a0 is None and a1 is None:
+            desc.variant = 129              # force the LDS-DMA kernel (it covers this call)
+        elif not _GEMM["dma"]:
+            desc.reserved[1] = 1            # keep the first kernel
     lib = _lib.load()
     fn = lib.bevmsda_linear_f32 if blob is None else lib.bevmsda_linear_packed_f32
     cb = _GEMM_TIMER["cb"]
@@ -531,6 +544,91 @@ def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
         return None
     _lib.check(rc, "linear_gather_mean")
     return y
+
+
+class Normed:
+    """Marks a module output to which the following "+ identity" and LayerNorm of the encoder layer
+    have already been applied (fused into the projection's epilogue)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+# Measured (profiles/r2, base frame): fused 54.6 / 62.9 / 72.4 us for tsa_output_proj / sca_output_proj /
+# ffn_fc2 against 33 + 20.6 / 38.5 + 20.6 / 51 + 20.6 us for projection + add_layernorm as two launches —
+# the epilogue's residual read and three barriers sit on a workgroup's critical path and cost what the
+# separate, 75 %-of-HBM-peak row kernel costs.  Off by default; BEVMSDA_FUSE_LN=1 turns it on.
+_LN_FUSE = {"enabled": os.environ.get("BEVMSDA_FUSE_LN", "0") == "1"}
+
+
+def set_layernorm_fusion(flag):
+    """Residual add + LayerNorm in the epilogue of the projection that precedes them (off by default:
+    no faster than projection and ``add_layernorm`` as two launches, see above)."""
+    _LN_FUSE["enabled"] = bool(flag)
+
+
+def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
+    """``LayerNorm(linear(A, weight, bias) + res)`` in one kernel (``bevmsda_linear_layernorm_packed_f32``),
+    A = ``x`` or, with ``gather = (idx (Q, 2) int32, scale (Q,))``, the camera mean of SpatialCrossAttention
+    over the rows of ``x``.  ``norm``: an ``nn.LayerNorm`` over N = 256.  Returns ``None`` when not covered
+    (then the caller runs the projection and ``add_layernorm``)."""
+    mode = _GEMM["mode"]
+    if not _LN_FUSE["enabled"] or mode == "native" or not _GEMM["pack"] or _GEMM["variant"] is not None \
+            or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None \
+            or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
+            or weight.shape[0] != 256 or tuple(norm.normalized_shape) != (256,) \
+            or not fused_wanted(x, weight, bias, res, norm.weight):
+        return None
+    K = weight.shape[1]
+    if K % 32 or x.shape[-1] != K:
+        return None
+    lead = res.shape[:-1] if res is not None else (x.shape[:-1] if gather is None else (gather[0].shape[0],))
+    x0, ldx0 = _rows2d(x, K)
+    if gather is not None:
+        idx, scale = gather
+        if idx.dim() != 2 or idx.shape[1] != 2 or idx.dtype != torch.int32:
+            return None
+        idx = idx.contiguous()
+        scale = scale.reshape(-1).float().contiguous()
+        M = idx.shape[0]
+        if scale.numel() != M:
+            return None
+    else:
+        M = x0.shape[0]
+    r2 = None
+    ldres = 0
+    if res is not None:
+        if res.dtype != torch.float32 or res.shape[-1] != 256 or res.numel() != M * 256:
+            return None
+        r2, ldres = _rows2d(res, 256)
+    w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0) \
+        else weight.contiguous()
+    blob = packed_weight(w)
+    if blob is None or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256)):
+        return None
+    y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return y.view(*lead, 256)
+    desc = _lib.LinearDesc(M=M, ldx0=ldx0, ldw=K, ldy=256, N=256, K0=K, K1=0, relu=0,
+                           precision=0 if mode == "split" else 1)
+    if os.environ.get("BEVMSDA_LN_BM") == "128":        # benchmark knob: 128-row tiles (half the workgroups)
+        desc.reserved[0] = 1
+    ln = _lib.LayerNormDesc(res=_ptr(r2) if r2 is not None else None, ldres=ldres, gamma=_ptr(norm.weight),
+                            beta=_ptr(norm.bias), eps=float(norm.eps))
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    nbytes = 4.0 * ((min(x0.shape[0], 2 * M) if gather is not None else M) * K + 256 * K + M * 256 * (2 if res is not None else 1))
+    ctx = cb(tag, 2.0 * M * 256 * K, nbytes) if cb is not None else _NoTimer()
+    with torch.cuda.device(x.device), ctx:
+        rc = lib.bevmsda_linear_layernorm_packed_f32(
+            _ptr(x0), None, None, None, _ptr(idx) if gather is not None else None,
+            _ptr(scale) if gather is not None else None, _ptr(blob), _ptr(bias.contiguous()) if bias is not None else None,
+            ctypes.byref(desc), ctypes.byref(ln), _ptr(y), torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear_layernorm")
+    return y.view(*lead, 256)
 
 
 def transposed_weight(weight):

@@ -336,6 +336,29 @@ int bevmsda_frame_plan_f32(const float *lidar2img, const float *ref_3d, const in
 int bevmsda_fold_extra_rows_f32(float *rows, int64_t ld_rows, const int32_t *q_rows, int64_t slots, int J,
                                 int C, const int32_t *n_extra, void *stream);
 
+/* The packed projection with the residual add and the LayerNorm that follow it fused into its epilogue:
+ *     y = LayerNorm(A w^T + bias + res) * gamma + beta         over the N = 256 columns of every row
+ * — `output_proj` / the FFN's second Linear, "+ identity" and `norms[i]` of an encoder layer
+ * (temporal_self_attention.py:267-272, spatial_cross_attention.py:173-175, encoder.py:376-404) in one
+ * pass.  A as in bevmsda_linear_packed_f32, or, with idx / scale given, the two-row gather of
+ * bevmsda_linear_gather_packed_f32 (then a0 / x1 must be NULL).  torch.nn.LayerNorm semantics.
+ * Requirements: N = 256, no grouping / ReLU / bf16 output, res (if not NULL), gamma, beta, y 16-byte
+ * aligned with row strides multiples of 4; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and the caller
+ * runs the projection and bevmsda_add_layernorm_f32 separately. */
+typedef struct bevmsda_layernorm_desc {
+  const float *res;      /* (M, ldres) or NULL */
+  int64_t ldres;
+  const float *gamma;    /* (N) */
+  const float *beta;     /* (N) */
+  float eps;
+  int32_t reserved[3];
+} bevmsda_layernorm_desc;
+
+int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
+                                        const int32_t *idx, const float *scale, const uint16_t *wpack,
+                                        const float *bias, const bevmsda_linear_desc *desc,
+                                        const bevmsda_layernorm_desc *ln, float *y, void *stream);
+
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *
  * bevmsda_rotate_bev_f32: dst = rotate(src) of an (H, W) grid of C-float rows (row p at

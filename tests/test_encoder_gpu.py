@@ -179,3 +179,19 @@ def test_encoder_forward_bf16_value_storage(name):
     assert (got - want).abs().max().item() < 0.1
     cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
     assert cos > 0.999, cos
+
+
+def test_encoder_forward_with_layernorm_fused_into_projections():
+    """Opt-in path (ops.set_layernorm_fusion): output_proj / fc2 + residual + LayerNorm in one kernel —
+    same encoder output within the encoder tolerance."""
+    enc, sd = build_pair("micro4", device=DEV)
+    q, f, kw = S.make_inputs("micro4", seed=0, temporal=True)
+    ops.set_layernorm_fusion(True)
+    try:
+        with torch.no_grad():
+            got = enc(q.to(DEV), f.to(DEV), f.to(DEV), **_to_dev(kw)).cpu()
+    finally:
+        ops.set_layernorm_fusion(False)
+    with torch.no_grad():
+        want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+    torch.testing.assert_close(got, want, **TOL)

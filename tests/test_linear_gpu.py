@@ -228,3 +228,111 @@ def test_linear_autograd_function_matches_torch(gemm_mode, relu):
     for got, want, what in ((x.grad, xr.grad, "dx"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
         err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
         assert err < 1e-4, f"{what}: {err:.2e}"
+
+
+@pytest.mark.parametrize("M,K", [(1000, 256), (4099, 512), (128, 256)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_linear_layernorm_fused_epilogue(M, K, with_res):
+    """``bevmsda_linear_layernorm_packed_f32``: LayerNorm(x W^T + b + res) against the fp64 statement of
+    the three torch ops; ragged last row tile, K = 256 / 512, with and without residual."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(256, K, generator=g) * K ** -0.5
+    b = torch.randn(256, generator=g) * 0.1
+    res = torch.randn(M, 256, generator=g) if with_res else None
+    norm = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(256, generator=g) * 0.2 + 1.0)
+        norm.bias.copy_(torch.randn(256, generator=g) * 0.1)
+    y64 = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if with_res:
+        y64 = y64 + res.double()
+    want = torch.nn.functional.layer_norm(y64, (256,), norm.weight.double(), norm.bias.double(), norm.eps)
+    norm = norm.to(DEV)
+    ops.set_layernorm_fusion(True)
+    try:
+        with torch.no_grad():
+            got = ops.linear_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV) if with_res else None, norm)
+    finally:
+        ops.set_layernorm_fusion(False)
+    assert got is not None and got.shape == (M, 256)
+    # (LayerNorm divides by the row's standard deviation: the split-bf16 product round-off of 4e-6 x
+    # |x||w| shows up as ~3e-5 on rows of unit-scale output)
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_linear_layernorm_with_camera_gather():
+    """The SCA form: A = scale * (rows[idx0] + rows[idx1]) gathered in the A-load, then projection +
+    residual + LayerNorm."""
+    g = torch.Generator().manual_seed(5)
+    R, Q = 700, 500
+    rows = torch.randn(R, 256, generator=g)
+    idx = torch.full((Q, 2), -1, dtype=torch.int32)
+    perm = torch.randperm(R, generator=g)
+    idx[:, 0] = perm[:Q].int()
+    idx[:200, 1] = perm[Q:Q + 200].int()
+    idx[450:, 0] = -1                                     # queries no camera sees
+    scale = 1.0 / (idx >= 0).sum(1).clamp(min=1).float()
+    w = torch.randn(256, 256, generator=g) / 16
+    b = torch.randn(256, generator=g) * 0.1
+    res = torch.randn(Q, 256, generator=g)
+    norm = torch.nn.LayerNorm(256)
+    a = torch.zeros(Q, 256, dtype=torch.float64)
+    for j in range(2):
+        ok = idx[:, j] >= 0
+        a[ok] += rows[idx[ok, j].long()].double()
+    a = a * scale[:, None].double()
+    want = torch.nn.functional.layer_norm(torch.nn.functional.linear(a, w.double(), b.double()) + res.double(), (256,),
+                                          norm.weight.double(), norm.bias.double(), norm.eps)
+    norm = norm.to(DEV)
+    ops.set_layernorm_fusion(True)
+    try:
+        with torch.no_grad():
+            got = ops.linear_layernorm(rows.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV), norm,
+                                       gather=(idx.to(DEV), scale.to(DEV)))
+    finally:
+        ops.set_layernorm_fusion(False)
+    assert got is not None
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
+    (1000, 256, 0, 256, False, 1, torch.float32), (4099, 256, 256, 192, False, 1, torch.float32),
+    (513, 256, 0, 512, True, 1, torch.float32), (2050, 256, 0, 768, False, 3, torch.float32),
+    (300, 512, 0, 256, False, 1, torch.float32), (1111, 256, 0, 256, False, 2, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_dma_kernel(M, K0, K1, N, relu, groups, out, mode):
+    """csrc/linear_dma.h (activations by LDS-DMA, swizzled fp32 image, in-register split) against the fp64
+    statement of F.linear: ragged row tiles, two K sources, ReLU, grouped output, bf16 output; and against
+    the first kernel (same arithmetic: bit-identical)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K0, generator=g)
+    x2 = torch.randn(M, K1, generator=g) if K1 else None
+    w = torch.randn(N, K0 + K1, generator=g) * (K0 + K1) ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    a64 = x.double() if x2 is None else torch.cat([x, x2], -1).double()
+    want = torch.nn.functional.linear(a64, w.double(), b.double())
+    if relu:
+        want = want.relu()
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        res = {}
+        for dma in (True, False):
+            ops.set_gemm_dma(dma)
+            with torch.no_grad():
+                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, x2=x2.to(DEV) if K1 else None, groups=groups,
+                               out_dtype=out)
+            assert y is not None
+            res[dma] = y
+    finally:
+        ops.set_gemm_dma(None)
+        ops.set_gemm_mode(saved)
+    y = res[True].float().cpu()
+    if groups > 1:
+        y = torch.cat(list(y), -1)
+    scale = (a64.abs() @ w.double().abs().t()).clamp(min=1e-6)
+    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
+    assert (((y.double() - want).abs()) / scale.max()).max().item() < tol
+    assert ((y.double() - want).abs() / scale).max().item() < tol * 40
+    assert torch.equal(res[True], res[False])
