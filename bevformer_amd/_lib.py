@@ -89,6 +89,8 @@ SIGNATURES = {
     "bevmsda_frame_plan_f32": ([_c_void_p] * 3 + [ctypes.POINTER(PlanDesc)] + [_c_void_p] * 12, _c_int),
     "bevmsda_fold_extra_rows_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int,
                                      _c_void_p, _c_void_p], _c_int),
+    "bevmsda_fused_forward_lds2_f32": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
+                                       _c_int),
     "bevmsda_fused_forward_lds_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_int, _c_int, _c_void_p,
                                                           _c_void_p], _c_int),
     "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,

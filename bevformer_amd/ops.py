@@ -154,13 +154,21 @@ def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, at
 _FUSED = {"enabled": True,
           # SCA sampling with the coarsest feature level staged in LDS (csrc/msda_d32.h,
           # msda_fused_d32_ldslevel_kernel): opt-in, BEVMSDA_SCA_LDS=1 / set_sca_lds_level(True)
-          "lds_level": os.environ.get("BEVMSDA_SCA_LDS", "0") == "1"}
+          "lds_level": os.environ.get("BEVMSDA_SCA_LDS", "0") == "1",
+          # SCA sampling with the two coarse levels of a (camera, head) patch in LDS (csrc/msda_lds2.h)
+          "lds2": os.environ.get("BEVMSDA_SCA_LDS2", "0") == "1"}
 
 
 def set_sca_lds_level(flag):
     """SpatialCrossAttention's sampling kernel with the last feature level of a (camera, head)
     staged in LDS (rows grouped by camera; fp32)."""
     _FUSED["lds_level"] = bool(flag)
+
+
+def set_sca_lds2(flag):
+    """SpatialCrossAttention's sampling kernel with levels L-2 and L-1 of a (camera, head) patch served from
+    LDS (fp32, 4 levels, rows grouped by camera)."""
+    _FUSED["lds2"] = bool(flag)
 
 
 def set_fused_front_end(flag):
@@ -246,6 +254,21 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                 return out
             if rc != _lib.ERR_UNSUPPORTED:
                 _lib.check(rc, "msda_fused forward (LDS level)")
+            ctx = cb(tag, alg) if cb is not None else _NoTimer()
+        if _FUSED["lds2"] and store == torch.float32 and K == 1 and ref_mode == 0 and L == 4 and P == 8 \
+                and row_batch is not None and vmul == 1 and vadd == 0:
+            with ctx:
+                if nrows is not None:
+                    desc.reserved[3] = int(max(0, min(launch_rows, R)))
+                rc = lib.bevmsda_fused_forward_lds2_f32(
+                    _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(), logits.data_ptr(),
+                    _ptr(ref), _ptr(row_batch), _ptr(row_src) if row_src is not None else None,
+                    nrows.data_ptr() if nrows is not None else None, ctypes.byref(desc), _ptr(out),
+                    torch.cuda.current_stream().cuda_stream)
+            if rc == 0:
+                return out
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "msda_fused forward (LDS2)")
             ctx = cb(tag, alg) if cb is not None else _NoTimer()
         with ctx:
             if nrows is not None:

@@ -199,6 +199,19 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
                                     const int32_t *nrows, const bevmsda_fused_desc *desc, uint16_t *out,
                                     void *stream);
 
+/* bevmsda_fused_forward_f32 / _rows_f32 for SpatialCrossAttention with the two COARSE feature levels of a
+ * (camera, head) patch served from LDS while the two fine levels stream through the vector-memory path
+ * (csrc/msda_lds2.h).  Rows must be grouped by value batch entry (camera).  nrows: NULL (desc->R rows), or
+ * the DEVICE row count with desc->R the capacity and desc->reserved[3] the host's hint, as for
+ * bevmsda_fused_forward_rows_f32.  Requirements: fp32, D = 32, P = 8, K = 1, L = 4, ref_mode 0, vmul = 1,
+ * vadd = 0; anything else returns BEVMSDA_ERR_UNSUPPORTED and the caller uses bevmsda_fused_forward_*.
+ * Same results up to the order in which the four level sums are added. */
+int bevmsda_fused_forward_lds2_f32(const float *value, const int64_t *spatial_shapes,
+                                   const int64_t *level_start, const float *offs, const float *logits,
+                                   const float *ref, const int32_t *row_batch, const int32_t *row_src,
+                                   const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
+                                   void *stream);
+
 /* bevmsda_fused_forward_f32 for SpatialCrossAttention with the LAST feature level staged in
  * LDS: rows must be grouped by camera (value batch entry), cam_start (N + 1) int32 holds the
  * first row of every camera's run, lds_pixels = H * W of the last level (<= 512: 64 KB of LDS

@@ -179,3 +179,52 @@ def test_small4_forward_backward_gradients(storage, modes):
         if l2 > l2_tol or mx > max_tol:
             bad[k] = (l2, mx)
     assert not bad, bad
+
+
+def test_sca_kernel_with_coarse_levels_in_lds_at_base():
+    """csrc/msda_lds2.h (levels 2 and 3 of a (camera, head) patch served from LDS, levels 0 and 1 streamed)
+    against the plain fused kernel over ALL base rows — fixed and device-side row counts, offsets of a few
+    pixels (inside the staged boxes) and wild offsets (most points leave the boxes: the spill path)."""
+    from bevformer_amd.modules import geometry as G
+    name = "base"
+    w = S.WORKLOADS[name]
+    Q = w["bev_h"] * w["bev_w"]
+    M, L, P, D = 8, 4, 8, 32
+    g = torch.Generator().manual_seed(3)
+    shapes, start = S.level_tensors(name)
+    Sv = int(shapes.prod(1).sum())
+    value = torch.randn(S.NUM_CAMS, Sv, M, D, generator=g).to(DEV)
+    n_off = M * L * P * 2
+    pl = G.DevicePlanner(w["bev_h"], w["bev_w"], 1, S.PC_RANGE, 4, S.NUM_CAMS, DEV, row_order="image")
+    plan = pl.plan(S.make_img_metas(name))
+    host = plan.materialize()
+    R = host.row_batch.numel()
+    kw = dict(M=M, L=L, P=P, K=1, off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0, vmul=1, vadd=0)
+    for scale in (4.0, 40.0):
+        proj = torch.randn(Q, M * L * P * 3, generator=g)
+        proj[:, :n_off] *= scale
+        proj = proj.to(DEV)
+        args = (value, shapes.to(DEV), start.to(DEV), proj, n_off)
+        ops.set_sca_lds2(False)
+        want = ops.msda_fused(*args, host.row_ref.reshape(-1, 1, 4, 2), host.row_batch, row_src=host.row_query32, **kw)
+        ops.set_sca_lds2(True)
+        try:
+            got = ops.msda_fused(*args, host.row_ref.reshape(-1, 1, 4, 2), host.row_batch, row_src=host.row_query32, **kw)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+            for hint in (plan.launch_rows, R // 3):
+                dyn = ops.msda_fused(*args, plan.row_ref.reshape(-1, 1, 4, 2), plan.row_batch, row_src=plan.row_query32,
+                                     nrows=plan.nrows_dev, launch_rows=hint, **kw)
+                torch.testing.assert_close(dyn[:R], want, rtol=1e-5, atol=1e-5)
+        finally:
+            ops.set_sca_lds2(False)
+
+
+@pytest.mark.parametrize("name", ["base", "micro4"])
+def test_encoder_forward_with_sca_lds2(name, modes):
+    ops.set_sca_lds2(True)
+    try:
+        got = _gpu_frame(name, True)
+    finally:
+        ops.set_sca_lds2(False)
+    want = _oracle_frame(name, True)
+    torch.testing.assert_close(got, want, **ENC_TOL)

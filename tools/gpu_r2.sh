@@ -15,6 +15,7 @@ for s in $steps; do
     bench_quick) timeout 600 python bench.py --no-cpu-baseline > "$out/bench_quick.json" 2> "$out/bench_quick.err"; echo "rc=$?" >> "$out/bench_quick.err"; tail -3 "$out/bench_quick.err"; python tools/bench_digest.py "$out/bench_quick.json";;
     bench_polar) timeout 600 python bench.py --no-cpu-baseline --no-variants --row-order polar > "$out/bench_polar.json" 2> "$out/bench_polar.err"; tail -2 "$out/bench_polar.err"; python tools/bench_digest.py "$out/bench_polar.json";;
     bench_main) timeout 600 python bench.py --no-cpu-baseline --no-variants > "$out/bench_main.json" 2> "$out/bench_main.err"; tail -2 "$out/bench_main.err"; python tools/bench_digest.py "$out/bench_main.json";;
+    bench_lds2) BEVMSDA_SCA_LDS2=1 timeout 600 python bench.py --no-cpu-baseline --no-variants > "$out/bench_lds2.json" 2> "$out/bench_lds2.err"; tail -2 "$out/bench_lds2.err"; python tools/bench_digest.py "$out/bench_lds2.json";;
     bench_static) timeout 600 python bench.py --no-cpu-baseline --no-variants --static-rig > "$out/bench_static.json" 2> "$out/bench_static.err"; tail -2 "$out/bench_static.err"; python tools/bench_digest.py "$out/bench_static.json";;
     bench_hostplans) timeout 600 python bench.py --no-cpu-baseline --no-variants --host-plans > "$out/bench_hostplans.json" 2> "$out/bench_hostplans.err"; tail -2 "$out/bench_hostplans.err"; python tools/bench_digest.py "$out/bench_hostplans.json";;
     bench_eager) timeout 600 python bench.py --no-cpu-baseline --graph off > "$out/bench_eager.json" 2> "$out/bench_eager.err"; tail -2 "$out/bench_eager.err"; python tools/bench_digest.py "$out/bench_eager.json";;
