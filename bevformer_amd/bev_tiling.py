@@ -161,6 +161,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
         hoisted = {}
         if sca_vals is not None:
             hoisted["projected_value"] = sca_vals[li]
+            if li == 0 and getattr(encoder, "_sca_ready", None) is not None:
+                hoisted["projected_value_ready"] = encoder._sca_ready      # projection issued on a side stream
         if tsa_vals is not None:
             hoisted["tsa_projected_value"] = tsa_vals[li]
         if prev_bev is None:

@@ -3,6 +3,7 @@
 #include "../../include/bevmsda.h"
 #include "linear_mfma.h"
 #include "linear_dma.h"
+#include "wgrad_mfma.h"
 
 namespace {
 // projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
@@ -203,6 +204,35 @@ int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const 
   if ((idx == nullptr) != (scale == nullptr)) return BEVMSDA_ERR_NULL_POINTER;
   if (idx && (d->K1 != 0 || a0)) return BEVMSDA_ERR_BAD_SHAPE;
   return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream, idx, scale, ln);
+}
+
+int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_t ldx, int64_t M, int N, int K,
+                             float *grad_w, int64_t ldgw, float *grad_b, int precision, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (precision != 0 && precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (N % 4 != 0 || K % 4 != 0 || ldg % 4 != 0 || ldx % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldg < N || ldx < K || ldgw < K) return BEVMSDA_ERR_BAD_SHAPE;
+  if (M == 0) return BEVMSDA_OK;
+  if (!g || !x || !grad_w) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(g) || misaligned(x) || (reinterpret_cast<uintptr_t>(grad_w) & 3u) != 0) return BEVMSDA_ERR_MISALIGNED;
+  bevmsda::WgradArgs a;
+  a.g = g; a.x = x; a.ldg = ldg; a.ldx = ldx; a.gw = grad_w; a.ldgw = ldgw; a.gb = grad_b; a.M = M; a.N = N; a.K = K;
+  a.tiles_n = (N + 127) / 128;
+  a.tiles_k = (K + 127) / 128;
+  // row slices: enough workgroups to fill the chip twice over (2 per CU resident), at least 128 rows each
+  const long long tiles = 1LL * a.tiles_n * a.tiles_k;
+  long long slices = (768 + tiles - 1) / tiles;
+  long long rows = (M + slices - 1) / slices;
+  rows = ((rows + 31) / 32) * 32;
+  if (rows < 128) rows = 128;
+  a.rows_per_block = static_cast<int>(rows);
+  slices = (M + rows - 1) / rows;
+  if (tiles * slices >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const dim3 grid(static_cast<unsigned>(tiles * slices)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<3>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<1>), grid, block, 0, st, a);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
 int64_t bevmsda_linear_packed_bytes(int N, int K) {

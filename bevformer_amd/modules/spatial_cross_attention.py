@@ -239,6 +239,9 @@ class SpatialCrossAttention(BaseModule):
             row_query, row_batch, row_ref, inv_count, _ = geometry.build_sca_rows(
                 reference_points_cam, bev_mask)
 
+        ready = kwargs.pop("projected_value_ready", None)
+        if ready is not None:           # the hoisted projection ran on a side stream: join it here
+            torch.cuda.current_stream(query.device).wait_event(ready)
         if projected_value is None:
             Nc, S, _, _ = value.shape
             feats = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, S, self.embed_dims)

@@ -670,6 +670,43 @@ def transposed_weight(weight):
     return wt
 
 
+_WGRAD = {"enabled": os.environ.get("BEVMSDA_WGRAD", "1") == "1"}
+
+
+def set_wgrad_kernel(flag):
+    """Weight / bias gradients of the Linear layers on the MFMA kernel (csrc/wgrad_mfma.h; default) or on
+    the library's TN GEMM + a column-sum reduction."""
+    _WGRAD["enabled"] = bool(flag)
+
+
+def linear_wgrad(g, x, with_bias, *, tag="linear_dw"):
+    """(grad_W (N, K), grad_b (N) or None) = (g^T x, g.sum(0)) through ``bevmsda_linear_wgrad_f32``; g (M, N),
+    x (M, K) fp32 GPU matrices.  Returns (None, None) when the call is not covered."""
+    mode = _GEMM["mode"]
+    if not _WGRAD["enabled"] or mode == "native" or not g.is_cuda or g.dtype != torch.float32 \
+            or x.dtype != torch.float32 or g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0]:
+        return None, None
+    M, N = g.shape
+    K = x.shape[1]
+    if N % 4 or K % 4 or M == 0:
+        return None, None
+    g, ldg = _rows2d(g, N)
+    x, ldx = _rows2d(x, K)
+    gw = torch.zeros((N, K), dtype=torch.float32, device=g.device)
+    gb = torch.zeros(N, dtype=torch.float32, device=g.device) if with_bias else None
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * (N + K) + N * K)) if cb is not None else _NoTimer()
+    with torch.cuda.device(g.device), ctx:
+        rc = lib.bevmsda_linear_wgrad_f32(_ptr(g), ldg, _ptr(x), ldx, M, N, K, _ptr(gw), K,
+                                          _ptr(gb) if gb is not None else None, 0 if mode == "split" else 1,
+                                          torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None, None
+    _lib.check(rc, "linear_wgrad")
+    return gw, gb
+
+
 class _LinearFunction(Function):
     """``act(x @ weight.T + bias)`` under autograd with the input gradient (``grad_y @ weight``:
     the projection kernel over the transposed weight) on the MFMA kernel; the weight gradient
@@ -717,9 +754,14 @@ class _LinearFunction(Function):
             if gx is None:
                 gx = g2 @ weight
             gx = gx.view(x.shape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = g2.t() @ x.reshape(-1, K)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw, gb_k = linear_wgrad(g2, x.reshape(-1, K), want_b, tag=ctx.tag + "_dw")
+            if gw is None:
+                gw = g2.t() @ x.reshape(-1, K)
+            elif want_b:
+                gb = gb_k
+        if want_b and gb is None:
             gb = g2.sum(0)
         return gx, gw, gb, None, None
 

@@ -372,6 +372,15 @@ int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const 
                                         const float *bias, const bevmsda_linear_desc *desc,
                                         const bevmsda_layernorm_desc *ln, float *y, void *stream);
 
+/* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
+ *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)
+ * g (M, ldg) = gradient w.r.t. the layer's output (N columns), x (M, ldx) = the layer's input (K columns).
+ * ACCUMULATES (fp32 atomics over row slices): the caller zeroes grad_w / grad_b.  precision as for
+ * bevmsda_linear_f32 (0: three bf16 MFMAs per product over split operands, 1: operands rounded to bf16).
+ * N, K, ldg, ldx multiples of 4, g / x 16-byte aligned; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED. */
+int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_t ldx, int64_t M, int N, int K,
+                             float *grad_w, int64_t ldgw, float *grad_b, int precision, void *stream);
+
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *
  * bevmsda_rotate_bev_f32: dst = rotate(src) of an (H, W) grid of C-float rows (row p at

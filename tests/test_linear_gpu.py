@@ -336,3 +336,27 @@ def test_linear_dma_kernel(M, K0, K1, N, relu, groups, out, mode):
     assert (((y.double() - want).abs()) / scale.max()).max().item() < tol
     assert ((y.double() - want).abs() / scale).max().item() < tol * 40
     assert torch.equal(res[True], res[False])
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (4099, 192, 512), (130, 768, 256), (40000, 256, 256), (33, 64, 32)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_wgrad_kernel(M, N, K, mode):
+    """csrc/wgrad_mfma.h: grad_W = g^T x and grad_b = g.sum(0) against their fp64 statements — ragged row
+    slices, N not a multiple of the 128-column tile, tiny and base-size M."""
+    g_ = torch.Generator().manual_seed(M + N + K)
+    g = torch.randn(M, N, generator=g_)
+    x = torch.randn(M, K, generator=g_)
+    want_w = g.double().t() @ x.double()
+    want_b = g.double().sum(0)
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        gw, gb = ops.linear_wgrad(g.to(DEV), x.to(DEV), True)
+    finally:
+        ops.set_gemm_mode(saved)
+    assert gw is not None and gw.shape == (N, K) and gb.shape == (N,)
+    scale = (g.double().abs().t() @ x.double().abs())
+    tol = 2.5e-5 if mode == "split" else 8e-3
+    assert ((gw.cpu().double() - want_w).abs() / scale.clamp(min=1e-9)).max().item() < tol * 40
+    assert ((gw.cpu().double() - want_w).abs().max() / scale.max()).item() < tol
+    torch.testing.assert_close(gb.cpu().double(), want_b, rtol=1e-4, atol=1e-4 * M ** 0.5)
