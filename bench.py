@@ -79,6 +79,9 @@ def parse():
                          "per-kernel HIP-event timings come from an eager pass right before)")
     ap.add_argument("--force-tiling", action="store_true",
                     help="run the multi-GPU schedule (row blocks + RCCL all-gather) even on 1 rank")
+    ap.add_argument("--simulate-rank", default=None, metavar="R,G",
+                    help="time rank R's schedule of a G-GPU BEV-tiled job on this one GPU (no process group; the "
+                         "all-gather is replaced by a local copy: bev_tiling.BevTiling.simulate)")
     ap.add_argument("--row-order", default=None, choices=["raster", "image", "polar"],
                     help="order of the ragged SCA rows inside a camera (default: the encoder's)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -255,7 +258,10 @@ class Config:
         if args.row_order:
             self.enc.sca_row_order = args.row_order
         self.enc.device_plans = not args.host_plans
-        if tiling:
+        if getattr(args, "simulate_rank", None) and world == 1 and not tiling:
+            r, g = (int(v) for v in args.simulate_rank.split(","))
+            bev_tiling.enable_bev_tiling(self.enc, simulate=(r, g))
+        elif tiling:
             bev_tiling.enable_bev_tiling(self.enc)
         self.q, self.f, self.kw = S.make_inputs(workload, seed=0, temporal=not first_frame, device=dev)
         self.metas0 = self.kw["img_metas"]
@@ -338,33 +344,119 @@ def capture(step, fence):
     return graph, out
 
 
-def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, windows, want=None, tol=None):
+def make_queue_step(cfg, workload, queue, dev):
+    """One scene of ``queue`` frames through ``get_bev_features`` with a rolling history BEV (frame i's BEV is
+    frame i + 1's history; frame 0 opens the scene): BASELINE configs[4]'s history queue on one GPU.  The
+    history driver (bevformer_amd.history.BevHistory = detectors/bevformer.py:236-269) turns ABSOLUTE can-bus
+    poses into deltas."""
+    import copy as _copy
+    import bevformer_amd
+    from bevformer_amd import synthetic as S
+    from bevformer_amd.history import BevHistory
+    tr = bevformer_amd.build_transformer(S.transformer_cfg(workload)).eval()
+    tr.init_weights()
+    tr.encoder = cfg.enc                   # the encoder of `cfg` (trained-like weights, tiling if enabled)
+    tr = tr.to(dev)
+    mlvl, bq, tkw = S.make_transformer_inputs(workload, seed=0, temporal=False, device=dev)
+    tkw.pop("prev_bev")
+    hist = BevHistory()
+    queue_metas = []
+    for i in range(queue):
+        m = _copy.deepcopy(tkw["img_metas"])
+        m[0]["scene_token"] = "bench-scene"
+        m[0]["can_bus"][:3] = np.array([2.0 * (i + 1), 0.5 * (i + 1), 0.0])
+        m[0]["can_bus"][-1] = 4.0 * (i + 1)
+        queue_metas.append(m)
+    tkw_rest = {k: v for k, v in tkw.items() if k != "img_metas"}
+
+    def step():
+        hist.reset()
+        out_q = None
+        with torch.no_grad():
+            for i in range(queue):
+                out_q = hist.step(lambda f, m, p: tr.get_bev_features(f, bq, prev_bev=p, img_metas=m, **tkw_rest),
+                                  mlvl, queue_metas[i])
+        return out_q
+
+    return step
+
+
+def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, windows, want=None, tol=None, queue=0):
     """A secondary configuration on the same line: ms per step (graph replay for forward, eager
-    for forward + backward), fresh geometry per step as in the main run."""
+    for forward + backward and for the history queue), fresh geometry per step as in the main run."""
     cfg = Config(args, dev, workload, gemm, storage, backward, args.first_frame, 1, False)
     cfg.modes()
+    step = make_queue_step(cfg, workload, queue, dev) if queue else cfg.encoder_step
     for _ in range(2):
-        cfg.encoder_step()
+        step()
     fence()
     graph, note = None, "eager"
-    if not backward and args.graph != "off":
+    if not backward and not queue and args.graph != "off":
         try:
-            graph, _ = capture(cfg.encoder_step, fence)
+            graph, _ = capture(step, fence)
             note = "hip graph replay"
         except Exception as e:      # noqa: BLE001
             graph, note = None, f"eager (capture failed: {type(e).__name__})"
             torch.cuda.synchronize()
-    ts = timed_windows(cfg, cfg.encoder_step, fence, steps, windows, graph)
+    ts = timed_windows(cfg, step, fence, steps, windows, graph)
     per = [t / steps * 1e3 for t in ts]
     res = dict(workload=workload, gemm=gemm, value_storage=storage, direction="fwd+bwd" if backward else "fwd",
                ms_per_step=statistics.median(per), ms_per_step_min=min(per), steps=steps, windows=windows,
-               queries_per_s=cfg.Q / (statistics.median(per) * 1e-3), launch_mode=note)
+               queries_per_s=cfg.Q * max(1, queue) / (statistics.median(per) * 1e-3), launch_mode=note)
+    if queue:
+        res["frames_per_step"] = queue
+        res["note"] = ("get_bev_features over a scene of %d frames with a rolling history BEV (can-bus MLP, shift, "
+                       "rotation of the history, encoder) per step" % queue)
     if want is not None:
         cfg.set_rig(0)
         res["parity"] = parity_report(cfg.encoder_step(), want, tol)
     del cfg, graph
     torch.cuda.empty_cache()
     return res
+
+
+def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 8)):
+    """What the BEV-tiled schedule costs per rank, measured on THIS GPU one rank at a time
+    (bev_tiling.BevTiling.simulate: every kernel of rank r's step, the all-gather replaced by a local copy),
+    plus a stated model of the all-gather.  Strong-scaling efficiency modelled from it = t1 / (G * T_G) with
+    T_G = max over ranks + all-gather.  NOT a multi-GPU measurement: one GPU per box here."""
+    from bevformer_amd import bev_tiling
+    LINK_GBS, LAT_US = 50.0, 20.0
+    cfg = Config(args, dev, "base", gemm, "fp32", False, args.first_frame, 1, False)
+    cfg.modes()
+    out = {"assumptions": {"xgmi_link_GBs_per_direction": LINK_GBS, "collective_latency_us": LAT_US,
+                           "all_gather": "direct: every rank sends its (Q/G, 256) fp32 shard to the G - 1 peers over "
+                                         "min(G - 1, 7) links in parallel"},
+           "t1_ms": t1_ms, "replicated_value_projections_us": replicated_us,
+           "status": "per-rank times measured on one GPU; collective modelled; unmeasured on multi-GPU hardware"}
+    for G in worlds:
+        per_rank = []
+        for r in range(G):
+            bev_tiling.enable_bev_tiling(cfg.enc, simulate=(r, G))
+            for _ in range(2):
+                cfg.encoder_step()
+            fence()
+            graph = None
+            if args.graph != "off":
+                try:
+                    graph, _ = capture(cfg.encoder_step, fence)
+                except Exception:      # noqa: BLE001
+                    graph = None
+                    torch.cuda.synchronize()
+            ts = timed_windows(cfg, cfg.encoder_step, fence, 10, 3, graph)
+            per_rank.append(statistics.median(ts) / 10 * 1e3)
+            del graph
+        shard = cfg.Q / G * 256 * 4
+        ag_us = LAT_US + shard * (G - 1) / (min(G - 1, 7) * LINK_GBS * 1e9) * 1e6
+        T = max(per_rank) + ag_us * 1e-3
+        out[str(G)] = dict(per_rank_ms=[round(p, 4) for p in per_rank], all_gather_model_us=ag_us, step_ms=T,
+                           queries_per_s=cfg.Q / (T * 1e-3), efficiency=t1_ms / (G * T),
+                           amdahl_bound_efficiency=t1_ms / (G * (replicated_us * 1e-3 + (t1_ms - replicated_us * 1e-3) / G))
+                           if replicated_us else None)
+    bev_tiling.disable_bev_tiling(cfg.enc)
+    del cfg
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -402,35 +494,11 @@ def main():
     ops.set_gemm_timer(timer.gemm)
     w, Q = cfg.w, cfg.Q
 
-    if args.queue > 0:
-        tr = bevformer_amd.build_transformer(S.transformer_cfg(args.workload)).eval()
-        tr.init_weights()
-        tr.encoder = cfg.enc                   # the encoder above (trained-like weights, tiling if enabled)
-        tr = tr.to(dev)
-        mlvl, bq, tkw = S.make_transformer_inputs(args.workload, seed=0, temporal=False, device=dev)
-        tkw.pop("prev_bev")
-        # one scene of `queue` frames with ABSOLUTE can-bus poses: the history driver
-        # (bevformer_amd.history.BevHistory = detectors/bevformer.py:236-269) turns them into deltas
-        from bevformer_amd.history import BevHistory
-        import copy as _copy
-        hist = BevHistory()
-        queue_metas = []
-        for i in range(args.queue):
-            m = _copy.deepcopy(tkw["img_metas"])
-            m[0]["scene_token"] = "bench-scene"
-            m[0]["can_bus"][:3] = np.array([2.0 * (i + 1), 0.5 * (i + 1), 0.0])
-            m[0]["can_bus"][-1] = 4.0 * (i + 1)
-            queue_metas.append(m)
-        tkw_rest = {k: v for k, v in tkw.items() if k != "img_metas"}
+    queue_step = make_queue_step(cfg, args.workload, args.queue, dev) if args.queue > 0 else None
 
     def step():
-        if args.queue > 0:      # frame i's BEV is frame i+1's history; frame 0 opens a scene
-            hist.reset()
-            out_q = None
-            for i in range(args.queue):
-                out_q = hist.step(lambda f, m, p: tr.get_bev_features(f, bq, prev_bev=p, img_metas=m, **tkw_rest),
-                                  mlvl, queue_metas[i])
-            return out_q
+        if queue_step is not None:
+            return queue_step()
         return cfg.encoder_step()
 
     def fence():
@@ -583,7 +651,12 @@ def main():
                 v["fwd_bwd_base"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3)
                 v["fwd_bwd_small4"] = run_variant(args, dev, fence, "small4", gemm, "fp32", True, 5, 3)
                 v["fwd_bwd_small4_bf16"] = run_variant(args, dev, fence, "small4", "bf16", "bf16", True, 5, 3)
+                v["queue4_bf16"] = run_variant(args, dev, fence, "base", "bf16", "bf16", False, 3, 3, queue=4)
                 line["variants"] = v
+                rep = None
+                if gs is not None:
+                    rep = sum(gs["per_tag"][t]["avg_us"] for t in ("sca_value_proj", "tsa_value_proj") if t in gs["per_tag"])
+                line["multi_gpu_model"] = multi_gpu_model(args, dev, fence, gemm, line["ms_per_step"], rep)
                 line["native_fp32_ms_per_step"] = v["native_fp32"]["ms_per_step"]
                 ok = ok and v["native_fp32"]["parity"]["ok"]
     else:

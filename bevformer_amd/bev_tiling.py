@@ -31,23 +31,28 @@ import torch.distributed as dist
 
 @dataclass
 class BevTiling:
+    """``simulate = (rank, world)``: run that rank's schedule of a ``world``-GPU job in ONE process without a
+    process group — every kernel of the rank's step is launched, the all-gather is replaced by the copy of
+    the rank's own shard into the full grid (the other rows stay zero).  For per-rank timing on a single
+    GPU (bench.py's ``multi_gpu_model``); the output is NOT the encoder's output."""
     group: Optional[object] = None
+    simulate: Optional[tuple] = None
 
     @property
     def world(self):
-        return dist.get_world_size(self.group)
+        return self.simulate[1] if self.simulate else dist.get_world_size(self.group)
 
     @property
     def rank(self):
-        return dist.get_rank(self.group)
+        return self.simulate[0] if self.simulate else dist.get_rank(self.group)
 
 
-def enable_bev_tiling(encoder, group=None):
+def enable_bev_tiling(encoder, group=None, simulate=None):
     """Switch ``encoder.forward`` to the tiled schedule on an initialised
-    ``torch.distributed`` process group (one process per GPU)."""
-    if not dist.is_initialized():
+    ``torch.distributed`` process group (one process per GPU); ``simulate``: see ``BevTiling``."""
+    if simulate is None and not dist.is_initialized():
         raise RuntimeError("enable_bev_tiling needs an initialised torch.distributed group")
-    encoder.bev_tiling = BevTiling(group)
+    encoder.bev_tiling = BevTiling(group, tuple(simulate) if simulate is not None else None)
     return encoder
 
 
@@ -90,11 +95,16 @@ def slice_plan(plan, q0, q1):
         max_cam_rows=max_cam_rows)
 
 
-def all_gather_rows(local, blocks, bev_w, group=None):
+def all_gather_rows(local, blocks, bev_w, group=None, simulate=None):
     """local (bs, rows_r*bev_w, C) on every rank -> (bs, Q, C).  Blocks may be
     uneven (padded to the largest for the collective)."""
     world = len(blocks)
     sizes = [(h1 - h0) * bev_w for h0, h1 in blocks]
+    if simulate is not None:                 # single-process timing run: my shard into an otherwise empty grid
+        full = local.new_zeros(local.shape[0], sum(sizes), local.shape[2])
+        q0 = sum(sizes[:simulate[0]])
+        full[:, q0:q0 + sizes[simulate[0]]] = local
+        return full
     mx = max(sizes)
     bs, n, C = local.shape
     if n < mx:
@@ -167,7 +177,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
             hoisted["tsa_projected_value"] = tsa_vals[li]
         if prev_bev is None:
             # no history: TSA's value is the CURRENT full BEV -> exchange per layer
-            full = full_query if li == 0 else all_gather_rows(x, blocks, bev_w, group)
+            full = full_query if li == 0 else all_gather_rows(x, blocks, bev_w, group, tiling.simulate)
             layer_value = torch.stack([full, full], 1).reshape(bs * 2, Q, -1)
         else:
             layer_value = tsa_value
@@ -177,7 +187,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                   reference_points_cam=tile.reference_points_cam, bev_mask=tile.bev_mask,
                   prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), **hoisted, **kwargs)
         if encoder.return_intermediate:
-            inter.append(all_gather_rows(x, blocks, bev_w, group))
+            inter.append(all_gather_rows(x, blocks, bev_w, group, tiling.simulate))
     if encoder.return_intermediate:
         return torch.stack(inter)
-    return all_gather_rows(x, blocks, bev_w, group)
+    return all_gather_rows(x, blocks, bev_w, group, tiling.simulate)

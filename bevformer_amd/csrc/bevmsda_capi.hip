@@ -20,7 +20,7 @@ using bevmsda::bf16_t;
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
 constexpr int kGvRowsPerBlock = 256;         // rows of one head per workgroup of the LDS-tiled grad_value kernel
-constexpr long kDynGridBlocks = 8192;        // grid of the device-row-count sampling launches (multiple of 8)
+constexpr long kDynGridBlocks = 2048;        // grid of the device-row-count sampling launches (multiple of 8)
 constexpr int kLds2RowsPerBlock = 256;       // msda_lds2.h: rows of one head per workgroup
 constexpr int kLds2Cap2 = 704, kLds2Cap3 = 384;   // its LDS tiles (pixels): (704 + 384 + 128 slack) x 128 B = 152 KB, one workgroup per CU
                                              // (128 rows with 320 + 128 pixels, two workgroups per CU: 320 us vs 270 us)

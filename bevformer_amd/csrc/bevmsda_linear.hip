@@ -3,6 +3,7 @@
 #include "../../include/bevmsda.h"
 #include "linear_mfma.h"
 #include "linear_dma.h"
+#include "linear_ws.h"
 #include "wgrad_mfma.h"
 
 namespace {
@@ -10,6 +11,8 @@ namespace {
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
 constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
+constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
+constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 }  // namespace
 
@@ -98,6 +101,43 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
       a.nblk_n = static_cast<int>(nbn);
       if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_dma_kernel<3>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((bevmsda::linear_dma_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
+      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+    }
+  }
+  // third kernel (linear_ws.h): weight-stationary, activations straight into MFMA fragments.  desc->variant = 130
+  // forces it (BEVMSDA_ERR_UNSUPPORTED when not covered), desc->reserved[1] = 1 disables it
+  {
+    const int nprod = d->precision == 0 ? 3 : 1;
+    const long lds_bytes = bevmsda::ws_lds_bytes(d->K0, nprod);
+    const bool covered = wpack && !add && d->K1 == 0 && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 &&
+                         !misaligned(y) && (!bias || !misaligned(bias)) &&
+                         (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) && lds_bytes <= bevmsda::kWsLdsLimit;
+    if (d->variant == 130 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
+    if (covered && (d->variant == 130 || (d->variant == 0 && d->reserved[1] == 0 && kLinearWsDefault &&
+                                          1LL * d->M * d->N >= kLinearWsMinWork))) {
+      const long long nbn = (d->N + bevmsda::kWsBN - 1) / bevmsda::kWsBN;
+      constexpr int wpb = bevmsda::kWsThreads / 64;
+      long long slabs = nbn >= 256 ? 1 : 256 / nbn;
+      long long rows = (d->M + slabs * wpb - 1) / (slabs * wpb);
+      rows = ((rows + 31) / 32) * 32;
+      slabs = (d->M + rows * wpb - 1) / (rows * wpb);
+      const long long grid = ((slabs + 7) / 8) * 8 * nbn;
+      if (grid >= (1LL << 31) || rows >= (1LL << 30)) return BEVMSDA_ERR_TOO_LARGE;
+      bevmsda::WsArgs g;
+      g.l = a;
+      g.l.nblk_n = static_cast<int>(nbn);
+      g.l.nblk_m = 0;
+      g.rows_per_wave = static_cast<int>(rows);
+      g.slabs = static_cast<int>(slabs);
+#define BEVMSDA_WS(NP_)                                                                                               \
+  do {                                                                                                                \
+    auto kern = bevmsda::linear_ws_kernel<NP_>;                                                                       \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                            static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;                    \
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(bevmsda::kWsThreads), lds_bytes, st, g);         \
+  } while (0)
+      if (nprod == 3) BEVMSDA_WS(3); else BEVMSDA_WS(1);
+#undef BEVMSDA_WS
       return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
     }
   }

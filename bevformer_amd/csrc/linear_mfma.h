@@ -66,7 +66,16 @@ struct LinArgs {
   long ldres;
   const float *gamma, *beta;       // (N)
   float eps;
+#ifdef BEVMSDA_LIN_DIAG
+  int diag;                        // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 A loads of chunk 0 only,
+                                   //   3 W copy of chunk 0 only, 4 no A split / LDS write after chunk 0
+#endif
 };
+#ifdef BEVMSDA_LIN_DIAG
+#define LIN_DIAG(a, bit) (((a).diag >> (bit)) & 1)
+#else
+#define LIN_DIAG(a, bit) 0
+#endif
 
 constexpr int kLinBM = 128, kLinBN = 128;   // kLinBN: column-tile granularity of the packed weight image
 constexpr int kLinKGran = 32;               // K0 and K1 must be multiples of this
@@ -302,6 +311,7 @@ linear_splitbf16_kernel(const LinArgs a) {
     // registers -> (+ addend) -> split -> LDS
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      if (LIN_DIAG(a, 4) && kc > 0) break;
       uint4 hi, lo;
       const int off = (p * RPP + srow) * ROW + skq;
       if (ADD && staged_add) {
@@ -341,7 +351,7 @@ linear_splitbf16_kernel(const LinArgs a) {
     const uint16_t *wcur = lds_w + (WMODE == 2 ? (c & 1) * NTW * NPL * PLANE : 0);
     if (!FRAGS && kc + BK < K) {                    // in flight under the MFMAs below
       if (kc + BK == a.K0) set_segment(true);
-      load_chunk();
+      if (!LIN_DIAG(a, 2)) load_chunk();
       if (WMODE == 1) load_w(c + 1, 0);
       if (WMODE == 2) load_w(c + 1, (c + 1) & 1);
     }
@@ -401,6 +411,7 @@ linear_splitbf16_kernel(const LinArgs a) {
         bh[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[bo]);
         if (LO) bl[t] = *reinterpret_cast<const lin_bf16x8 *>(&wcur[PLANE + bo]);
       }
+      if (LIN_DIAG(a, 0) && kc > 0) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -421,7 +432,7 @@ linear_splitbf16_kernel(const LinArgs a) {
         }
     }
     __syncthreads();          // every fragment of this chunk has been read
-    if (WMODE == 3 && kc + BK < K) load_w(c + 1, 0);
+    if (WMODE == 3 && kc + BK < K && !LIN_DIAG(a, 3)) load_w(c + 1, 0);
   }
 
   // grouped output: the N columns are `N / group_cols` consecutive (M, ldy) matrices (one
@@ -542,6 +553,7 @@ linear_splitbf16_kernel(const LinArgs a) {
             if (m < a.M && n < a.N) {         // N % 4 == 0: n < N covers n .. n+3
               float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
                                      acc[i][j][4 * g + 3]);
+              if (LIN_DIAG(a, 1) && v.x != 1.2345e30f) continue;
               if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
               if (a.relu) {                   // NaN stays NaN, as torch.relu
                 v.x = v.x < 0.f ? 0.f : v.x;

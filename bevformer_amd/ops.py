@@ -364,10 +364,10 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
                      else None),
          "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1",
          # autograd path: forward projections on the MFMA kernel too (see _LinearFunction)
-         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "0") == "1",
+         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "1") == "1",
          # second projection kernel (csrc/linear_dma.h: activations by LDS-DMA, one barrier per chunk) for the
          # calls it covers (packed weights, no addend / gather); None = library default
-         "dma": {"1": True, "0": False}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
+         "dma": {"1": True, "0": False, "ws": "ws"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -426,6 +426,18 @@ def packed_weight(weight):
 def set_gemm_dma(flag):
     """True / False: use / avoid the LDS-DMA projection kernel where it applies; None: library default."""
     _GEMM["dma"] = flag
+
+
+def set_gemm_kernel(name):
+    """Which projection kernel serves the calls several of them cover: ``None`` (library default), ``"first"``
+    (linear_mfma.h), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary)."""
+    assert name in (None, "first", "dma", "ws")
+    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws"}[name]
+
+
+def _ws_covers(M, N, K0, K1, a0, a1, mode):
+    planes = 2 if mode == "split" else 1
+    return K1 == 0 and a0 is None and a1 is None and planes * 128 * (K0 + 8) * 2 <= 150 * 1024 and M * N >= 1 << 24
 
 
 def set_gemm_timer(cb):
@@ -503,7 +515,10 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
     elif _GEMM["dma"] is not None and blob is not None:
-        if _GEMM["dma"] and a0 is None and a1 is None:
+        if _GEMM["dma"] == "ws":
+            if _ws_covers(M, N, K0, K1, a0, a1, mode):
+                desc.variant = 130          # force the weight-stationary kernel
+        elif _GEMM["dma"] and a0 is None and a1 is None:
             desc.variant = 129              # force the LDS-DMA kernel (it covers this call)
         elif not _GEMM["dma"]:
             desc.reserved[1] = 1            # keep the first kernel
@@ -708,17 +723,20 @@ def linear_wgrad(g, x, with_bias, *, tag="linear_dw"):
 
 
 class _LinearFunction(Function):
-    """``act(x @ weight.T + bias)`` under autograd with the input gradient (``grad_y @ weight``:
-    the projection kernel over the transposed weight) on the MFMA kernel; the weight gradient
-    (a reduction over the rows: a TN GEMM) runs on hipBLASLt.
+    """``act(x @ weight.T + bias)`` under autograd, all three GEMMs on this package's MFMA kernels: the
+    forward (the projection kernel), the input gradient (``grad_y @ weight``: the projection kernel over the
+    transposed weight) and the weight / bias gradient (``grad_y^T x``, a reduction over the rows:
+    csrc/wgrad_mfma.h).
 
-    The FORWARD stays on hipBLASLt fp32 by default: the gradient of bilinear sampling w.r.t. the
-    sampling location is piecewise constant — discontinuous at pixel boundaries — so the 4e-6
-    (instead of 1e-6) forward round-off of the split-bf16 kernel moves a few more sampling points
-    across a boundary than the library GEMM does and the *gradients* then differ from the fp32
-    oracle by up to 1e-2 of their scale although the forward output agrees to 7e-6 (measured:
-    tools/dbg_bwd.py).  ``BEVMSDA_TRAIN_FWD_MFMA=1`` puts the forward on the kernel as well
-    (76.9 vs 81.9 ms per base frame fwd + bwd) for users who accept that."""
+    Which GEMM the FORWARD uses matters for the gradients because bilinear sampling is piecewise linear in
+    the location: forward round-off moves sampling points across pixel boundaries and single gradient
+    entries then take the slope of the other side.  Measured at BASELINE configs[2] against the oracle in
+    float64 (tools/train_fwd_table.py, profiles/r2/train_fwd_table.txt), relative L2 error of
+    d/d(query), d/d(feat), worst parameter gradient: float32 oracle on the CPU 2.0e-3 / 1.7e-3 / 6.0e-3;
+    library fp32 forward 2.0e-3 / 1.7e-3 / 6.0e-3; split-bf16 forward 2.7e-3 / 2.4e-3 / 5.2e-3;
+    1-product bf16 forward 4.6e-2 / 3.9e-2 / 7.0e-2.  Any float32 evaluation sits at 2e-3; the split-bf16
+    kernel adds a third to that and is the default (``BEVMSDA_TRAIN_FWD_MFMA=0`` restores the library
+    forward)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -745,7 +763,7 @@ class _LinearFunction(Function):
         x, weight, y = ctx.saved_tensors
         gy = gy.float()
         if ctx.relu:
-            gy = gy * (y > 0).to(gy.dtype)
+            gy = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0.0)     # one pass: gy where y > 0
         K = x.shape[-1]
         g2 = gy.reshape(-1, gy.shape[-1])
         gx = gw = gb = None

@@ -360,3 +360,43 @@ def test_linear_wgrad_kernel(M, N, K, mode):
     assert ((gw.cpu().double() - want_w).abs() / scale.clamp(min=1e-9)).max().item() < tol * 40
     assert ((gw.cpu().double() - want_w).abs().max() / scale.max()).item() < tol
     torch.testing.assert_close(gb.cpu().double(), want_b, rtol=1e-4, atol=1e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("M,K,N,relu,groups,out", [
+    (70000, 256, 256, False, 1, torch.float32), (33001, 256, 512, True, 1, torch.float32),
+    (12345, 256, 1536, False, 6, torch.float32), (20011, 128, 896, False, 1, torch.float32),
+    (65570, 256, 256, False, 2, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_weight_stationary_kernel(M, K, N, relu, groups, out, mode):
+    """csrc/linear_ws.h (weight image of a column tile resident in LDS, activation rows loaded straight into
+    MFMA fragments with a permuted k order, 64- and 32-row tiles per wavefront) against the fp64 statement
+    of F.linear and against the first kernel: ragged row runs, N not a multiple of 128, grouped / bf16 output."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if relu:
+        want = want.relu()
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        res = {}
+        for kern in ("ws", "first"):
+            ops.set_gemm_kernel(kern)
+            with torch.no_grad():
+                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, groups=groups, out_dtype=out)
+            assert y is not None
+            res[kern] = y.float().cpu()
+    finally:
+        ops.set_gemm_kernel(None)
+        ops.set_gemm_mode(saved)
+    y = res["ws"]
+    if groups > 1:
+        y = torch.cat(list(y), -1)
+    scale = (x.double().abs() @ w.double().abs().t()).clamp(min=1e-6)
+    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
+    assert ((y.double() - want).abs() / scale).max().item() < tol
+    # same products, another summation order over k inside a 32-deep chunk
+    torch.testing.assert_close(res["ws"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
+                               atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)

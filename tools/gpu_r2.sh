@@ -24,6 +24,9 @@ for s in $steps; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -3 "$out/smoke.log";;
     trace) PMC=0 timeout 400 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; head -40 "$out/prof_summary.txt" | cut -c1-170;;
     prof) PMC=1 timeout 1200 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; tail -30 "$out/prof_summary.txt" | cut -c1-170;;
+    prof_bwd) PMC=1 timeout 1200 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --backward --steps 2 --warmup 1 --windows 1 > "$out/prof_bwd_summary.txt" 2>&1; tail -30 "$out/prof_bwd_summary.txt" | cut -c1-170;;
+    prof_lds2) BEVMSDA_SCA_LDS2=1 TRACE=0 PMC=1 PMC_ONLY="1 3 4" timeout 900 tools/prof.sh "${tag}_lds2" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_lds2_summary.txt" 2>&1; tail -30 "$out/prof_lds2_summary.txt" | cut -c1-170;;
+    trace_sim) PMC=0 timeout 400 tools/prof.sh "${tag}_sim" python "$root/bench.py" --no-cpu-baseline --no-variants --simulate-rank 3,8 --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_sim_summary.txt" 2>&1; head -40 "$out/prof_sim_summary.txt" | cut -c1-170;;
     trace_bwd) PMC=0 timeout 400 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --backward --steps 2 --warmup 1 --windows 1 > "$out/prof_bwd_summary.txt" 2>&1; head -40 "$out/prof_bwd_summary.txt" | cut -c1-170;;
     kb*) timeout 600 python tools/kbench2.py > "$out/$s.log" 2>&1; tail -30 "$out/$s.log";;
   esac
