@@ -63,6 +63,17 @@ template <> __device__ __forceinline__ float4 load_gout4<bf16_t>(const bf16_t *p
   return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on
+// gfx9 is `s_waitcnt vmcnt(0)` before the s_barrier: every wavefront would first wait for its outstanding
+// memory-side flush atomics (vmcnt counts them until the L2 has retired them), i.e. the ~10 G line-atomics / s
+// of the L2 would sit on the critical path of the NEXT level's sort instead of running under it (measured:
+// the phase after a level's flush took 59 % of the kernel).  The sort only communicates through LDS, and the
+// atomics are fire-and-forget (no return value, nothing reads grad_value here), so lgkmcnt(0) + s_barrier is
+// all the ordering it needs.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // In-place exclusive scan of cnt[0 .. kGvBuckets] (kGvBuckets + 1 entries, the last one = total) by the
 // whole workgroup: 4 counters per thread.  Two barriers.
 __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvThreads / 64 ints */) {
@@ -78,7 +89,7 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvTh
     if (lane >= o) inc += t;
   }
   if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
+  lds_barrier();
   int base = inc - s, total = 0;
 #pragma unroll
   for (int w = 0; w < kGvThreads / 64; ++w) {
@@ -87,7 +98,7 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvTh
     total += t;
   }
   reinterpret_cast<int4 *>(cnt)[tid] = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
-  __syncthreads();
+  lds_barrier();
   return total;
 }
 
@@ -196,14 +207,27 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       }
     GV_TICK(0)
 
+    // level geometry up front as well: a load inside the level loop would wait on vmcnt and with it on every
+    // flush atomic still in flight (the counter retires in order)
+    int Hs[kGvMaxLevels], Ws[kGvMaxLevels];
+    long ls[kGvMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kGvMaxLevels; ++l) {
+      const int ll = l < L ? l : 0;
+      // (readfirstlane pins the loads here — the scheduler would otherwise sink them back into the loop —
+      // and keeps the uniform values in SGPRs)
+      Hs[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll]));
+      Ws[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll + 1]));
+      ls[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.lstart[ll]));
+    }
 #pragma unroll
     for (int l = 0; l < kGvMaxLevels; ++l) {
       if (l >= L) break;
-      const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
-      float *gv = a.grad_value + ((n0 * a.S + a.lstart[l]) * a.M + m) * D + c;
+      const int H = Hs[l], W = Ws[l];
+      float *gv = a.grad_value + ((n0 * a.S + ls[l]) * a.M + m) * D + c;
       // ---- (1) zero the counters
       reinterpret_cast<int4 *>(cnt)[tid] = make_int4(0, 0, 0, 0);
-      __syncthreads();
+      lds_barrier();
       // ---- (2) my records: four taps each, counted into their buckets
       int pix[RPT][4], key[RPT][4], rowj[RPT];
       float k[RPT][4];
@@ -230,7 +254,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
           if (ok[j][t]) atomicAdd(&cnt[key[j][t]], 1);
         }
       }
-      __syncthreads();
+      lds_barrier();
       GV_TICK(1)
       // ---- (3) scan, place
       const int total = block_exclusive_scan(cnt, wsum);
@@ -243,7 +267,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
             const int pos = atomicAdd(&cnt[key[j][t]], 1);
             ent[pos] = make_int2(pix[j][t] | ((grow0 + rowj[j]) << 23), __float_as_int(k[j][t]));
           }
-      __syncthreads();
+      lds_barrier();
       GV_TICK(3)
       // ---- (4) segmented reduction: my 1/32 of the sorted entries, one atomic per pixel run
       {

@@ -93,16 +93,33 @@ def test_deformable_attention_3d_batch_layout():
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("fwd_mfma", [True, False])
 @pytest.mark.parametrize("temporal", [False, True])
-def test_encoder_backward(temporal):
+def test_encoder_backward(temporal, fwd_mfma):
     """fwd+bwd through two layers: parameter and input gradients vs autograd of
-    the oracle (eval mode so dropout is the identity on both sides)."""
-    enc, sd = build_pair("micro4", device=DEV)
-    q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
-    qd, fd = q.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
-    out = enc(qd, fd, fd, **_to_dev(kw))
-    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
-    out.backward(gout.to(DEV))
+    the oracle (eval mode so dropout is the identity on both sides).
+
+    Tolerances (the gradient level of DESIGN.md's parity table): bilinear sampling is piecewise linear in
+    the location, so forward round-off can move a sampling point across a pixel boundary and single
+    gradient entries then take the other side's slope.  With the library fp32 GEMM in the forward pass
+    (``fwd_mfma = False``) this 120-query case has no such flip and every gradient agrees to 2e-3 of its
+    largest entry; with the split-bf16 MFMA forward (the default, 4e-6 forward round-off) a flip may occur:
+    per-tensor max error < 0.1 of the largest entry as in the BASELINE-config gradient test
+    (tests/test_baseline_configs_gpu.py) and relative L2 error < 3e-2 — that test's 1e-2 is for 22,500
+    queries; one flipped slope among 120 queries weighs more (measured here: 1.1e-2 on the
+    sampling-offset weights of layer 1)."""
+    from bevformer_amd import ops
+    saved = ops._GEMM["train_forward_mfma"]
+    ops._GEMM["train_forward_mfma"] = fwd_mfma
+    try:
+        enc, sd = build_pair("micro4", device=DEV)
+        q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
+        qd, fd = q.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+        out = enc(qd, fd, fd, **_to_dev(kw))
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+        out.backward(gout.to(DEV))
+    finally:
+        ops._GEMM["train_forward_mfma"] = saved
 
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     qc, fc = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
@@ -113,7 +130,11 @@ def test_encoder_backward(temporal):
     def close(a, b, what):
         scale = b.abs().max().item() + 1e-12
         err = (a - b).abs().max().item() / scale
-        assert err < 2e-3, f"{what}: relative max error {err:.3e}"
+        l2 = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        if fwd_mfma:
+            assert l2 < 3e-2 and err < 0.1, f"{what}: relative L2 {l2:.3e}, relative max error {err:.3e}"
+        else:
+            assert err < 2e-3, f"{what}: relative max error {err:.3e}"
 
     close(qd.grad.cpu(), qc.grad, "bev_query grad")
     close(fd.grad.cpu(), fc.grad, "camera feature grad")
