@@ -4,6 +4,7 @@
 #include "linear_mfma.h"
 #include "linear_dma.h"
 #include "linear_ws.h"
+#include "linear_pipe.h"
 #include "wgrad_mfma.h"
 
 namespace {
@@ -11,6 +12,7 @@ namespace {
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
 constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
+constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
 constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
 constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -101,6 +103,34 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
       a.nblk_n = static_cast<int>(nbn);
       if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_dma_kernel<3>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((bevmsda::linear_dma_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
+      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+    }
+  }
+  // software-pipelined kernel (linear_pipe.h): desc->variant = 131 forces it (BEVMSDA_ERR_UNSUPPORTED when not
+  // covered), desc->reserved[1] = 1 disables it
+  {
+    const int nch = (d->K0 + d->K1) / 32;
+    const bool covered = wpack && !add && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
+                         (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) &&
+                         (nch == 8 || nch == 16);
+    if (d->variant == 131 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
+    if (covered && (d->variant == 131 || (d->variant == 0 && d->reserved[1] == 0 && kLinearPipeDefault))) {
+      const long long nbm = (d->M + 127) / 128, nbn = (d->N + 127) / 128;
+      const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+      if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+      a.nblk_m = static_cast<int>(nbm);
+      a.nblk_n = static_cast<int>(nbn);
+#define BEVMSDA_PIPE(NP_, NCH_)                                                                                       \
+  do {                                                                                                                \
+    auto kern = bevmsda::linear_pipe_kernel<NP_, NCH_>;                                                               \
+    const int dyn = 2 * ((NP_) == 3 ? 2 : 1) * bevmsda::kPipePlane * 2;                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != \
+        hipSuccess) return BEVMSDA_ERR_LAUNCH;                                                                        \
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), dyn, st, a);                               \
+  } while (0)
+      if (d->precision == 0) { if (nch == 8) BEVMSDA_PIPE(3, 8); else BEVMSDA_PIPE(3, 16); }
+      else { if (nch == 8) BEVMSDA_PIPE(1, 8); else BEVMSDA_PIPE(1, 16); }
+#undef BEVMSDA_PIPE
       return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
     }
   }

@@ -400,3 +400,33 @@ def test_linear_weight_stationary_kernel(M, K, N, relu, groups, out, mode):
     # same products, another summation order over k inside a 32-deep chunk
     torch.testing.assert_close(res["ws"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
                                atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)
+
+
+@pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
+    (1000, 256, 0, 256, False, 1, torch.float32), (4099, 256, 256, 192, False, 1, torch.float32),
+    (513, 256, 0, 512, True, 1, torch.float32), (2050, 256, 0, 768, False, 3, torch.float32),
+    (300, 512, 0, 256, False, 1, torch.float32), (1111, 256, 0, 256, False, 2, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_software_pipelined_kernel(M, K0, K1, N, relu, groups, out, mode):
+    """csrc/linear_pipe.h (two LDS stages, two fragment register sets, activations two chunks ahead, one
+    barrier per chunk; K loop unrolled for K = 256 and 512) against the first kernel: same products in the
+    same order, so bit-identical — ragged row tiles, two K sources, ReLU, grouped and bf16 output."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K0, generator=g).to(DEV)
+    x2 = torch.randn(M, K1, generator=g).to(DEV) if K1 else None
+    w = (torch.randn(N, K0 + K1, generator=g) * (K0 + K1) ** -0.5).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        res = {}
+        for kern in ("pipe", "first"):
+            ops.set_gemm_kernel(kern)
+            with torch.no_grad():
+                y = ops.linear(x, w, b, relu=relu, x2=x2, groups=groups, out_dtype=out)
+            assert y is not None
+            res[kern] = y.float().cpu()
+    finally:
+        ops.set_gemm_kernel(None)
+        ops.set_gemm_mode(saved)
+    assert torch.equal(res["pipe"], res["first"])
