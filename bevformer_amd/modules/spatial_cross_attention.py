@@ -135,10 +135,11 @@ class MSDeformableAttention3D(BaseModule):
         return v.view(value.shape[0], value.shape[1], self.num_heads, -1)
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
-                                       spatial_shapes, level_start_index, frame_plan=None):
+                                       spatial_shapes, level_start_index, frame_plan=None, autograd=False):
         """queries (Q, C) projected once; row r samples with the projection row
         ``row_src[r]`` and its own anchors ``row_ref[r]`` -> (R, C), or None when
-        the fused kernel does not cover the shape."""
+        the fused kernel does not cover the shape.  ``autograd``: through
+        ``ops.msda_fused_autograd`` (gradients w.r.t. the value and the projection rows)."""
         M, L, P = self.num_heads, self.num_levels, self.num_points
         Dz = row_ref.shape[-2]
         if P % Dz != 0 or row_ref.shape[-1] != 2:
@@ -146,6 +147,13 @@ class MSDeformableAttention3D(BaseModule):
         n_off = self.sampling_offsets.out_features
         w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
         proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
+        if autograd:
+            if value.shape[-1] != 32 or L > 4 or P not in (4, 8) or value.dtype != torch.float32:
+                return None
+            return ops.msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off,
+                                           row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
+                                           off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
+                                           vmul=1, vadd=0, row_src=row_src, tag="sca_fwd").to(queries.dtype)
         lds = {}
         if frame_plan is not None and frame_plan.dynamic:
             # row count on the device (geometry.DevicePlanner); launch sized by the planner's hint
@@ -282,9 +290,17 @@ class SpatialCrossAttention(BaseModule):
                 # the unfused statements need the row count on the host: one read of the plan's counters
                 fp = frame_plan.materialize()
                 row_query, row_batch, row_ref = fp.row_query, fp.row_batch, fp.row_ref
-            q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
-            out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
-                                         spatial_shapes, level_start_index)
+            out_rows = None
+            if ops.fused_training_wanted(query, projected_value) and row_query.numel() > 0:
+                # autograd path: the queries are projected once here too and the fused kernel reads a row's
+                # projection through row_src; its backward accumulates over the cameras of a query
+                out_rows = da.forward_rows_shared_projection(
+                    query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
+                    row_query.to(torch.int32), spatial_shapes, level_start_index, autograd=True)
+            if out_rows is None:
+                q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
+                out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
+                                             spatial_shapes, level_start_index)
             slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
             slots.index_add_(0, row_query, out_rows)
             slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)

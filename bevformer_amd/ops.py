@@ -291,6 +291,103 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     return out
 
 
+_FUSED_TRAIN = {"enabled": os.environ.get("BEVMSDA_FUSED_TRAIN", "1") == "1"}
+
+
+def set_fused_training(flag):
+    """Autograd path of the attention modules through the fused sampling kernel + its three-step backward
+    (default) or through the unfused operator with the softmax / location arithmetic as torch ops."""
+    _FUSED_TRAIN["enabled"] = bool(flag)
+
+
+def fused_training_wanted(*tensors):
+    return _FUSED["enabled"] and _FUSED_TRAIN["enabled"] and _STORAGE["dtype"] == torch.float32 \
+        and torch.is_grad_enabled() and all(t is None or t.is_cuda for t in tensors) \
+        and any(t is not None and t.requires_grad for t in tensors) and not torch.is_autocast_enabled()
+
+
+class _FusedSampleFunction(Function):
+    """``msda_fused`` under autograd.  Forward: the fused kernel (softmax, locations, sampling, queue mean from
+    the raw projection rows) — nothing but its inputs is saved.  Backward (include/bevmsda.h,
+    ``bevmsda_frontend_*``): (1) locations / weights / value batch entries of every (row, queue entry)
+    recomputed from the projection rows, (2) the operator's backward kernels, (3) softmax backward and
+    1 / (W, H) back onto the projection rows, accumulated over the rows that share one."""
+
+    @staticmethod
+    def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag):
+        out = msda_fused(value.detach(), shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
+                         tag=tag, **meta)
+        if out is None:
+            raise RuntimeError("bevmsda: fused sampling kernel does not cover this call")
+        ctx.save_for_backward(value, proj, shapes, start, ref.float().contiguous(),
+                              row_batch if row_batch is not None else shapes.new_empty(0),
+                              row_src if row_src is not None else shapes.new_empty(0))
+        ctx.n_off, ctx.meta = n_off, meta
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        value, proj, shapes, start, ref, row_batch, row_src = ctx.saved_tensors
+        row_batch = row_batch if row_batch.numel() else None
+        row_src = row_src if row_src.numel() else None
+        m = ctx.meta
+        M, L, P, K = m["M"], m["L"], m["P"], m["K"]
+        N, S, _, D = value.shape
+        R = proj.shape[0] if row_src is None else row_src.numel()
+        A = ref.shape[-2]
+        desc = _lib.FusedDesc(R=R, proj_row=proj.stride(0), N=N, S=S, M=M, D=D, L=L, P=P, Q=m.get("Q", 0), K=K, A=A,
+                              ref_mode=m["ref_mode"], off_head=m["off_head"], off_k=m["off_k"],
+                              lg_head=m["lg_head"], lg_k=m["lg_k"], vmul=m["vmul"], vadd=m["vadd"])
+        dev = value.device
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        RK = R * K
+        loc = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
+        attn = torch.empty((RK, M, L, P), dtype=torch.float32, device=dev)
+        rbk = torch.empty(RK, dtype=torch.int32, device=dev)
+        value = value.detach().float().contiguous()
+        proj = proj.detach()
+        logits = proj[:, ctx.n_off:]
+        with torch.cuda.device(dev):
+            _lib.check(lib.bevmsda_frontend_expand_f32(
+                proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
+                _ptr(row_src) if row_src is not None else None, _ptr(shapes), ctypes.byref(desc), _ptr(loc),
+                _ptr(attn), _ptr(rbk), st), "fused backward: expand")
+            g = grad_out.float()
+            if K > 1:       # out = mean over the queue entries; rows are queue-major
+                g = (g * (1.0 / K)).repeat(K, 1)
+            g = g.contiguous()
+            gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
+            gl = torch.empty_like(loc)
+            ga = torch.empty_like(attn)
+            if row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
+                # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
+                # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
+                _lib.check(lib.bevmsda_backward_f32(
+                    _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
+                    _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
+            else:
+                _lib.check(lib.bevmsda_backward_ragged_f32(
+                    _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
+                    RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
+            gproj = torch.zeros_like(proj) if row_src is not None else torch.empty_like(proj)
+            glogits = gproj[:, ctx.n_off:]
+            _lib.check(lib.bevmsda_frontend_chain_f32(
+                _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
+                ctypes.byref(desc), gproj.data_ptr(), glogits.data_ptr(), st), "fused backward: chain")
+        return gv, gproj, None, None, None, None, None, None, None, None
+
+
+def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
+                        tag="msda_fwd", **meta):
+    """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (fp32 storage, D = 32; the caller checks
+    ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
+    columns, logits behind them, every column of a row used by exactly one (head, queue entry, level, point))."""
+    return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
+                                      meta, tag)
+
+
 def fold_extra_rows(rows, q_rows_all, n_extra):
     """In place: rows[q_rows_all[s, 0]] += sum_{j >= 2} rows[q_rows_all[s, j]] for the slots more
     than two cameras see (``bevmsda_fold_extra_rows_f32``; a no-op launch when the device counter

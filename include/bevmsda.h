@@ -199,6 +199,28 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
                                     const int32_t *nrows, const bevmsda_fused_desc *desc, uint16_t *out,
                                     void *stream);
 
+/* Backward of bevmsda_fused_forward_f32 in three steps (the autograd path of the modules; reference statements:
+ * bevformer/modules/spatial_cross_attention.py:340-372, temporal_self_attention.py:209-229, 257-262 — what
+ * autograd records there as softmax / divide / add / view nodes):
+ *   1. bevmsda_frontend_expand_f32: the raw projection rows -> sampling locations `loc` (K*R, M, L, P, 2),
+ *      attention weights `attn` (K*R, M, L, P) and `row_batch_k` (K*R) = the value batch entry of every (queue entry,
+ *      row), QUEUE-MAJOR (row q*R + r): the operands of bevmsda_backward_ragged_f32 (or, with one batch element and
+ *      one value batch entry per queue entry, of bevmsda_backward_f32 with N = K, Q = R), recomputed instead of saved
+ *      by the forward;
+ *   2. the operator's backward over those K*R rows with grad_out[q*R + r] = grad_out[r] / K;
+ *   3. bevmsda_frontend_chain_f32: its grad_loc / grad_attn -> the gradient of the raw projection rows (softmax
+ *      backward over the L*P logits of a (row, head, queue entry); 1 / (W_l, H_l) on the offsets).  With `row_src`
+ *      (several rows share a projection row) the results are ADDED to grad_offs / grad_logits with fp32 atomics — the
+ *      caller zeroes them; without it they are stored.  grad_offs / grad_logits address the gradient matrix exactly as
+ *      offs / logits address the projection matrix (same desc->proj_row, off_head, off_k, lg_head, lg_k).
+ * Supported: P in {4, 8}, L <= 4, K in {1, 2}; else BEVMSDA_ERR_UNSUPPORTED. */
+int bevmsda_frontend_expand_f32(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                const int32_t *row_src, const int64_t *spatial_shapes, const bevmsda_fused_desc *desc,
+                                float *loc, float *attn, int32_t *row_batch_k, void *stream);
+int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, const float *attn, const int32_t *row_src,
+                               const int64_t *spatial_shapes, const bevmsda_fused_desc *desc, float *grad_offs,
+                               float *grad_logits, void *stream);
+
 /* bevmsda_fused_forward_f32 / _rows_f32 for SpatialCrossAttention with the two COARSE feature levels of a
  * (camera, head) patch served from LDS while the two fine levels stream through the vector-memory path
  * (csrc/msda_lds2.h).  Rows must be grouped by value batch entry (camera).  nrows: NULL (desc->R rows), or

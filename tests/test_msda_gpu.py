@@ -15,6 +15,7 @@ import torch
 
 from bevformer_amd import _lib
 from bevformer_amd import ext
+from bevformer_amd import ops
 from bevformer_amd.functions import (MultiScaleDeformableAttnFunction_bf16,
                                      MultiScaleDeformableAttnFunction_fp32)
 from bevformer_amd.synthetic import make_msda_case, make_sca_msda_case, make_tsa_msda_case
@@ -277,3 +278,66 @@ def test_fused_front_end_bf16_storage_kernels(kind, monkeypatch):
     torch.testing.assert_close(got16.cpu(), want, rtol=1e-4, atol=2e-5)
     assert got8.dtype == torch.bfloat16
     torch.testing.assert_close(got8.float().cpu(), want, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("case", ["sca_shared_rows", "sca_three_levels", "tsa_queue"])
+def test_fused_autograd_function_matches_unfused_autograd(case):
+    """``ops.msda_fused_autograd`` (fused forward; backward = front-end expand + the operator's backward
+    kernels + front-end chain, include/bevmsda.h ``bevmsda_frontend_*``) against autograd through the
+    torch statements of the same front end around ``ops.msda_ragged``: output, d/d(value), d/d(projection
+    rows) — with several rows sharing a projection row (SCA) and with two queue entries averaged (TSA)."""
+    g = torch.Generator().manual_seed(11)
+    M, D = 8, 32
+    if case.startswith("sca"):
+        L, P, K, Dz, Nq, R, N = (4 if case == "sca_shared_rows" else 3), 8, 1, 4, 150, 230, 3
+        shapes = torch.tensor([[12, 20], [6, 10], [3, 5], [2, 3]])[:L]
+    else:
+        L, P, K, Dz, Nq, R, N = 1, 4, 2, 1, 180, 180, 2
+        shapes = torch.tensor([[12, 15]])
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    S = int(shapes.prod(1).sum())
+    n_off = M * K * L * P * 2
+    value = torch.randn(N, S, M, D, generator=g).to(DEV).requires_grad_(True)
+    proj = torch.randn(Nq, n_off + M * K * L * P, generator=g)
+    proj[:, :n_off] *= 2.0
+    proj = proj.to(DEV).requires_grad_(True)
+    gout = torch.randn(R, M * D, generator=g).to(DEV)
+    sh, st = shapes.to(DEV), start.to(DEV)
+    if case.startswith("sca"):
+        row_src = torch.randint(0, Nq, (R,), generator=g).to(torch.int32).to(DEV)
+        row_batch = torch.randint(0, N, (R,), generator=g).sort().values.to(torch.int32).to(DEV)
+        ref = torch.rand(R, 1, Dz, 2, generator=g).to(DEV)
+        meta = dict(M=M, L=L, P=P, K=1, off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0, vmul=1, vadd=0)
+        out = ops.msda_fused_autograd(value, sh, st, proj, n_off, ref, row_batch, row_src=row_src, **meta)
+        out.backward(gout)
+        got = (out.detach(), value.grad.clone(), proj.grad.clone())
+        value.grad = proj.grad = None
+        # torch statement: point p uses anchor p % Dz (spatial_cross_attention.py:357-372)
+        rows = proj[row_src.long()]
+        off = rows[:, :n_off].reshape(R, M, L, P, 2)
+        att = rows[:, n_off:].reshape(R, M, L * P).softmax(-1).view(R, M, L, P)
+        norm = torch.stack([sh[:, 1], sh[:, 0]], -1).float()
+        loc = ref.view(R, 1, 1, 1, Dz, 2) + (off / norm[None, None, :, None, :]).view(R, M, L, P // Dz, Dz, 2)
+        want = ops.msda_ragged(value, sh, st, loc.reshape(R, M, L, P, 2).contiguous(), att.contiguous(), row_batch)
+    else:
+        ref = torch.rand(R, K, L, 2, generator=g).to(DEV)
+        meta = dict(M=M, L=L, P=P, K=K, off_head=K * L * P * 2, off_k=L * P * 2, lg_head=K * L * P, lg_k=L * P,
+                    ref_mode=1, vmul=K, vadd=1, Q=R)
+        value = torch.randn(1 * K, S, M, D, generator=g).to(DEV).requires_grad_(True)
+        out = ops.msda_fused_autograd(value, sh, st, proj, n_off, ref, None, **meta)
+        out.backward(gout)
+        got = (out.detach(), value.grad.clone(), proj.grad.clone())
+        value.grad = proj.grad = None
+        # torch statement: two queue entries with their own value batch entry, averaged
+        off = proj[:, :n_off].reshape(R, M, K, L, P, 2).permute(2, 0, 1, 3, 4, 5)          # (K, R, M, L, P, 2)
+        att = proj[:, n_off:].reshape(R, M, K, L * P).softmax(-1).view(R, M, K, L, P).permute(2, 0, 1, 3, 4)
+        norm = torch.stack([sh[:, 1], sh[:, 0]], -1).float()
+        loc = ref.permute(1, 0, 2, 3)[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        rb = torch.arange(K, device=DEV, dtype=torch.int32).repeat_interleave(R)
+        o = ops.msda_ragged(value, sh, st, loc.reshape(K * R, M, L, P, 2).contiguous(),
+                            att.reshape(K * R, M, L, P).contiguous(), rb)
+        want = o.view(K, R, M * D).mean(0)
+    want.backward(gout)
+    torch.testing.assert_close(got[0], want.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[1], value.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(got[2], proj.grad, rtol=1e-3, atol=2e-4)
