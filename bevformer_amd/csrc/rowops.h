@@ -70,6 +70,91 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const float *__restr
   }
 }
 
+// Backward of add_layernorm: z = x + res is recomputed (x and res are kept by the caller; nothing else is saved
+// by the forward), grad_x = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) is the gradient of BOTH
+// x and res; grad_gamma += sum_rows g * xhat, grad_beta += sum_rows g (accumulated: the caller zeroes them).
+// One wavefront walks rows row0, row0 + W, ... with its column sums in registers; the 4 wavefronts of a block
+// combine them through LDS and issue one atomic per column and block.  3 reads + 1 write of the grid.
+template <int VPL>
+__global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ res,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ gout, float eps, long rows,
+                                                               float *__restrict__ gx, float *__restrict__ ggamma,
+                                                               float *__restrict__ gbeta) {
+  constexpr int C = 256 * VPL;
+  __shared__ float part[2][4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nwaves = static_cast<long>(gridDim.x) * 4;
+  const float4 *gp = reinterpret_cast<const float4 *>(gamma);
+  float4 gam[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    gam[i] = gp[lane + 64 * i];
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long row = static_cast<long>(blockIdx.x) * 4 + wave; row < rows; row += nwaves) {
+    const float4 *xp = reinterpret_cast<const float4 *>(x + row * C);
+    const float4 *rp = res ? reinterpret_cast<const float4 *>(res + row * C) : nullptr;
+    const float4 *yp = reinterpret_cast<const float4 *>(gout + row * C);
+    float4 v[VPL], gy[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i] = xp[lane + 64 * i];
+      gy[i] = yp[lane + 64 * i];
+      if (rp) {
+        const float4 t = rp[lane + 64 * i];
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;           // xhat
+      dg[i].x += gy[i].x * v[i].x; dg[i].y += gy[i].y * v[i].y; dg[i].z += gy[i].z * v[i].z; dg[i].w += gy[i].w * v[i].w;
+      db[i].x += gy[i].x; db[i].y += gy[i].y; db[i].z += gy[i].z; db[i].w += gy[i].w;
+      gy[i].x *= gam[i].x; gy[i].y *= gam[i].y; gy[i].z *= gam[i].z; gy[i].w *= gam[i].w;   // g * gamma
+      s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+      s2 += (gy[i].x * v[i].x + gy[i].y * v[i].y) + (gy[i].z * v[i].z + gy[i].w * v[i].w);
+    }
+    s1 = wave_sum(s1) * (1.0f / C);
+    s2 = wave_sum(s2) * (1.0f / C);
+    float4 *op = reinterpret_cast<float4 *>(gx + row * C);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float4 o;
+      o.x = rstd * (gy[i].x - s1 - v[i].x * s2);
+      o.y = rstd * (gy[i].y - s1 - v[i].y * s2);
+      o.z = rstd * (gy[i].z - s1 - v[i].z * s2);
+      o.w = rstd * (gy[i].w - s1 - v[i].w * s2);
+      op[lane + 64 * i] = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    reinterpret_cast<float4 *>(part[0][wave])[lane + 64 * i] = dg[i];
+    reinterpret_cast<float4 *>(part[1][wave])[lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float a = (part[0][0][c] + part[0][1][c]) + (part[0][2][c] + part[0][3][c]);
+    const float b = (part[1][0][c] + part[1][1][c]) + (part[1][2][c] + part[1][3][c]);
+    unsafeAtomicAdd(ggamma + c, a);
+    unsafeAtomicAdd(gbeta + c, b);
+  }
+}
+
 // rows (R, C); idx (Q, J) int32 row ids, -1 = empty; scale (Q,); out (Q, C); C % 4 == 0.
 __global__ void __launch_bounds__(256) gather_mean_kernel(const float *__restrict__ rows,
                                                          const int32_t *__restrict__ idx,

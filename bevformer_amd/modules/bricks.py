@@ -91,9 +91,8 @@ class FFN(BaseModule):
             return self.dropout_layer(out)
         if identity is None:
             identity = x
-        if defer_residual and not (self.training and isinstance(self.dropout_layer, nn.Dropout)
-                                   and self.dropout_layer.p > 0):
-            return out, identity                # the layer fuses "+ identity" into its LayerNorm
+        if defer_residual:
+            return self.dropout_layer(out), identity    # the layer fuses "+ identity" into its LayerNorm
         return identity + self.dropout_layer(out)
 
 

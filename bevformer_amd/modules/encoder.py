@@ -279,15 +279,18 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         # (post-norm orders only: with a leading norm the "+ identity" of a step feeds the NEXT
         # step's residual, not the norm that follows)
         fuse_norm = (not self.training) and (not torch.is_grad_enabled()) and not self.pre_norm
+        # autograd path: the same "+ identity" deferral, resolved by ops.add_layernorm_autograd (one forward pass,
+        # one backward kernel instead of torch's add + LayerNorm and their four backward launches)
+        fuse_norm_grad = torch.is_grad_enabled() and query.is_cuda and not self.pre_norm
         pending = None                          # (branch output, identity) awaiting its norm
 
         def _defer(i):
-            return fuse_norm and i + 1 < len(order) and order[i + 1] == "norm" \
+            return (fuse_norm or fuse_norm_grad) and i + 1 < len(order) and order[i + 1] == "norm" \
                 and isinstance(self.norms[norm_i], torch.nn.LayerNorm)
 
         def _post_norm(i):
             """The LayerNorm the step at ``i`` may fold into its last projection (inference fast path)."""
-            return self.norms[norm_i] if _defer(i) else None
+            return self.norms[norm_i] if (fuse_norm and _defer(i)) else None
 
         skip_norm = False                       # the previous step returned ops.Normed
         for i, op in enumerate(order):
@@ -312,7 +315,10 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 elif pending is not None:
                     branch, res = pending
                     pending = None
-                    query = ops.add_layernorm(branch, res, norm.weight, norm.bias, norm.eps)
+                    if torch.is_grad_enabled():
+                        query = ops.add_layernorm_autograd(branch, res, norm)
+                    else:
+                        query = ops.add_layernorm(branch, res, norm.weight, norm.bias, norm.eps)
                     if query is None:
                         query = norm(branch + res)
                 else:

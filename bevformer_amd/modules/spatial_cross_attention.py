@@ -307,6 +307,6 @@ class SpatialCrossAttention(BaseModule):
         if not projected:
             slots = ops.linear_or_torch(slots, self.output_proj.weight, self.output_proj.bias,
                                         tag="sca_output_proj")
-        if defer_residual and not (self.training and self.dropout.p > 0):
-            return slots, inp_residual          # the layer fuses "+ residual" into its LayerNorm
+        if defer_residual:
+            return self.dropout(slots), inp_residual    # the layer fuses "+ residual" into its LayerNorm
         return self.dropout(slots) + inp_residual

@@ -211,6 +211,6 @@ class TemporalSelfAttention(BaseModule):
                                   tag="tsa_output_proj")
         if not self.batch_first:
             out = out.permute(1, 0, 2)
-        if defer_residual and not (self.training and self.dropout.p > 0):
-            return out, identity                # the layer fuses "+ identity" into its LayerNorm
+        if defer_residual:
+            return self.dropout(out), identity  # the layer fuses "+ identity" into its LayerNorm
         return self.dropout(out) + identity

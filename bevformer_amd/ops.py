@@ -430,6 +430,49 @@ def add_layernorm(x, res, weight, bias, eps):
     return out
 
 
+class _AddLayerNormFunction(Function):
+    """``LayerNorm(x + res)`` under autograd on the row kernels: forward = ``add_layernorm`` (one pass), backward =
+    ``bevmsda_add_layernorm_backward_f32`` (x + res recomputed; one gradient for both addends, column sums for
+    weight / bias).  Replaces torch's add + LayerNorm forward (2 passes) and its 3-kernel backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        x = x.contiguous()
+        res = res.contiguous()
+        y = add_layernorm(x.detach(), res.detach(), weight.detach(), bias.detach(), eps)
+        if y is None:
+            raise RuntimeError("bevmsda: add_layernorm does not cover this call")
+        ctx.save_for_backward(x, res, weight)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, res, weight = ctx.saved_tensors
+        C = x.shape[-1]
+        g = g.float().contiguous()
+        gx = torch.empty_like(x)
+        gwb = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bevmsda_add_layernorm_backward_f32(
+                _ptr(x), _ptr(res), _ptr(weight), _ptr(g), ctx.eps, x.numel() // C, C, _ptr(gx), _ptr(gwb[0]),
+                _ptr(gwb[1]), torch.cuda.current_stream().cuda_stream), "add_layernorm backward")
+        return gx, gx, gwb[0], gwb[1], None
+
+
+def add_layernorm_autograd(x, res, norm):
+    """``norm(x + res)`` with gradients, or ``None`` when the kernels do not cover the call."""
+    C = x.shape[-1]
+    if not (_FUSED_TRAIN["enabled"] and x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32
+            and res.shape == x.shape and C in (256, 512) and isinstance(norm, torch.nn.LayerNorm)
+            and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32
+            and tuple(norm.normalized_shape) == (C,) and not torch.is_autocast_enabled()):
+        return None
+    return _AddLayerNormFunction.apply(x, res, norm.weight, norm.bias, norm.eps)
+
+
 def gather_mean(rows, idx, scale):
     """out[q] = scale[q] * sum_j rows[idx[q, j]] (idx int32, -1 = empty): the SCA
     scatter-add + camera-count division as a gather (``bevmsda_gather_mean_f32``)."""

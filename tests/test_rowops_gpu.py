@@ -57,3 +57,34 @@ def test_ffn_inference_path_matches_sequential():
         fast = ffn(x)
         slow = x + ffn.layers(x)
     torch.testing.assert_close(fast, slow, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,C", [(1, 256), (37, 256), (40000, 256), (5003, 512)])
+def test_add_layernorm_autograd_matches_torch(rows, C):
+    """``ops.add_layernorm_autograd`` (forward row kernel + ``bevmsda_add_layernorm_backward_f32``) against
+    torch's add + LayerNorm under autograd: output, the (shared) gradient of both addends, weight / bias
+    gradients (column sums over all rows through per-block partials + atomics)."""
+    from bevformer_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).to(DEV)
+    res = torch.randn(rows, C, generator=g).to(DEV)
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.3 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    gout = torch.randn(rows, C, generator=g).to(DEV)
+    x1, r1 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = ops.add_layernorm_autograd(x1, r1, norm)
+    assert y is not None
+    y.backward(gout)
+    got = (y.detach(), x1.grad.clone(), r1.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone())
+    norm.weight.grad = norm.bias.grad = None
+    x2, r2 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    want = norm(x2 + r2)
+    want.backward(gout)
+    torch.testing.assert_close(got[0], want.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got[1], x2.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[2], r2.grad, rtol=1e-4, atol=1e-5)
+    tol = dict(rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5))
+    torch.testing.assert_close(got[3], norm.weight.grad, **tol)
+    torch.testing.assert_close(got[4], norm.bias.grad, **tol)
