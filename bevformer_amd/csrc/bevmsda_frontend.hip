@@ -75,4 +75,28 @@ int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, co
   return front_launch<true>(desc, f, stream);
 }
 
+int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_attn, const float *attn,
+                                      const int32_t *q_rows, int64_t slots, int J, const int64_t *spatial_shapes,
+                                      const bevmsda_fused_desc *desc, float *grad_offs, float *grad_logits,
+                                      void *stream) {
+  bevmsda::FrontArgs f{};
+  const int rc = front_common(desc, f);
+  if (rc != BEVMSDA_OK) return rc;
+  if (slots < 0 || J < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (desc->K != 1 || !(desc->L == 1 || desc->L == 2 || desc->L == 4)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (slots == 0) return BEVMSDA_OK;
+  if (!grad_loc || !grad_attn || !attn || !q_rows || !spatial_shapes || !grad_offs || !grad_logits) return BEVMSDA_ERR_NULL_POINTER;
+  if (mis8(grad_loc) || mis4(grad_attn) || mis4(attn) || mis4(q_rows) || mis8(grad_offs) || mis4(grad_logits)) return BEVMSDA_ERR_MISALIGNED;
+  f.shapes = spatial_shapes; f.grad_loc = grad_loc; f.grad_attn = grad_attn; f.attn_in = attn;
+  f.grad_offs = grad_offs; f.grad_logits = grad_logits;
+  const long long threads = static_cast<long long>(slots) * desc->M * desc->L * desc->P;
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (desc->P == 8) hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<8>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J);
+  else hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<4>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
 }  // extern "C"

@@ -167,4 +167,39 @@ __global__ void __launch_bounds__(256) frontend_chain_flat_kernel(const FrontArg
   }
 }
 
+// Chain pass as a GATHER over the rows of a projection row (q_rows (slots, J) int32, -1 = none: the frame plan's
+// table of the (camera, query) rows of every BEV query): one thread per (slot, head, level, point) walks the <= J
+// rows of its slot and STORES the sums — no atomics, no zero fill of the gradient matrix, a fixed summation order.
+// K = 1 (SpatialCrossAttention); L * PT a power of two <= 32.
+template <int PT>
+__global__ void __launch_bounds__(256) frontend_chain_gather_kernel(const FrontArgs f, const int32_t *__restrict__ q_rows,
+                                                                   long slots, int J) {
+  const int LP = f.L * PT;
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  const int lp = static_cast<int>(t % LP);
+  long g = t / LP;
+  const int m = static_cast<int>(g % f.M);
+  long sl = g / f.M;
+  const bool active = sl < slots;
+  if (!active) sl = slots - 1;
+  const int l = lp / PT;
+  const float W = static_cast<float>(f.shapes[2 * l + 1]), H = static_cast<float>(f.shapes[2 * l]);
+  float glogit = 0.f, gx = 0.f, gy = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const int r = q_rows[sl * J + j];                // uniform over the LP lanes of a group
+    if (r < 0) continue;
+    const long o = (static_cast<long>(r) * f.M + m) * LP + lp;
+    const float aw = f.attn_in[o], ga = f.grad_attn[o];
+    float dot = aw * ga;
+    for (int s = 1; s < LP; s <<= 1) dot += __shfl_xor(dot, s, 64);
+    const float2 gl = reinterpret_cast<const float2 *>(f.grad_loc)[o];
+    glogit += aw * (ga - dot);
+    gx += gl.x / W;
+    gy += gl.y / H;
+  }
+  if (!active) return;
+  f.grad_logits[sl * f.proj_row + m * f.lg_head + lp] = glogit;
+  *reinterpret_cast<float2 *>(f.grad_offs + sl * f.proj_row + m * f.off_head + lp * 2) = make_float2(gx, gy);
+}
+
 }  // namespace bevmsda

@@ -135,7 +135,8 @@ class MSDeformableAttention3D(BaseModule):
         return v.view(value.shape[0], value.shape[1], self.num_heads, -1)
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
-                                       spatial_shapes, level_start_index, frame_plan=None, autograd=False):
+                                       spatial_shapes, level_start_index, frame_plan=None, autograd=False,
+                                       q_rows=None):
         """queries (Q, C) projected once; row r samples with the projection row
         ``row_src[r]`` and its own anchors ``row_ref[r]`` -> (R, C), or None when
         the fused kernel does not cover the shape.  ``autograd``: through
@@ -153,7 +154,8 @@ class MSDeformableAttention3D(BaseModule):
             return ops.msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off,
                                            row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
                                            off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,
-                                           vmul=1, vadd=0, row_src=row_src, tag="sca_fwd").to(queries.dtype)
+                                           vmul=1, vadd=0, row_src=row_src, q_rows=q_rows,
+                                           tag="sca_fwd").to(queries.dtype)
         lds = {}
         if frame_plan is not None and frame_plan.dynamic:
             # row count on the device (geometry.DevicePlanner); launch sized by the planner's hint
@@ -296,7 +298,8 @@ class SpatialCrossAttention(BaseModule):
                 # projection through row_src; its backward accumulates over the cameras of a query
                 out_rows = da.forward_rows_shared_projection(
                     query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
-                    row_query.to(torch.int32), spatial_shapes, level_start_index, autograd=True)
+                    row_query.to(torch.int32), spatial_shapes, level_start_index, autograd=True,
+                    q_rows=frame_plan.q_rows if frame_plan is not None else None)
             if out_rows is None:
                 q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
                 out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,

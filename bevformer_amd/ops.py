@@ -314,7 +314,7 @@ class _FusedSampleFunction(Function):
     1 / (W, H) back onto the projection rows, accumulated over the rows that share one."""
 
     @staticmethod
-    def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag):
+    def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None):
         out = msda_fused(value.detach(), shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
                          tag=tag, **meta)
         if out is None:
@@ -323,6 +323,7 @@ class _FusedSampleFunction(Function):
                               row_batch if row_batch is not None else shapes.new_empty(0),
                               row_src if row_src is not None else shapes.new_empty(0))
         ctx.n_off, ctx.meta = n_off, meta
+        ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
         return out
 
     @staticmethod
@@ -371,21 +372,35 @@ class _FusedSampleFunction(Function):
                 _lib.check(lib.bevmsda_backward_ragged_f32(
                     _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
                     RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
-            gproj = torch.zeros_like(proj) if row_src is not None else torch.empty_like(proj)
-            glogits = gproj[:, ctx.n_off:]
-            _lib.check(lib.bevmsda_frontend_chain_f32(
-                _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
-                ctypes.byref(desc), gproj.data_ptr(), glogits.data_ptr(), st), "fused backward: chain")
-        return gv, gproj, None, None, None, None, None, None, None, None
+            qr = ctx.q_rows
+            rc = _lib.ERR_UNSUPPORTED
+            if row_src is not None and qr is not None and K == 1 and qr.shape[0] == proj.shape[0]:
+                gproj = torch.empty_like(proj)
+                rc = lib.bevmsda_frontend_chain_gather_f32(
+                    _ptr(gl), _ptr(ga), _ptr(attn), _ptr(qr), qr.shape[0], qr.shape[1], _ptr(shapes),
+                    ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st)
+                if rc != _lib.ERR_UNSUPPORTED:
+                    _lib.check(rc, "fused backward: chain (gather)")
+            if rc == _lib.ERR_UNSUPPORTED:
+                gproj = torch.zeros_like(proj)
+                _lib.check(lib.bevmsda_frontend_chain_f32(
+                    _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
+                    ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")
+        return gv, gproj, None, None, None, None, None, None, None, None, None
 
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
-                        tag="msda_fwd", **meta):
+                        q_rows=None, tag="msda_fwd", **meta):
     """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (fp32 storage, D = 32; the caller checks
     ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
-    columns, logits behind them, every column of a row used by exactly one (head, queue entry, level, point))."""
+    columns, logits behind them, every column of a row used by exactly one (head, queue entry, level, point)).
+    ``q_rows`` (slots, J): the rows that read each projection row (inverse of ``row_src``) — with it the
+    backward's last step is a gather (stores) instead of atomics."""
+    if q_rows is not None:
+        _req(q_rows.dtype == torch.int32 and q_rows.dim() == 2 and q_rows.is_contiguous() and q_rows.device == proj.device,
+             "bevmsda: q_rows must be a contiguous int32 (slots, J) device tensor")
     return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
-                                      meta, tag)
+                                      meta, tag, q_rows)
 
 
 def fold_extra_rows(rows, q_rows_all, n_extra):
@@ -850,8 +865,10 @@ def linear_wgrad(g, x, with_bias, *, tag="linear_dw"):
         return None, None
     g, ldg = _rows2d(g, N)
     x, ldx = _rows2d(x, K)
-    gw = torch.zeros((N, K), dtype=torch.float32, device=g.device)
-    gb = torch.zeros(N, dtype=torch.float32, device=g.device) if with_bias else None
+    # (one zero fill for both accumulators)
+    buf = torch.zeros(N * K + (N if with_bias else 0), dtype=torch.float32, device=g.device)
+    gw = buf[:N * K].view(N, K)
+    gb = buf[N * K:] if with_bias else None
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * (N + K) + N * K)) if cb is not None else _NoTimer()

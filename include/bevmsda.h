@@ -220,6 +220,13 @@ int bevmsda_frontend_expand_f32(const float *offs, const float *logits, const fl
 int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, const float *attn, const int32_t *row_src,
                                const int64_t *spatial_shapes, const bevmsda_fused_desc *desc, float *grad_offs,
                                float *grad_logits, void *stream);
+/* Step 3 as a gather (K = 1, L in {1, 2, 4}): `q_rows` (slots, J) int32 lists the rows that read projection row
+ * `slot` (-1 = none; the frame plan's table, spatial_cross_attention.py:136-153 inverted); every element of the
+ * gradient matrix rows [0, slots) is STORED (no atomics, no zeroing by the caller, fixed summation order). */
+int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_attn, const float *attn,
+                                      const int32_t *q_rows, int64_t slots, int J, const int64_t *spatial_shapes,
+                                      const bevmsda_fused_desc *desc, float *grad_offs, float *grad_logits,
+                                      void *stream);
 
 /* bevmsda_fused_forward_f32 / _rows_f32 for SpatialCrossAttention with the two COARSE feature levels of a
  * (camera, head) patch served from LDS while the two fine levels stream through the vector-memory path

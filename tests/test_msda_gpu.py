@@ -312,6 +312,14 @@ def test_fused_autograd_function_matches_unfused_autograd(case):
         out.backward(gout)
         got = (out.detach(), value.grad.clone(), proj.grad.clone())
         value.grad = proj.grad = None
+        # the same with the rows of every projection row given: last backward step as a gather (stores)
+        from bevformer_amd.modules.geometry import build_q_rows
+        out = ops.msda_fused_autograd(value, sh, st, proj, n_off, ref, row_batch, row_src=row_src,
+                                      q_rows=build_q_rows(row_src.long(), Nq), **meta)
+        out.backward(gout)
+        torch.testing.assert_close(proj.grad, got[2], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(value.grad, got[1], rtol=1e-3, atol=1e-4)
+        value.grad = proj.grad = None
         # torch statement: point p uses anchor p % Dz (spatial_cross_attention.py:357-372)
         rows = proj[row_src.long()]
         off = rows[:, :n_off].reshape(R, M, L, P, 2)
