@@ -344,7 +344,7 @@ def capture(step, fence):
     return graph, out
 
 
-def make_queue_step(cfg, workload, queue, dev):
+def make_queue_step(cfg, workload, queue, dev, graph=True):
     """One scene of ``queue`` frames through ``get_bev_features`` with a rolling history BEV (frame i's BEV is
     frame i + 1's history; frame 0 opens the scene): BASELINE configs[4]'s history queue on one GPU.  The
     history driver (bevformer_amd.history.BevHistory = detectors/bevformer.py:236-269) turns ABSOLUTE can-bus
@@ -352,14 +352,13 @@ def make_queue_step(cfg, workload, queue, dev):
     import copy as _copy
     import bevformer_amd
     from bevformer_amd import synthetic as S
-    from bevformer_amd.history import BevHistory
+    from bevformer_amd.history import BevHistory, GraphedBevHistory
     tr = bevformer_amd.build_transformer(S.transformer_cfg(workload)).eval()
     tr.init_weights()
     tr.encoder = cfg.enc                   # the encoder of `cfg` (trained-like weights, tiling if enabled)
     tr = tr.to(dev)
     mlvl, bq, tkw = S.make_transformer_inputs(workload, seed=0, temporal=False, device=dev)
     tkw.pop("prev_bev")
-    hist = BevHistory()
     queue_metas = []
     for i in range(queue):
         m = _copy.deepcopy(tkw["img_metas"])
@@ -369,15 +368,23 @@ def make_queue_step(cfg, workload, queue, dev):
         queue_metas.append(m)
     tkw_rest = {k: v for k, v in tkw.items() if k != "img_metas"}
 
+    def bev_fn(f, m, p):
+        return tr.get_bev_features(f, bq, prev_bev=p, img_metas=m, **tkw_rest)
+
+    # graph mode: prologue + frame plan + encoder replayed from two captured HIP graphs (first frame of the
+    # scene / frame with history); the host runs the history state machine and refreshes the device-side pose
+    # and camera matrices (bevformer_amd.history.GraphedBevHistory)
+    hist = GraphedBevHistory(bev_fn, mlvl) if graph else BevHistory()
+
     def step():
         hist.reset()
         out_q = None
         with torch.no_grad():
             for i in range(queue):
-                out_q = hist.step(lambda f, m, p: tr.get_bev_features(f, bq, prev_bev=p, img_metas=m, **tkw_rest),
-                                  mlvl, queue_metas[i])
+                out_q = hist.step(bev_fn, mlvl, queue_metas[i])
         return out_q
 
+    step.launch_mode = "hip graph replay per frame (2 graphs)" if graph else "eager"
     return step
 
 
@@ -386,7 +393,7 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
     for forward + backward and for the history queue), fresh geometry per step as in the main run."""
     cfg = Config(args, dev, workload, gemm, storage, backward, args.first_frame, 1, False)
     cfg.modes()
-    step = make_queue_step(cfg, workload, queue, dev) if queue else cfg.encoder_step
+    step = make_queue_step(cfg, workload, queue, dev, graph=args.graph != "off") if queue else cfg.encoder_step
     for _ in range(2):
         step()
     fence()
@@ -404,6 +411,7 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
                ms_per_step=statistics.median(per), ms_per_step_min=min(per), steps=steps, windows=windows,
                queries_per_s=cfg.Q * max(1, queue) / (statistics.median(per) * 1e-3), launch_mode=note)
     if queue:
+        res["launch_mode"] = step.launch_mode
         res["frames_per_step"] = queue
         res["note"] = ("get_bev_features over a scene of %d frames with a rolling history BEV (can-bus MLP, shift, "
                        "rotation of the history, encoder) per step" % queue)
@@ -494,7 +502,7 @@ def main():
     ops.set_gemm_timer(timer.gemm)
     w, Q = cfg.w, cfg.Q
 
-    queue_step = make_queue_step(cfg, args.workload, args.queue, dev) if args.queue > 0 else None
+    queue_step = make_queue_step(cfg, args.workload, args.queue, dev, graph=args.graph != "off") if args.queue > 0 else None
 
     def step():
         if queue_step is not None:
@@ -533,7 +541,15 @@ def main():
             graph = None
             graph_note = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
             torch.cuda.synchronize()
-    if graph is None:
+    if graph is None and queue_step is not None and getattr(queue_step, "launch_mode", "eager") != "eager":
+        # the queue replays its own graphs: kernel durations from one eager pass of the same frames
+        eager_q = make_queue_step(cfg, args.workload, args.queue, dev, graph=False)
+        timer.enabled = True
+        eager_q()
+        fence()
+        timer.enabled = False
+        graph_note = queue_step.launch_mode
+    elif graph is None:
         timer.enabled = not timer.events
     ts = timed_windows(cfg, step, fence, args.steps, 1, graph)       # window 0 carries the in-region events
     timer.enabled = False

@@ -117,6 +117,8 @@ SIGNATURES = {
                                        _c_int),
     "bevmsda_rotate_bev_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int, _c_int,
                                 ctypes.POINTER(ctypes.c_float), _c_void_p], _c_int),
+    "bevmsda_rotate_bev_dev_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int, _c_int,
+                                _c_void_p, _c_void_p], _c_int),
     "bevmsda_flatten_feats_f32": ([_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p], _c_int),
     "bevmsda_forward_bf16_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                              ctypes.POINTER(Tuning)], _c_int),

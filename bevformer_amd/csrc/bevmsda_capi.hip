@@ -723,19 +723,37 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+static int rotate_launch(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
+                         const float *theta, const float *theta_dev, void *stream);
+
 int bevmsda_rotate_bev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
                            const float *theta, void *stream) {
+  if (!theta) return BEVMSDA_ERR_NULL_POINTER;
+  return rotate_launch(src, ld_src, dst, ld_dst, H, W, C, theta, nullptr, stream);
+}
+
+int bevmsda_rotate_bev_dev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
+                               const float *theta_dev, void *stream) {
+  if (!theta_dev) return BEVMSDA_ERR_NULL_POINTER;
+  if ((reinterpret_cast<uintptr_t>(theta_dev) & 3u) != 0) return BEVMSDA_ERR_MISALIGNED;
+  return rotate_launch(src, ld_src, dst, ld_dst, H, W, C, nullptr, theta_dev, stream);
+}
+
+static int rotate_launch(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
+                         const float *theta, const float *theta_dev, void *stream) {
   if (H < 0 || W < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (C != 256 && C != 512) return BEVMSDA_ERR_UNSUPPORTED;
   if (H == 0 || W == 0) return BEVMSDA_OK;
-  if (!src || !dst || !theta) return BEVMSDA_ERR_NULL_POINTER;
+  if (!src || !dst) return BEVMSDA_ERR_NULL_POINTER;
   if (ld_src < C || ld_dst < C) return BEVMSDA_ERR_BAD_SHAPE;
   if (ld_src % 4 != 0 || ld_dst % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
   if (misaligned(src) || misaligned(dst)) return BEVMSDA_ERR_MISALIGNED;
   if (src == dst) return BEVMSDA_ERR_BAD_OPTION;          // a gather cannot run in place
   bevmsda::RotateArgs a;
   a.src = src; a.dst = dst; a.ld_src = ld_src; a.ld_dst = ld_dst; a.H = H; a.W = W; a.C = C;
-  a.t00 = theta[0]; a.t01 = theta[1]; a.t02 = theta[2]; a.t10 = theta[3]; a.t11 = theta[4]; a.t12 = theta[5];
+  a.theta_dev = theta_dev;
+  if (theta) { a.t00 = theta[0]; a.t01 = theta[1]; a.t02 = theta[2]; a.t10 = theta[3]; a.t11 = theta[4]; a.t12 = theta[5]; }
+  else a.t00 = a.t01 = a.t02 = a.t10 = a.t11 = a.t12 = 0.f;
   const long long nb = (static_cast<long long>(H) * W + 3) / 4;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream);

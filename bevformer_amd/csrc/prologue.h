@@ -26,6 +26,8 @@ struct RotateArgs {
   long ld_src, ld_dst;
   int H, W, C;        // C = 256 * VPL floats per row
   float t00, t01, t02, t10, t11, t12;   // inverse affine matrix rows, already divided by (W/2, H/2)
+  const float *theta_dev;               // when set: the six values above are read from DEVICE memory instead (a
+                                        // captured launch then follows the pose of every replayed frame)
 };
 
 template <int VPL>
@@ -37,9 +39,12 @@ __global__ void __launch_bounds__(256) rotate_bev_kernel(const RotateArgs a) {
   // base grid of pixel centres: linspace(-W/2 + 0.5, W/2 - 0.5, W) (exact: step 1)
   const float bx = static_cast<float>(ox) + (0.5f - 0.5f * static_cast<float>(a.W));
   const float by = static_cast<float>(oy) + (0.5f - 0.5f * static_cast<float>(a.H));
+  const float t00 = a.theta_dev ? a.theta_dev[0] : a.t00, t01 = a.theta_dev ? a.theta_dev[1] : a.t01;
+  const float t02 = a.theta_dev ? a.theta_dev[2] : a.t02, t10 = a.theta_dev ? a.theta_dev[3] : a.t10;
+  const float t11 = a.theta_dev ? a.theta_dev[4] : a.t11, t12 = a.theta_dev ? a.theta_dev[5] : a.t12;
   // (bx, by, 1) . rescaled_theta, products and sums rounded separately (no contraction)
-  const float gx = __fadd_rn(__fadd_rn(__fmul_rn(bx, a.t00), __fmul_rn(by, a.t01)), a.t02);
-  const float gy = __fadd_rn(__fadd_rn(__fmul_rn(bx, a.t10), __fmul_rn(by, a.t11)), a.t12);
+  const float gx = __fadd_rn(__fadd_rn(__fmul_rn(bx, t00), __fmul_rn(by, t01)), t02);
+  const float gy = __fadd_rn(__fadd_rn(__fmul_rn(bx, t10), __fmul_rn(by, t11)), t12);
   const float fx = __fdiv_rn(__fadd_rn(__fmul_rn(__fadd_rn(gx, 1.f), static_cast<float>(a.W)), -1.f), 2.f);
   const float fy = __fdiv_rn(__fadd_rn(__fmul_rn(__fadd_rn(gy, 1.f), static_cast<float>(a.H)), -1.f), 2.f);
   const float rx = rintf(fx), ry = rintf(fy);          // round half to even (nearbyint)

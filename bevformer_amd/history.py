@@ -80,3 +80,108 @@ class BevHistory:
         info["prev_angle"] = tmp_angle
         info["prev_bev"] = new_prev_bev
         return new_prev_bev
+
+
+class GraphedBevHistory(BevHistory):
+    """``BevHistory`` whose per-frame device work — the prologue of ``get_bev_features`` (pose -> shift,
+    rotation of the history BEV, can-bus MLP; camera-feature flatten), the frame plan and the encoder — is
+    replayed from two captured HIP graphs (a scene's first frame / a frame with history).
+
+    The host keeps running the reference's state machine (scene reset, absolute pose -> delta,
+    detectors/bevformer.py:243-268) and refreshes two small DEVICE tensors per frame — the rewritten can-bus
+    vector (float64, as the reference's numpy arithmetic) and the camera matrices — which the captured kernels
+    read: ``PerceptionTransformer.get_bev_features`` takes the pose from device tensors
+    (``bev_shift_device``, ``ops.rotation_theta_device``, ``bevmsda_rotate_bev_dev_f32``) and the encoder plans
+    the frame on the device (``csrc/frame_plan.h``), so nothing in the step reads the pose on the host.
+
+    ``bev_fn(mlvl_feats, img_metas, prev_bev)`` as for ``BevHistory``; ``mlvl_feats`` are STATIC buffers (the
+    backbone writes each frame's features into them; ``step`` copies when handed other tensors).  The
+    returned BEV is a static buffer too: it is overwritten by the next ``step``."""
+
+    def __init__(self, bev_fn, mlvl_feats, video_test_mode=True):
+        super().__init__(video_test_mode)
+        self.bev_fn = bev_fn
+        self.feats = list(mlvl_feats)
+        self.device = self.feats[0].device
+        self.graphs = {}
+        self.can_bus = None            # (bs, 18) float64, device
+        self.l2i = None                # (bs, Nc, 4, 4) float32, device
+        self.static_metas = None
+        self.prev = None               # (bs, Q, C): the history the next frame reads
+        self.out = {}
+
+    def _static_inputs(self, metas):
+        import numpy as np
+        bs = len(metas)
+        cb = torch.tensor(np.array([np.asarray(m["can_bus"], dtype=np.float64) for m in metas]), dtype=torch.float64)
+        l2i = torch.tensor(np.array([np.asarray(m["lidar2img"], dtype=np.float64) for m in metas]), dtype=torch.float32)
+        if self.can_bus is None:
+            self.can_bus = cb.to(self.device)
+            self.l2i = l2i.to(self.device)
+            self.static_metas = []
+            for i in range(bs):
+                m = {k: v for k, v in metas[i].items() if k not in ("can_bus", "lidar2img")}
+                m["can_bus"] = self.can_bus[i]
+                m["lidar2img"] = self.l2i[i]
+                self.static_metas.append(m)
+        else:
+            self.can_bus.copy_(cb, non_blocking=True)
+            self.l2i.copy_(l2i, non_blocking=True)
+
+    def _run(self, has_prev):
+        out = self.bev_fn(self.feats, self.static_metas, self.prev if has_prev else None)
+        if self.prev is None:
+            self.prev = torch.empty_like(out)
+        self.prev.copy_(out)           # the next frame's history (inside the captured step)
+        return out
+
+    def step(self, bev_fn, mlvl_feats, img_metas):
+        """Same contract as ``BevHistory.step`` (``bev_fn`` is ignored: the one given at construction is what
+        the graphs hold)."""
+        info = self.prev_frame_info
+        if img_metas[0]["scene_token"] != info["scene_token"]:
+            info["prev_bev"] = None
+        info["scene_token"] = img_metas[0]["scene_token"]
+        if not self.video_test_mode:
+            info["prev_bev"] = None
+        metas = copy.deepcopy(img_metas)
+        tmp_pos = copy.deepcopy(metas[0]["can_bus"][:3])
+        tmp_angle = copy.deepcopy(metas[0]["can_bus"][-1])
+        has_prev = info["prev_bev"] is not None
+        if has_prev:
+            metas[0]["can_bus"][:3] -= info["prev_pos"]
+            metas[0]["can_bus"][-1] -= info["prev_angle"]
+        else:
+            metas[0]["can_bus"][-1] = 0
+            metas[0]["can_bus"][:3] = 0
+        self.rewritten_metas = metas
+        for dst, src in zip(self.feats, mlvl_feats):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self._static_inputs(metas)
+        with torch.no_grad():
+            graph = self.graphs.get(has_prev)
+            if graph is None:
+                # first frame of this kind: two eager runs (planners, weight images, allocator state) and the
+                # capture; the eager runs advance the stored history, so it is put back before the replay
+                saved = self.prev.clone() if has_prev else None
+                self._run(has_prev)
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    if has_prev:
+                        self.prev.copy_(saved)
+                    self._run(has_prev)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.out[has_prev] = self._run(has_prev)
+                self.graphs[has_prev] = graph
+                if has_prev:
+                    self.prev.copy_(saved)
+            graph.replay()
+        info["prev_pos"] = tmp_pos
+        info["prev_angle"] = tmp_angle
+        info["prev_bev"] = self.prev
+        return self.out[has_prev]

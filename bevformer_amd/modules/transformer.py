@@ -94,6 +94,21 @@ class PerceptionTransformer(BaseModule):
         shift_x = translation_length * np.sin(bev_angle / 180 * np.pi) / grid_length_x / bev_w
         return np.stack([shift_x * use_shift, shift_y * use_shift], -1)
 
+    @staticmethod
+    def bev_shift_device(can_bus, bev_h, bev_w, grid_length, use_shift):
+        """``bev_shift`` for a DEVICE can-bus tensor (bs, 18): the same float64 statements as torch ops —
+        no host read, so the whole prologue can sit inside a captured step.  -> (bs, 2) float64."""
+        cb = can_bus.to(torch.float64)
+        delta_x, delta_y = cb[:, 0], cb[:, 1]
+        ego_angle = cb[:, -2] / np.pi * 180
+        grid_length_y, grid_length_x = grid_length[0], grid_length[1]
+        translation_length = torch.sqrt(delta_x ** 2 + delta_y ** 2)
+        translation_angle = torch.atan2(delta_y, delta_x) / np.pi * 180
+        bev_angle = ego_angle - translation_angle
+        shift_y = translation_length * torch.cos(bev_angle / 180 * np.pi) / grid_length_y / bev_h
+        shift_x = translation_length * torch.sin(bev_angle / 180 * np.pi) / grid_length_x / bev_w
+        return torch.stack([shift_x * use_shift, shift_y * use_shift], -1)
+
     @auto_fp16(apply_to=("mlvl_feats", "bev_queries", "prev_bev", "bev_pos"))
     def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512],
                          bev_pos=None, prev_bev=None, **kwargs):
@@ -103,16 +118,27 @@ class PerceptionTransformer(BaseModule):
         img_metas = kwargs["img_metas"]
         bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
         bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
-        shift = bev_queries.new_tensor(self.bev_shift(img_metas, bev_h, bev_w, grid_length,
-                                                      self.use_shift))
+        # can_bus given as DEVICE tensors (one (18,) per sample, e.g. views of a static buffer the caller
+        # refreshes every frame): shift, rotation and MLP input stay on the device — no host read of the pose
+        # anywhere in the step, which makes it capturable in a HIP graph (bevformer_amd.history.GraphedBevHistory)
+        dev_pose = all(torch.is_tensor(each["can_bus"]) and each["can_bus"].is_cuda for each in img_metas)
+        if dev_pose:
+            can_bus_dev = torch.stack([each["can_bus"].reshape(-1) for each in img_metas])
+            shift = self.bev_shift_device(can_bus_dev, bev_h, bev_w, grid_length, self.use_shift).to(bev_queries.dtype)
+        else:
+            shift = bev_queries.new_tensor(self.bev_shift(img_metas, bev_h, bev_w, grid_length,
+                                                          self.use_shift))
         if prev_bev is not None:
             if prev_bev.shape[1] == bev_h * bev_w:
                 prev_bev = prev_bev.permute(1, 0, 2)
             if self.rotate_prev_bev:
-                angles = [img_metas[i]["can_bus"][-1] for i in range(bs)]
+                angles = can_bus_dev[:, -1] if dev_pose else [img_metas[i]["can_bus"][-1] for i in range(bs)]
                 prev_bev = ops.rotate_bev(prev_bev, angles, self.rotate_center, bev_h, bev_w)
 
-        can_bus = bev_queries.new_tensor(np.array([each["can_bus"] for each in img_metas]))
+        if dev_pose:
+            can_bus = can_bus_dev.to(bev_queries.dtype)
+        else:
+            can_bus = bev_queries.new_tensor(np.array([each["can_bus"] for each in img_metas]))
         can_bus = self.can_bus_mlp(can_bus)[None, :, :]
         bev_queries = bev_queries + can_bus * self.use_can_bus
 

@@ -7,6 +7,7 @@ which is how this package runs SpatialCrossAttention without zero-padded rows.
 Neither has a CPU implementation: CPU tensors raise ``RuntimeError``.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -1003,6 +1004,26 @@ def rotation_theta(angle_deg, center, h, w):
     return (theta / torch.tensor([[0.5 * w], [0.5 * h]], dtype=torch.float32)).reshape(-1).tolist()
 
 
+def rotation_theta_device(angles_deg, center, h, w):
+    """``rotation_theta`` for a DEVICE tensor of angles (bs,) -> (bs, 6) fp32 on the device: the same
+    formulas in float64 device arithmetic, the same fp32 roundings at the end; no host synchronisation
+    (a captured step follows the pose of every replayed frame)."""
+    a = angles_deg.to(torch.float64)
+    cx, cy = 1.0 * (center[0] - w * 0.5), 1.0 * (center[1] - h * 0.5)
+    rot = -a * (math.pi / 180.0)
+    ca, sa = torch.cos(rot), torch.sin(rot)
+    # (a, b, c, d) = (cos, -sin, sin, cos); m = [d, -b, 0, -c, a, 0]
+    m0, m1, m3, m4 = ca, sa, -sa, ca
+    m2 = m0 * (-cx) + m1 * (-cy) + cx
+    m5 = m3 * (-cx) + m4 * (-cy) + cy
+    theta = torch.stack([m0, m1, m2, m3, m4, m5], -1).to(torch.float32)
+    key = ("rot_scale", h, w, str(theta.device))
+    scale = _CONST_CACHE.get(key)
+    if scale is None:
+        scale = _CONST_CACHE[key] = torch.tensor([0.5 * w] * 3 + [0.5 * h] * 3, dtype=torch.float32, device=theta.device)
+    return (theta / scale).contiguous()
+
+
 def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
     """prev_bev (Q, bs, C) -> a new tensor whose batch entry i is rotated by ``angles_deg[i]``
     about ``center`` (nearest, zero fill): ``bevmsda_rotate_bev_f32`` (transformer.py:146-156).
@@ -1026,6 +1047,15 @@ def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
     src = prev_bev.contiguous()
     out = torch.empty_like(src)
     lib = _lib.load()
+    if torch.is_tensor(angles_deg) and angles_deg.is_cuda:
+        theta = rotation_theta_device(angles_deg.reshape(-1), center, bev_h, bev_w)
+        with torch.cuda.device(src.device):
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(bs):
+                rc = lib.bevmsda_rotate_bev_dev_f32(src.data_ptr() + i * C * 4, bs * C, out.data_ptr() + i * C * 4,
+                                                    bs * C, bev_h, bev_w, C, theta.data_ptr() + i * 24, st)
+                _lib.check(rc, "rotate_bev (device pose)")
+        return out
     with torch.cuda.device(src.device):
         st = torch.cuda.current_stream().cuda_stream
         for i in range(bs):
@@ -1034,6 +1064,20 @@ def rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
                                             bs * C, bev_h, bev_w, C, theta, st)
             _lib.check(rc, "rotate_bev")
     return out
+
+
+_CONST_CACHE = {}
+
+
+def _level_tensors(shapes, device):
+    """(spatial_shapes, level_start_index) int64 device tensors of a level shape list, built once per
+    (shapes, device): a host -> device copy per frame is a latency bubble and cannot be captured in a HIP graph."""
+    key = ("levels", shapes, str(device))
+    hit = _CONST_CACHE.get(key)
+    if hit is None:
+        ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+        hit = _CONST_CACHE[key] = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
+    return hit
 
 
 def _flatten_feats_torch(mlvl_feats, cams_embeds, level_embeds):
@@ -1085,6 +1129,5 @@ def flatten_feats(mlvl_feats, cams_embeds, level_embeds):
                                                S, s0, st)
             _lib.check(rc, "flatten_feats")
             s0 += h * w
-    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=f0.device)
-    level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+    spatial_shapes, level_start_index = _level_tensors(tuple(map(tuple, shapes)), f0.device)
     return out, spatial_shapes, level_start_index

@@ -431,6 +431,11 @@ int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_
  * be NULL) — transformer.py:165-184.  C a multiple of 64. */
 int bevmsda_rotate_bev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W,
                            int C, const float *theta, void *stream);
+
+/* The same with the six matrix values in DEVICE memory (`theta_dev`, fp32, read when the kernel runs): a captured
+ * launch follows the ego pose of every replayed frame (detectors/bevformer.py:253-261 feeding transformer.py:146-156). */
+int bevmsda_rotate_bev_dev_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int H, int W, int C,
+                               const float *theta_dev, void *stream);
 int bevmsda_flatten_feats_f32(const float *feat, const float *cams_embeds, const float *level_embed,
                               float *out, int bs, int Nc, int C, int hw, int S, int s0, void *stream);
 

@@ -41,3 +41,31 @@ def test_video_through_the_history_queue(name):
         # the fraction of rows out of tolerance instead of every element
         err = (got - want).abs().amax(-1)
         assert (err > 1e-3).float().mean().item() < 5e-3, err.max().item()
+
+
+@pytest.mark.parametrize("name", ["micro4", "tiny"])
+def test_graph_replayed_history_queue_equals_the_eager_one(name):
+    """``GraphedBevHistory``: prologue (pose from DEVICE tensors: shift, rotation matrix, can-bus MLP input),
+    frame plan and encoder replayed from two captured HIP graphs, against ``BevHistory`` launching the same
+    modules eagerly with the pose read on the host — a video of 6 frames with a scene break (both graphs are
+    captured and then replayed with new poses and camera matrices)."""
+    frames = _video(name, 6, scene_break=4)
+    t, _ = build_transformer_pair(name, device=DEV)
+    mlvl0, _, bq, kw = frames[0]
+    feats = [x.to(DEV) for x in mlvl0]
+    bq_d, pos_d = bq.to(DEV), kw["bev_pos"].to(DEV)       # (no host -> device copies inside a captured step)
+
+    def bev_fn(f, m, p):
+        return t.get_bev_features(f, bq_d, kw["bev_h"], kw["bev_w"], grid_length=kw["grid_length"],
+                                  bev_pos=pos_d, prev_bev=p, img_metas=m)
+
+    eager = history.BevHistory()
+    graphed = history.GraphedBevHistory(bev_fn, feats)
+    for mlvl, metas, _, _ in frames:
+        f = [x.to(DEV) for x in mlvl]
+        want = eager.step(bev_fn, f, metas).clone()
+        got = graphed.step(None, f, metas).clone()
+        # (device float64 cos / sin against the host's: a rotation tie may move single history rows)
+        err = (got - want).abs().amax(-1)
+        assert (err > 1e-3).float().mean().item() < 5e-3, err.max().item()
+    assert set(graphed.graphs) == {False, True}
