@@ -149,7 +149,7 @@ class MSDeformableAttention3D(BaseModule):
         w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
         proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
         if autograd:
-            if value.shape[-1] != 32 or L > 4 or P not in (4, 8) or value.dtype != torch.float32:
+            if value.shape[-1] != 32 or L > 4 or P not in (4, 8) or value.dtype != torch.float32:   # (storage may be bf16)
                 return None
             return ops.msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off,
                                            row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,

@@ -302,8 +302,7 @@ def set_fused_training(flag):
 
 
 def fused_training_wanted(*tensors):
-    return _FUSED["enabled"] and _FUSED_TRAIN["enabled"] and _STORAGE["dtype"] == torch.float32 \
-        and torch.is_grad_enabled() and all(t is None or t.is_cuda for t in tensors) \
+    return _FUSED["enabled"] and _FUSED_TRAIN["enabled"] and torch.is_grad_enabled() and all(t is None or t.is_cuda for t in tensors) \
         and any(t is not None and t.requires_grad for t in tensors) and not torch.is_autocast_enabled()
 
 
@@ -324,6 +323,7 @@ class _FusedSampleFunction(Function):
                               row_batch if row_batch is not None else shapes.new_empty(0),
                               row_src if row_src is not None else shapes.new_empty(0))
         ctx.n_off, ctx.meta = n_off, meta
+        ctx.store = _STORAGE["dtype"]     # the value storage the forward sampled (bf16: rounded copy of `value`)
         ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
         return out
 
@@ -348,7 +348,8 @@ class _FusedSampleFunction(Function):
         loc = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
         attn = torch.empty((RK, M, L, P), dtype=torch.float32, device=dev)
         rbk = torch.empty(RK, dtype=torch.int32, device=dev)
-        value = value.detach().float().contiguous()
+        bf = ctx.store == torch.bfloat16
+        value = value.detach().to(ctx.store).contiguous()      # bf16 storage: the rounded values the forward saw
         proj = proj.detach()
         logits = proj[:, ctx.n_off:]
         with torch.cuda.device(dev):
@@ -359,18 +360,18 @@ class _FusedSampleFunction(Function):
             g = grad_out.float()
             if K > 1:       # out = mean over the queue entries; rows are queue-major
                 g = (g * (1.0 / K)).repeat(K, 1)
-            g = g.contiguous()
+            g = g.to(ctx.store).contiguous()
             gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
             gl = torch.empty_like(loc)
             ga = torch.empty_like(attn)
             if row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
                 # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
                 # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
-                _lib.check(lib.bevmsda_backward_f32(
+                _lib.check((lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
                     _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
                     _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
             else:
-                _lib.check(lib.bevmsda_backward_ragged_f32(
+                _lib.check((lib.bevmsda_backward_ragged_bf16 if bf else lib.bevmsda_backward_ragged_f32)(
                     _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
                     RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
             qr = ctx.q_rows
