@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--simulate-rank", default=None, metavar="R,G",
                     help="time rank R's schedule of a G-GPU BEV-tiled job on this one GPU (no process group; the "
                          "all-gather is replaced by a local copy: bev_tiling.BevTiling.simulate)")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="no HIP-event brackets around the kernels (they also keep the value projections off "
+                         "their side stream): whole-step timing only")
     ap.add_argument("--row-order", default=None, choices=["raster", "image", "polar"],
                     help="order of the ragged SCA rows inside a camera (default: the encoder's)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -498,8 +501,9 @@ def main():
     if args.sca_lds:
         ops.set_sca_lds_level(args.sca_lds == "on")
     timer = KernelTimer()
-    ops.set_kernel_timer(timer)
-    ops.set_gemm_timer(timer.gemm)
+    if not args.no_kernel_timers:
+        ops.set_kernel_timer(timer)
+        ops.set_gemm_timer(timer.gemm)
     w, Q = cfg.w, cfg.Q
 
     queue_step = make_queue_step(cfg, args.workload, args.queue, dev, graph=args.graph != "off") if args.queue > 0 else None
@@ -586,7 +590,9 @@ def main():
             # matrix-core utilisation: the split kernel issues 3 bf16 MFMA products per algorithmic product
             if ops.gemm_mode() != "native":
                 gs["frac_of_bf16_mfma_peak_2500"] = gs["TFLOPs"] * (3 if ops.gemm_mode() == "split" else 1) / 2500.0
-        dom = ks.get("sca_fwd") or next(iter(ks.values()))
+        dom = ks.get("sca_fwd") or next(iter(ks.values()), None)
+        if dom is None:         # --no-kernel-timers: whole-step timing only
+            dom = dict(GBs=float("nan"), avg_us=None, alg_bytes=None, launches=0)
         traffic = None
         if os.path.exists(args.traffic_json):
             try:

@@ -84,13 +84,20 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     // (one memory-side atomic per tap) or the shape does not fit the tiled kernel
     const int G = a.P % 4 == 0 ? 4 : (a.P % 2 == 0 ? 2 : 1);
     // (entries carry the pixel index of a level in 23 bits and the row of the block in 8)
-    const int rpt = (kGvRowsPerBlock * a.P + bevmsda::kGvThreads - 1) / bevmsda::kGvThreads;
+    // 256 rows / 1024 threads per workgroup (one per CU) for single-level calls (TemporalSelfAttention: the
+    // 16 x 16 grid tiles), 128 rows / 512 threads (two per CU: one sorts while the other's flushes drain) for
+    // multi-level calls — measured on the padded base SCA call, image-ordered rows: 1.13 vs 1.27 ms (raster rows:
+    // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  BEVMSDA_GV_ROWS=128 / 256 forces one.
+    static const int gv_forced = [] { const char *e = getenv("BEVMSDA_GV_ROWS"); return e ? atoi(e) : 0; }();
+    const int gv_rows = gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? 128 : kGvRowsPerBlock);
+    const int gv_threads = gv_rows == 128 ? 512 : bevmsda::kGvThreads;
+    const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
     tiled = tiled && 1LL * a.S < (1LL << 23) && a.NQ < (1LL << 30) && 1LL * a.N * (1LL * a.Q * 3 / 512 + 4) * 256 < (1LL << 30);
     if (tiled) {
       bevmsda::GradValueArgs s{};
       s.k = a;
-      s.rows_per_block = kGvRowsPerBlock;
+      s.rows_per_block = gv_rows;
       s.gbits = G == 4 ? 2 : (G == 2 ? 1 : 0);
       long chunks = (a.NQ + s.rows_per_block - 1) / s.rows_per_block;
       if (!a.row_batch && a.L == 1 && a.Q >= 1024 && s.rows_per_block == 256) {
@@ -101,7 +108,7 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       if (chunks * a.M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
       const size_t lds_bytes = (static_cast<size_t>(bevmsda::kGvBuckets) + static_cast<size_t>(s.rows_per_block) * a.P * 8 +
                                 static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4;
-      const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(bevmsda::kGvThreads);
+      const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(gv_threads);
       // BEVMSDA_GV_PROFILE=<hex device address of 8 uint64>: phase clocks of the sort kernel (tools/gvprof.py)
       const char *pe = getenv("BEVMSDA_GV_PROFILE");
       if (pe) s.prof = reinterpret_cast<unsigned long long *>(strtoull(pe, nullptr, 16));
@@ -119,7 +126,14 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);                                                    \
     }                                                                                                                   \
   } while (0)
-      if (rpt == 1) BEVMSDA_GV(1);
+      if (gv_threads == 512) {
+        auto k1 = bevmsda::msda_gradvalue_sort_kernel<T, 1, false, 512>;
+        auto k2 = bevmsda::msda_gradvalue_sort_kernel<T, 2, false, 512>;
+        auto kern = rpt == 1 ? k1 : k2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);
+      } else if (rpt == 1) BEVMSDA_GV(1);
       else BEVMSDA_GV(2);
 #undef BEVMSDA_GV
       // grad_loc / grad_attn: the forward-style gather kernel (buffer loads: value < 2 GiB, P in {4, 8}),

@@ -76,12 +76,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // In-place exclusive scan of cnt[0 .. kGvBuckets] (kGvBuckets + 1 entries, the last one = total) by the
 // whole workgroup: 4 counters per thread.  Two barriers.
-__device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvThreads / 64 ints */) {
+template <int THREADS>
+__device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* THREADS / 64 ints */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int PER = kGvBuckets / kGvThreads;
-  int4 v = reinterpret_cast<int4 *>(cnt)[tid];
-  static_assert(PER == 4, "4 counters per thread");
-  const int s = v.x + v.y + v.z + v.w;
+  constexpr int PER = kGvBuckets / THREADS;
+  static_assert(PER == 4 || PER == 8, "4 or 8 counters per thread");
+  int4 v = reinterpret_cast<int4 *>(cnt)[tid * (PER / 4)];
+  int4 v2 = make_int4(0, 0, 0, 0);
+  if constexpr (PER == 8) v2 = reinterpret_cast<int4 *>(cnt)[tid * 2 + 1];
+  const int s1 = v.x + v.y + v.z + v.w;
+  const int s = s1 + (v2.x + v2.y) + (v2.z + v2.w);
   int inc = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -92,12 +96,16 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvTh
   lds_barrier();
   int base = inc - s, total = 0;
 #pragma unroll
-  for (int w = 0; w < kGvThreads / 64; ++w) {
+  for (int w = 0; w < THREADS / 64; ++w) {
     const int t = wsum[w];
     if (w < wave) base += t;
     total += t;
   }
-  reinterpret_cast<int4 *>(cnt)[tid] = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+  reinterpret_cast<int4 *>(cnt)[tid * (PER / 4)] = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+  if constexpr (PER == 8) {
+    const int b2 = base + s1;
+    reinterpret_cast<int4 *>(cnt)[tid * 2 + 1] = make_int4(b2, b2 + v2.x, b2 + v2.x + v2.y, b2 + v2.x + v2.y + v2.z);
+  }
   lds_barrier();
   return total;
 }
@@ -110,9 +118,11 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* kGvTh
   }
 
 // LDS carve (4-byte words): [cnt: kGvBuckets][entries: rows * P * 4 x 2][grad_out rows: rows * 32][wsum 16][misc 4]
-// RPT = (row, point) records per thread and level = ceil(rows_per_block * P / kGvThreads).
-template <typename T, int RPT, bool PROF = false>
-__global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const GradValueArgs s) {
+// RPT = (row, point) records per thread and level = ceil(rows_per_block * P / THREADS).
+// THREADS = 1024 with 256 rows per workgroup (112 KB of LDS: one workgroup per CU) or 512 with 128 rows (64 KB: two
+// workgroups per CU, one sorting while the other's flushes drain, at the price of a smaller footprint per flush).
+template <typename T, int RPT, bool PROF = false, int THREADS = kGvThreads>
+__global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const GradValueArgs s) {
   unsigned long long t_prev = 0;
   if constexpr (PROF) t_prev = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -123,7 +133,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
   int2 *ent = reinterpret_cast<int2 *>(cnt + kGvBuckets);
   float *gl = reinterpret_cast<float *>(ent + s.rows_per_block * P * 4);
   int *wsum = reinterpret_cast<int *>(gl + static_cast<long>(s.rows_per_block) * D);
-  int *misc = wsum + kGvThreads / 64;
+  int *misc = wsum + THREADS / 64;
   const int tid = threadIdx.x;
   const int m = blockIdx.x % a.M;
   const int chunk = blockIdx.x / a.M;
@@ -156,7 +166,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
   const int xm = (1 << xb) - 1, ym = (1 << yb) - 1;
 
   // grad_out of the chunk's rows and my head -> LDS
-  for (int i = tid; i < (c1 - c0) * 8; i += kGvThreads) {
+  for (int i = tid; i < (c1 - c0) * 8; i += THREADS) {
     const int row = i >> 3, q4 = (i & 7) * 4;
     const int pr = phys(c0 + row);
     reinterpret_cast<float4 *>(gl)[i] = pr < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) :
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       __syncthreads();
       if (tid == 0) misc[0] = c1 - r0;
       __syncthreads();
-      for (int r = r0 + tid; r < c1; r += kGvThreads)
+      for (int r = r0 + tid; r < c1; r += THREADS)
         if (a.row_batch[r] != n0) atomicMin(&misc[0], r - r0);
       __syncthreads();
       r1 = r0 + misc[0];
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       for (int j = 0; j < RPT; ++j) {
         xy[l][j] = make_float2(-8.f, -8.f);             // outside every map: no tap
         aw[l][j] = 0.f;
-        const int i = j * kGvThreads + tid;
+        const int i = j * THREADS + tid;
         if (l < L && i < nrec) {
           const int rw = i / P, p = i - rw * P;
           const int pr = phys(r0 + rw);
@@ -226,7 +236,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       const int H = Hs[l], W = Ws[l];
       float *gv = a.grad_value + ((n0 * a.S + ls[l]) * a.M + m) * D + c;
       // ---- (1) zero the counters
-      reinterpret_cast<int4 *>(cnt)[tid] = make_int4(0, 0, 0, 0);
+      for (int z = tid; z < kGvBuckets / 4; z += THREADS) reinterpret_cast<int4 *>(cnt)[z] = make_int4(0, 0, 0, 0);
       lds_barrier();
       // ---- (2) my records: four taps each, counted into their buckets
       int pix[RPT][4], key[RPT][4], rowj[RPT];
@@ -234,7 +244,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       bool ok[RPT][4];
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
-        const int i = j * kGvThreads + tid;
+        const int i = j * THREADS + tid;
         const int rw = i / P, p = i - rw * P;
         rowj[j] = rw;
         const float x = xy[l][j].x * W - 0.5f, y = xy[l][j].y * H - 0.5f;
@@ -257,7 +267,7 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       lds_barrier();
       GV_TICK(1)
       // ---- (3) scan, place
-      const int total = block_exclusive_scan(cnt, wsum);
+      const int total = block_exclusive_scan<THREADS>(cnt, wsum);
       GV_TICK(2)
 #pragma unroll
       for (int j = 0; j < RPT; ++j)
@@ -271,8 +281,8 @@ __global__ void __launch_bounds__(kGvThreads) msda_gradvalue_sort_kernel(const G
       GV_TICK(3)
       // ---- (4) segmented reduction: my 1/32 of the sorted entries, one atomic per pixel run
       {
-        const int e0 = static_cast<int>(static_cast<long>(total) * half / (kGvThreads / 32));
-        const int e1 = static_cast<int>(static_cast<long>(total) * (half + 1) / (kGvThreads / 32));
+        const int e0 = static_cast<int>(static_cast<long>(total) * half / (THREADS / 32));
+        const int e1 = static_cast<int>(static_cast<long>(total) * (half + 1) / (THREADS / 32));
         int cur = -1;
         float acc = 0.f;
         // 8 entries at a time: their LDS reads (entry, then grad_out of its row) are issued together,
