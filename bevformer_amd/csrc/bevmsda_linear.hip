@@ -5,6 +5,7 @@
 #include "linear_dma.h"
 #include "linear_ws.h"
 #include "linear_pipe.h"
+#include "linear_areg.h"
 #include "wgrad_mfma.h"
 
 namespace {
@@ -12,6 +13,7 @@ namespace {
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
 constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
+constexpr int kLinearAregMinN = 0;               // linear_areg.h as the default for N >= this (0: never; set from measurements)
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
 constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
 constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
@@ -103,6 +105,33 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
       a.nblk_n = static_cast<int>(nbn);
       if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_dma_kernel<3>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((bevmsda::linear_dma_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
+      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+    }
+  }
+  // activation-stationary kernel (linear_areg.h): desc->variant = 132 forces it (BEVMSDA_ERR_UNSUPPORTED when not
+  // covered), desc->reserved[1] = 1 disables it
+  {
+    const bool covered = wpack && !add && d->K0 == 256 && d->K1 == 0 && (d->N % 128) == 0 && (d->ldy % 4) == 0 &&
+                         (gcols % 4) == 0 && !misaligned(y) && (!bias || !misaligned(bias)) &&
+                         (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
+    if (d->variant == 132 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
+    if (covered && (d->variant == 132 || (d->variant == 0 && d->reserved[1] == 0 && kLinearAregMinN > 0 &&
+                                          d->N >= kLinearAregMinN))) {
+      const long long nb = (d->M + bevmsda::kAregRows - 1) / bevmsda::kAregRows;
+      if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+      a.nblk_n = d->N / 128;
+      a.nblk_m = static_cast<int>(nb);
+      const dim3 grid(static_cast<unsigned>(nb)), block(bevmsda::kAregThreads);
+#define BEVMSDA_AREG(NP_)                                                                                             \
+  do {                                                                                                                \
+    auto kern = bevmsda::linear_areg_kernel<NP_>;                                                                     \
+    const int dyn = 6 * ((NP_) == 3 ? 2 : 1) * bevmsda::kAregPlane * 2;                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != \
+        hipSuccess) return BEVMSDA_ERR_LAUNCH;                                                                        \
+    hipLaunchKernelGGL(kern, grid, block, dyn, st, a);                                                                \
+  } while (0)
+      if (d->precision == 0) BEVMSDA_AREG(3); else BEVMSDA_AREG(1);
+#undef BEVMSDA_AREG
       return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
     }
   }

@@ -524,7 +524,7 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
          "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "1") == "1",
          # second projection kernel (csrc/linear_dma.h: activations by LDS-DMA, one barrier per chunk) for the
          # calls it covers (packed weights, no addend / gather); None = library default
-         "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
+         "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -587,9 +587,10 @@ def set_gemm_dma(flag):
 
 def set_gemm_kernel(name):
     """Which projection kernel serves the calls several of them cover: ``None`` (library default), ``"first"``
-    (linear_mfma.h), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined)."""
-    assert name in (None, "first", "dma", "ws", "pipe")
-    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe"}[name]
+    (linear_mfma.h), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined), ``"areg"`` (linear_areg.h,
+    activation rows resident in registers)."""
+    assert name in (None, "first", "dma", "ws", "pipe", "areg")
+    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe", "areg": "areg"}[name]
 
 
 def _ws_covers(M, N, K0, K1, a0, a1, mode):
@@ -672,7 +673,10 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
     elif _GEMM["dma"] is not None and blob is not None:
-        if _GEMM["dma"] == "pipe":
+        if _GEMM["dma"] == "areg":
+            if a0 is None and a1 is None and K0 == 256 and K1 == 0 and N % 128 == 0:
+                desc.variant = 132          # force the activation-stationary kernel
+        elif _GEMM["dma"] == "pipe":
             if a0 is None and a1 is None and (K0 + K1) // 32 in (8, 16):
                 desc.variant = 131          # force the software-pipelined kernel
         elif _GEMM["dma"] == "ws":

@@ -430,3 +430,44 @@ def test_linear_software_pipelined_kernel(M, K0, K1, N, relu, groups, out, mode)
         ops.set_gemm_kernel(None)
         ops.set_gemm_mode(saved)
     assert torch.equal(res["pipe"], res["first"])
+
+
+@pytest.mark.parametrize("M,N,relu,groups,out", [
+    (70000, 256, False, 1, torch.float32), (33001, 512, True, 1, torch.float32),
+    (12345, 1536, False, 6, torch.float32), (300, 128, False, 1, torch.float32),
+    (65570, 256, False, 2, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_activation_stationary_kernel(M, N, relu, groups, out, mode):
+    """csrc/linear_areg.h (a wavefront's 32 rows resident in registers as MFMA fragments for all of K = 256, the
+    packed weight image streamed through a 6-stage LDS ring five chunks ahead across column tiles, per-wavefront
+    wait counts) against the fp64 statement of F.linear and against the first kernel: ragged last workgroup,
+    wavefronts without rows, 1 - 12 column tiles, grouped / bf16 output."""
+    K = 256
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if relu:
+        want = want.relu()
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        res = {}
+        for kern in ("areg", "first"):
+            ops.set_gemm_kernel(kern)
+            with torch.no_grad():
+                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, groups=groups, out_dtype=out)
+            assert y is not None
+            res[kern] = y.float().cpu()
+    finally:
+        ops.set_gemm_kernel(None)
+        ops.set_gemm_mode(saved)
+    y = res["areg"]
+    if groups > 1:
+        y = torch.cat(list(y), -1)
+    scale = (x.double().abs() @ w.double().abs().t()).clamp(min=1e-6)
+    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
+    assert ((y.double() - want).abs() / scale).max().item() < tol
+    torch.testing.assert_close(res["areg"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
+                               atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)

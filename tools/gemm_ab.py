@@ -16,8 +16,8 @@ shapes = [("sca_value_proj", 184950, 256, 0, 1536, 6), ("tsa_value_proj", 80000,
 g = torch.Generator(device=DEV).manual_seed(0)
 for mode in ("split", "bf16"):
     ops.set_gemm_mode(mode)
-    print(f"mode {mode}: {'shape':22s} first-kernel   dma-kernel   ws-kernel  pipe-kernel (us, median of 20)   max |pipe - first|")
-    tot = [0.0, 0.0, 0.0, 0.0]
+    print(f"mode {mode}: {'shape':22s} first-kernel   dma-kernel   ws-kernel  pipe-kernel  areg-kernel (us, median of 20)   max |areg - first|")
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0]
     for name, M, K0, K1, N, G in shapes:
         x = torch.randn(M, K0, device=DEV, generator=g)
         x2 = torch.randn(M, K1, device=DEV, generator=g) if K1 else None
@@ -26,12 +26,12 @@ for mode in ("split", "bf16"):
         t = []
         with torch.no_grad():
             outs = []
-            for kern in ("first", "dma", "ws", "pipe"):
+            for kern in ("first", "dma", "ws", "pipe", "areg"):
                 ops.set_gemm_kernel(kern)
                 outs.append(ops.linear(x, w, b, x2=x2, groups=G))
                 t.append(timeit(lambda: ops.linear(x, w, b, x2=x2, groups=G), 20)[0] * 1e6)
         ops.set_gemm_kernel(None)
-        for i in range(4):
+        for i in range(5):
             tot[i] += t[i] * (1 if G > 1 else 6)
-        print(f"   {name:22s} {t[0]:10.1f} {t[1]:10.1f} {t[2]:10.1f} {t[3]:10.1f}      {(outs[3] - outs[0]).abs().max().item():.3e}")
-    print(f"   per frame (hoisted x1, per-layer x6): {tot[0]:.0f} vs {tot[1]:.0f} vs {tot[2]:.0f} vs {tot[3]:.0f} us")
+        print(f"   {name:22s} {t[0]:10.1f} {t[1]:10.1f} {t[2]:10.1f} {t[3]:10.1f} {t[4]:10.1f}      {(outs[4] - outs[0]).abs().max().item():.3e}")
+    print(f"   per frame (hoisted x1, per-layer x6): {tot[0]:.0f} vs {tot[1]:.0f} vs {tot[2]:.0f} vs {tot[3]:.0f} vs {tot[4]:.0f} us")
