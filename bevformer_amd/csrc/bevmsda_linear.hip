@@ -13,7 +13,9 @@ namespace {
 constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
 constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
 constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
-constexpr int kLinearAregMinN = 0;               // linear_areg.h as the default for N >= this (0: never; set from measurements)
+constexpr int kLinearAregMinN = 0;               // linear_areg.h as the default for N >= this and M >= kLinearAregMinM (0: never:
+                                                 // inside the bench step it measured 640-665 us against 600-605 us for the first kernel)
+constexpr long long kLinearAregMinM = 1LL << 17; // (the camera-value projection of all layers; the 80 k-row BEV-value one loses: 1.22 rounds)
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
 constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
 constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
@@ -116,7 +118,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
                          (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
     if (d->variant == 132 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
     if (covered && (d->variant == 132 || (d->variant == 0 && d->reserved[1] == 0 && kLinearAregMinN > 0 &&
-                                          d->N >= kLinearAregMinN))) {
+                                          d->N >= kLinearAregMinN && d->M >= kLinearAregMinM))) {
       const long long nb = (d->M + bevmsda::kAregRows - 1) / bevmsda::kAregRows;
       if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
       a.nblk_n = d->N / 128;
