@@ -214,3 +214,39 @@ def test_device_plan_runs_without_host_sync():
             kw["img_metas"] = m
             want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
             torch.testing.assert_close(out.cpu(), want, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("temporal", [True, False])
+def test_encoder_when_no_camera_sees_anything(temporal):
+    """Every pillar anchor behind every camera (depth row replaced: depth = -1 everywhere): zero ragged rows — the device plan writes a
+    row count of 0, the head launches have nothing to do, the tail launches exit, the camera mean divides by the
+    clamped count — and the encoder output equals the oracle's (SpatialCrossAttention contributes only its
+    output-projection bias and the residual, spatial_cross_attention.py:165-173)."""
+    name = "micro4"
+    enc, sd = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=temporal)
+    metas = S.make_img_metas(name)
+    behind = []
+    for m in metas[0]["lidar2img"]:
+        m = np.array(m, dtype=np.float64)
+        m[2] = [0.0, 0.0, 0.0, -1.0]          # depth -1 for every point
+        behind.append(m)
+    metas[0]["lidar2img"] = behind
+    kw["img_metas"] = metas
+    want_plan = _host_plan(name, 1, metas)
+    assert want_plan.row_query.numel() == 0
+    _, dyn = _device_plan(name, 1, metas)
+    assert int(dyn.nrows_dev.item()) == 0
+    with torch.no_grad():
+        got = enc(q.to(DEV), f.to(DEV), f.to(DEV),
+                  **{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}).cpu()
+        want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+    torch.testing.assert_close(got, want, rtol=5e-4, atol=5e-4)
+    # and with gradients (the autograd path with an empty row list)
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    qd = q.to(DEV).requires_grad_(True)
+    out = enc(qd, f.to(DEV), f.to(DEV), **{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()})
+    out.sum().backward()
+    assert torch.isfinite(qd.grad).all()
+    torch.testing.assert_close(out.detach().cpu(), want, rtol=5e-4, atol=5e-4)
