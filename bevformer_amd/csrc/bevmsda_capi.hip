@@ -140,7 +140,12 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       // else the first-generation kernel without its scatter
       if (d32_fwd_eligible<T>(a)) {
         // (P = 8 in fp32 needs 140 VGPRs for two batches of 16 taps in flight: 3 waves / SIMD)
-        if (a.P == 8) hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_kernel<T, 8, sizeof(T) == 4 ? 3 : 4>), dim3(grid8), dim3(256), 0, stream, b);
+        // bf16 storage: the 16-byte-lane form (2 requests per point); BEVMSDA_BF16_LANES8 keeps the 8-byte-lane one
+        static const bool lanes8 = getenv("BEVMSDA_BF16_LANES8") != nullptr;
+        if (sizeof(T) == 2 && !lanes8 && (reinterpret_cast<uintptr_t>(a.grad_out) & 15u) == 0) {
+          if (a.P == 8) hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_bf16x8_kernel<8, 4>), dim3(grid8), dim3(256), 0, stream, b);
+          else hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_bf16x8_kernel<4, 4>), dim3(grid8), dim3(256), 0, stream, b);
+        } else if (a.P == 8) hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_kernel<T, 8, sizeof(T) == 4 ? 3 : 4>), dim3(grid8), dim3(256), 0, stream, b);
         else hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_kernel<T, 4, 4>), dim3(grid8), dim3(256), 0, stream, b);
       } else {
         switch (a.P) {

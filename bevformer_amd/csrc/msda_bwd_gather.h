@@ -163,4 +163,113 @@ msda_gradloc_d32_kernel(const KArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ bf16 value storage, 16-byte lanes
+// The gather kernel above with TapLoad<bf16_t> fetches 8 bytes per lane and tap: half the bytes of fp32 but the same
+// number of lane requests, and the kernel is bound by requests (msda_d32.h, K1b).  Here, as in
+// msda_fused_d32_bf16x8_kernel, a lane fetches 16 bytes = 8 channels, four lanes cover a tap, and the two halves of
+// an 8-lane group fetch the two x-adjacent taps of a bilinear footprint in ONE instruction (a second one for the
+// row below): 2 requests per point instead of 4.  A lane then holds, per point, the dot products of its 8 channels
+// of grad_out with its top and bottom tap (t, b); its share of the three sums of the point is linear in (t, b)
+//   lower half (x0):      attn  gy gx t + fy gx b     d/dx  -(gy t + fy b)     d/dy  gx (b - t)
+//   upper half (x0 + 1):  attn  gy fx t + fy fx b     d/dx  +(gy t + fy b)     d/dy  fx (b - t)
+// so the same butterfly reduce-scatter over the 8 lanes finishes the job.
+__device__ __forceinline__ float dot8_bf16(const float (&g)[8], const uint4 &w) {
+  float s = g[0] * bf16_lo(w.x);
+  s = fmaf(g[1], bf16_hi(w.x), s);
+  s = fmaf(g[2], bf16_lo(w.y), s); s = fmaf(g[3], bf16_hi(w.y), s);
+  s = fmaf(g[4], bf16_lo(w.z), s); s = fmaf(g[5], bf16_hi(w.z), s);
+  s = fmaf(g[6], bf16_lo(w.w), s); s = fmaf(g[7], bf16_hi(w.w), s);
+  return s;
+}
+
+template <int J0, int j, int CNT>
+struct GradPointsB8 {
+  static __device__ __forceinline__ void issue(const GradPointParams &p, __amdgpu_buffer_rsrc_t r, uint32_t lane_term,
+                                               bool upper, uint4 (&v)[CNT][2], float (&fx)[CNT], float (&fy)[CNT]) {
+    constexpr int J = J0 + j;
+    fx[j] = bcast8<J>(p.fx);
+    fy[j] = bcast8<J>(p.fy);
+    const uint32_t o00 = bcast8<J>(p.o00), o01 = bcast8<J>(p.o01), o10 = bcast8<J>(p.o10), o11 = bcast8<J>(p.o11);
+    // (an out-of-map tap carries kOobOffset: the load returns 0 and touches no line)
+    v[j][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>((upper ? o01 : o00) + lane_term), 0, 0));
+    v[j][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>((upper ? o11 : o10) + lane_term), 0, 0));
+    if constexpr (j + 1 < CNT) GradPointsB8<J0, j + 1, CNT>::issue(p, r, lane_term, upper, v, fx, fy);
+  }
+};
+
+template <int J0, int CNT, int PT>
+__device__ __forceinline__ void grad_points_b8(const GradPointParams &p, __amdgpu_buffer_rsrc_t r, uint32_t lane_term,
+                                               bool upper, const float (&g)[8], float (&pa)[PT], float (&px)[PT],
+                                               float (&py)[PT]) {
+  uint4 v[CNT][2];
+  float fx[CNT], fy[CNT];
+  GradPointsB8<J0, 0, CNT>::issue(p, r, lane_term, upper, v, fx, fy);
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const float t = dot8_bf16(g, v[j][0]), b = dot8_bf16(g, v[j][1]);
+    const float gy = 1.f - fy[j];
+    const float wx = upper ? fx[j] : 1.f - fx[j];          // my x weight
+    const float col = gy * t + fy[j] * b;                   // my column of the footprint, y-interpolated
+    pa[J0 + j] = wx * col;
+    px[J0 + j] = upper ? col : -col;
+    py[J0 + j] = wx * (b - t);
+  }
+}
+
+template <int PT, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
+  constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
+  static_assert(PT == 4 || PT == 8, "PT");
+  const int lig = threadIdx.x & 7;
+  const bool upper = lig >= 4;
+  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  long nq; int m;
+  map_group(G, a, nq, m);
+  const bool active = nq < a.NQ;
+  if (!active) nq = a.NQ - 1;
+  const int L = a.L;
+  const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
+  const long row = nq * a.M + m;
+  const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * 2;
+  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * 2);
+  const uint32_t lane_term = (lig & 3) * 16;
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  const int pj = lig % PT;
+  const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * PT + pj;
+  const float *__restrict__ ap = a.attn + row * L * PT + pj;
+  float2 *__restrict__ glp = reinterpret_cast<float2 *>(a.grad_loc) + row * L * PT + pj;
+  float *__restrict__ gap = a.grad_attn + row * L * PT + pj;
+
+  float g[8];
+  {
+    const uint4 t = *reinterpret_cast<const uint4 *>(static_cast<const bf16_t *>(a.grad_out) + row * D + (lig & 3) * 8);
+    g[0] = bf16_lo(t.x); g[1] = bf16_hi(t.x); g[2] = bf16_lo(t.y); g[3] = bf16_hi(t.y);
+    g[4] = bf16_lo(t.z); g[5] = bf16_hi(t.z); g[6] = bf16_lo(t.w); g[7] = bf16_hi(t.w);
+  }
+  float2 xy = lp[0];
+  float aw = ap[0];
+  for (int l = 0; l < L; ++l) {
+    const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
+    const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
+    const GradPointParams p = grad_point_params(xy.x, xy.y, H, W, head_base + lbytes, pix_bytes);
+    const float aw_l = aw;
+    if (l + 1 < L) {
+      xy = lp[(l + 1) * PT];
+      aw = ap[(l + 1) * PT];
+    }
+    float pa[PT], px[PT], py[PT];
+    grad_points_b8<0, PT, PT>(p, rsrc, lane_term, upper, g, pa, px, py);
+    const float ga = reduce_scatter8<PT>(pa, lig);
+    const float gx = reduce_scatter8<PT>(px, lig);
+    const float gy = reduce_scatter8<PT>(py, lig);
+    if (active && lig < PT) {
+      gap[l * PT] = ga;
+      glp[l * PT] = make_float2(gx * aw_l * static_cast<float>(W), gy * aw_l * static_cast<float>(H));
+    }
+  }
+}
+
 }  // namespace bevmsda

@@ -315,11 +315,14 @@ class _FusedSampleFunction(Function):
 
     @staticmethod
     def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None):
-        out = msda_fused(value.detach(), shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
+        # bf16 storage: ONE rounded copy of the value serves the forward kernel and, saved, the backward kernels
+        vs = value.detach().to(_STORAGE["dtype"]).contiguous()
+        out = msda_fused(vs, shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
                          tag=tag, **meta)
         if out is None:
             raise RuntimeError("bevmsda: fused sampling kernel does not cover this call")
-        ctx.save_for_backward(value, proj, shapes, start, ref.float().contiguous(),
+        ctx.value_dtype = value.dtype
+        ctx.save_for_backward(vs, proj, shapes, start, ref.float().contiguous(),
                               row_batch if row_batch is not None else shapes.new_empty(0),
                               row_src if row_src is not None else shapes.new_empty(0))
         ctx.n_off, ctx.meta = n_off, meta
@@ -388,7 +391,7 @@ class _FusedSampleFunction(Function):
                 _lib.check(lib.bevmsda_frontend_chain_f32(
                     _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")
-        return gv, gproj, None, None, None, None, None, None, None, None, None
+        return gv.to(ctx.value_dtype), gproj, None, None, None, None, None, None, None, None, None
 
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
