@@ -328,8 +328,9 @@ int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_
   if (rows < 128) rows = 128;
   a.rows_per_block = static_cast<int>(rows);
   slices = (M + rows - 1) / rows;
-  if (tiles * slices >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  const dim3 grid(static_cast<unsigned>(tiles * slices)), block(256);
+  const long long slices8 = ((slices + 7) / 8) * 8;        // the kernel deals slices to XCDs: slice = 8 i + xcd
+  if (tiles * slices8 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const dim3 grid(static_cast<unsigned>(tiles * slices8)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<3>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<1>), grid, block, 0, st, a);
