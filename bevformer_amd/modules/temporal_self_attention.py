@@ -25,6 +25,21 @@ from .. import ops
 from ..registry import ATTENTION, BaseModule, constant_, xavier_uniform_
 
 
+def _rows_layout(reference_points, bs, nq, Q, L):
+    """(bs*nq, Q, L, 2) -> (bs*Q, nq, L, 2) contiguous, the layout the fused kernel reads.  The encoder hands every
+    layer the same reference tensor: the permuted copy is made once per tensor (keyed on the object and its
+    version) instead of once per layer."""
+    hit = getattr(reference_points, "_bevmsda_rows", None)
+    if hit is not None and hit[0] == (reference_points._version, bs, nq, Q, L):
+        return hit[1]
+    rows = reference_points.reshape(bs, nq, Q, L, 2).permute(0, 2, 1, 3, 4).reshape(bs * Q, nq, L, 2).contiguous()
+    try:
+        reference_points._bevmsda_rows = ((reference_points._version, bs, nq, Q, L), rows)
+    except AttributeError:
+        pass
+    return rows
+
+
 def _is_power_of_2(n):
     if (not isinstance(n, int)) or (n < 0):
         raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
@@ -177,8 +192,7 @@ class TemporalSelfAttention(BaseModule):
         if reference_points.shape[-1] == 2 and self.batch_first and key_padding_mask is None \
                 and ops.fused_wanted(proj, v):
             # softmax, locations, sampling of both queue entries and their mean in ONE kernel
-            ref = reference_points.reshape(bs, nq, Q, L, 2).permute(0, 2, 1, 3, 4) \
-                .reshape(bs * Q, nq, L, 2)
+            ref = _rows_layout(reference_points, bs, nq, Q, L)
             out = ops.msda_fused(v, spatial_shapes, level_start_index, proj.view(bs * Q, -1), n_off,
                                  ref, None, M=M, L=L, P=P, K=nq, off_head=nq * L * P * 2,
                                  off_k=L * P * 2, lg_head=nq * L * P, lg_k=L * P, ref_mode=1,
@@ -190,8 +204,7 @@ class TemporalSelfAttention(BaseModule):
                 and v.shape[-1] == 32 and L <= 4 and P in (4, 8) and nq * P <= 8 and v.dtype == torch.float32 \
                 and ops.fused_training_wanted(proj, v):
             # autograd path: same kernel, gradients w.r.t. the value and the projection rows
-            ref = reference_points.reshape(bs, nq, Q, L, 2).permute(0, 2, 1, 3, 4) \
-                .reshape(bs * Q, nq, L, 2)
+            ref = _rows_layout(reference_points, bs, nq, Q, L)
             out = ops.msda_fused_autograd(v.contiguous(), spatial_shapes, level_start_index,
                                           proj.reshape(bs * Q, -1), n_off, ref, None, M=M, L=L, P=P, K=nq,
                                           off_head=nq * L * P * 2, off_k=L * P * 2, lg_head=nq * L * P,
