@@ -125,8 +125,8 @@ class GraphedBevHistory(BevHistory):
                 m["lidar2img"] = self.l2i[i]
                 self.static_metas.append(m)
         else:
-            self.can_bus.copy_(cb, non_blocking=True)
-            self.l2i.copy_(l2i, non_blocking=True)
+            self.can_bus.copy_(cb)          # (two small host -> device copies per frame: 144 + 384 bytes per sample)
+            self.l2i.copy_(l2i)
 
     def _run(self, has_prev):
         out = self.bev_fn(self.feats, self.static_metas, self.prev if has_prev else None)

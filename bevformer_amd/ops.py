@@ -396,7 +396,8 @@ class _FusedSampleFunction(Function):
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
                         q_rows=None, tag="msda_fwd", **meta):
-    """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (fp32 storage, D = 32; the caller checks
+    """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (D = 32; fp32 or bf16 value storage — with bf16
+    the forward's rounded copy of ``value`` is what the backward kernels read; the caller checks
     ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
     columns, logits behind them, every column of a row used by exactly one (head, queue entry, level, point)).
     ``q_rows`` (slots, J): the rows that read each projection row (inverse of ``row_src``) — with it the
