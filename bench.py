@@ -470,6 +470,17 @@ def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 
     return out
 
 
+def l1_path(w, rows, avg_us, storage):
+    """Gather volume of one SCA sampling launch against the L1 data path (64 B/clk/CU x 256 CUs x 2.4 GHz)."""
+    if not avg_us:
+        return None
+    heads, points, D = 8, 8, 32
+    gather = rows * heads * len(w["shapes"]) * points * 4 * D * (2 if storage == "bf16" else 4)
+    peak = 64 * 256 * 2.4e9
+    return dict(gather_bytes=gather, achieved_TBs=gather / (avg_us * 1e-6) / 1e12, peak_TBs=peak / 1e12,
+                frac=gather / (avg_us * 1e-6) / peak)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -646,7 +657,11 @@ def main():
                          "launches_timed": dom["launches"],
                          "timing": "HIP events on the launch stream, " +
                                    ("every launch of the first timed window" if graph is None
-                                    else "eager pass right before the timed region")},
+                                    else "eager pass right before the timed region"),
+                         # what actually bounds the kernel (counters in profiles/r2): the lanes
+                         # request rows x heads x levels x points x 4 taps x (32 channels x bytes per channel)
+                         # through the CUs' vector-memory path, 64 B/clk/CU
+                         "l1_path": l1_path(w, rows_per_frame, dom["avg_us"], args.value_storage)},
             "launch_mode": graph_note,
             "kernels": ks,
             "gemms": gs,
