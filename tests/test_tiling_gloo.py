@@ -81,3 +81,29 @@ def test_row_blocks_cover_grid_unevenly():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [x1 - x0 for x0, x1 in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_simulated_rank_equals_its_rows_of_the_untiled_encoder(world):
+    """``BevTiling.simulate = (rank, world)`` (bench.py's ``multi_gpu_model`` / ``--simulate-rank``): one process, no
+    process group, the all-gather replaced by the copy of the rank's own shard — the rows of that shard must be the
+    untiled encoder's rows, for every rank (host logic on the CPU, operator calls through the oracle)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import build_pair, oracle_ops
+    from bevformer_amd import bev_tiling
+    from bevformer_amd import synthetic as S
+    name = "micro"
+    enc, _ = build_pair(name)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=True)
+    w = S.WORKLOADS[name]
+    with oracle_ops(), torch.no_grad():
+        want = enc(q, f, f, **kw)
+        for rank in range(world):
+            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+            got = enc(q, f, f, **kw)
+            bev_tiling.disable_bev_tiling(enc)
+            h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+            q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
+            torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-5, atol=1e-5)
+            assert (got[:, :q0] == 0).all() and (got[:, q1:] == 0).all()
