@@ -99,6 +99,7 @@ SIGNATURES = {
                                                           _c_void_p], _c_int),
     "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,
                                                      _c_void_p, _c_void_p], _c_int),
+    "bevmsda_add_layernorm_backward_partials": ([ctypes.c_int64], ctypes.c_int64),
     "bevmsda_add_layernorm_backward_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int] +
                                            [_c_void_p] * 4, _c_int),
     "bevmsda_gather_mean_f32": ([_c_void_p] * 3 + [ctypes.c_int64, _c_int, _c_int,

@@ -708,22 +708,31 @@ int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gam
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+int64_t bevmsda_add_layernorm_backward_partials(int64_t rows) {
+  if (rows <= 0) return 0;
+  const int64_t nb = (rows + 3) / 4;
+  return nb > 2048 ? 2048 : nb;           // 8 workgroups per CU; every wavefront walks rows / 8192 rows
+}
+
 int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
-                                       float eps, int64_t rows, int C, float *grad_x, float *grad_gamma,
-                                       float *grad_beta, void *stream) {
+                                       float eps, int64_t rows, int C, float *grad_x, float *scratch,
+                                       float *grad_gamma_beta, void *stream) {
   if (rows < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (C != 256 && C != 512) return BEVMSDA_ERR_UNSUPPORTED;
-  if (rows == 0) return BEVMSDA_OK;
-  if (!x || !gamma || !grad_out || !grad_x || !grad_gamma || !grad_beta) return BEVMSDA_ERR_NULL_POINTER;
-  if (misaligned(x) || misaligned(grad_out) || misaligned(grad_x) || misaligned(gamma) || (res && misaligned(res)) ||
-      (reinterpret_cast<uintptr_t>(grad_gamma) & 3u) != 0 || (reinterpret_cast<uintptr_t>(grad_beta) & 3u) != 0)
-    return BEVMSDA_ERR_MISALIGNED;
-  long long nb = (rows + 3) / 4;
-  if (nb > 1024) nb = 1024;               // 4 blocks per CU; every wavefront walks rows / 4096 rows
-  const dim3 grid(static_cast<unsigned>(nb));
+  if (!grad_gamma_beta) return BEVMSDA_ERR_NULL_POINTER;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (C == 256) hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<1>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, grad_gamma, grad_beta);
-  else hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<2>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, grad_gamma, grad_beta);
+  if (rows == 0) return hipMemsetAsync(grad_gamma_beta, 0, 2 * static_cast<size_t>(C) * sizeof(float), st) == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  if (!x || !gamma || !grad_out || !grad_x || !scratch) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(x) || misaligned(grad_out) || misaligned(grad_x) || misaligned(gamma) || (res && misaligned(res)) ||
+      (reinterpret_cast<uintptr_t>(scratch) & 3u) != 0 || (reinterpret_cast<uintptr_t>(grad_gamma_beta) & 3u) != 0)
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = bevmsda_add_layernorm_backward_partials(rows);
+  const dim3 grid(static_cast<unsigned>(nb));
+  if (C == 256) hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<1>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr));
+  else hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<2>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr));
+  if (hipMemsetAsync(grad_gamma_beta, 0, 2 * static_cast<size_t>(C) * sizeof(float), st) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
+  hipLaunchKernelGGL(bevmsda::colsum_partials_kernel, dim3(static_cast<unsigned>((2 * C + 63) / 64), 16), dim3(256), 0, st,
+                     scratch, static_cast<long>(nb), 2 * C, grad_gamma_beta);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

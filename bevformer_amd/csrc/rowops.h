@@ -72,9 +72,11 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const float *__restr
 
 // Backward of add_layernorm: z = x + res is recomputed (x and res are kept by the caller; nothing else is saved
 // by the forward), grad_x = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) is the gradient of BOTH
-// x and res; grad_gamma += sum_rows g * xhat, grad_beta += sum_rows g (accumulated: the caller zeroes them).
+// x and res; the column sums sum_rows g * xhat and sum_rows g are written as per-workgroup partial rows
+// of a (gridDim.x, 2 C) scratch matrix [gamma sums | beta sums] (`ggamma`; `gbeta` unused), reduced by
+// colsum_partials_kernel.
 // One wavefront walks rows row0, row0 + W, ... with its column sums in registers; the 4 wavefronts of a block
-// combine them through LDS and issue one atomic per column and block.  3 reads + 1 write of the grid.
+// combine them through LDS.  3 reads + 1 write of the grid.
 template <int VPL>
 __global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__restrict__ x,
                                                                const float *__restrict__ res,
@@ -147,12 +149,31 @@ __global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__r
     reinterpret_cast<float4 *>(part[1][wave])[lane + 64 * i] = db[i];
   }
   __syncthreads();
+  // per-block partial sums: row blockIdx.x of ggamma / gbeta (gridDim.x, C); the caller adds the rows up
+  // (1,024 atomics per address were a third of the kernel's time)
   for (int c = threadIdx.x; c < C; c += 256) {
     const float a = (part[0][0][c] + part[0][1][c]) + (part[0][2][c] + part[0][3][c]);
     const float b = (part[1][0][c] + part[1][1][c]) + (part[1][2][c] + part[1][3][c]);
-    unsafeAtomicAdd(ggamma + c, a);
-    unsafeAtomicAdd(gbeta + c, b);
+    ggamma[static_cast<long>(blockIdx.x) * (2 * C) + c] = a;          // (P, 2 C): [gamma sums | beta sums]
+    ggamma[static_cast<long>(blockIdx.x) * (2 * C) + C + c] = b;
   }
+}
+
+// Second stage of the column sums: out[c] += sum_p parts[p, c] for a (P, C2) matrix of per-workgroup partials
+// (C2 = both vectors side by side; `out` zeroed by the launcher).  Block (x, y): 64 columns, rows y*4 + rg,
+// + 4 * gridDim.y, ...; the 4 row groups of a block combine through LDS, one atomic per column and block
+// (gridDim.y = 16 atomics per address).
+__global__ void __launch_bounds__(256) colsum_partials_kernel(const float *__restrict__ parts, long P, int C2,
+                                                              float *__restrict__ out) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < C2)
+    for (long p = blockIdx.y * 4 + rg; p < P; p += 4 * gridDim.y) s += parts[p * C2 + col];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && col < C2)
+    unsafeAtomicAdd(out + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // rows (R, C); idx (Q, J) int32 row ids, -1 = empty; scale (Q,); out (Q, C); C % 4 == 0.

@@ -474,12 +474,15 @@ class _AddLayerNormFunction(Function):
         C = x.shape[-1]
         g = g.float().contiguous()
         gx = torch.empty_like(x)
-        gwb = torch.zeros(2, C, dtype=torch.float32, device=x.device)
         lib = _lib.load()
+        rows = x.numel() // C
+        parts = int(lib.bevmsda_add_layernorm_backward_partials(rows))
+        scratch = torch.empty(max(parts, 1) * 2 * C, dtype=torch.float32, device=x.device)
+        gwb = torch.empty(2, C, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.bevmsda_add_layernorm_backward_f32(
-                _ptr(x), _ptr(res), _ptr(weight), _ptr(g), ctx.eps, x.numel() // C, C, _ptr(gx), _ptr(gwb[0]),
-                _ptr(gwb[1]), torch.cuda.current_stream().cuda_stream), "add_layernorm backward")
+                _ptr(x), _ptr(res), _ptr(weight), _ptr(g), ctx.eps, rows, C, _ptr(gx), _ptr(scratch),
+                _ptr(gwb), torch.cuda.current_stream().cuda_stream), "add_layernorm backward")
         return gx, gx, gwb[0], gwb[1], None
 
 

@@ -266,11 +266,13 @@ int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gam
 
 /* Backward of bevmsda_add_layernorm_f32 (what autograd records for `dropout(x) + identity` followed by
  * torch.nn.LayerNorm, encoder.py:360-404): grad_x (rows, C) = the gradient of BOTH x and res (z = x + res is
- * recomputed, the forward saves nothing); grad_gamma / grad_beta (C) are ACCUMULATED into (the caller zeroes them).
- * C in {256, 512}. */
+ * recomputed, the forward saves nothing); grad_gamma_beta (2, C) = [sum_rows g * xhat ; sum_rows g], written (not
+ * accumulated).  `scratch`: bevmsda_add_layernorm_backward_partials(rows) * 2 * C floats (per-workgroup partial
+ * column sums, reduced by a second small launch).  C in {256, 512}. */
+int64_t bevmsda_add_layernorm_backward_partials(int64_t rows);
 int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
-                                       float eps, int64_t rows, int C, float *grad_x, float *grad_gamma,
-                                       float *grad_beta, void *stream);
+                                       float eps, int64_t rows, int C, float *grad_x, float *scratch,
+                                       float *grad_gamma_beta, void *stream);
 /* out[q, :] = scale[q] * sum_{j<J, idx[q,j]>=0} rows[idx[q,j], :] — the per-camera
  * scatter-add and division by the camera count of SpatialCrossAttention
  * (spatial_cross_attention.py:165-172) as a gather.  idx: (Q, J) int32, -1 = empty. */
