@@ -89,8 +89,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     // multi-level calls — measured on the padded base SCA call, image-ordered rows: 1.13 vs 1.27 ms (raster rows:
     // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  BEVMSDA_GV_ROWS=128 / 256 forces one.
     static const int gv_forced = [] { const char *e = getenv("BEVMSDA_GV_ROWS"); return e ? atoi(e) : 0; }();
-    const int gv_rows = gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? 128 : kGvRowsPerBlock);
-    const int gv_threads = gv_rows == 128 ? 512 : bevmsda::kGvThreads;
+    const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? 128 : kGvRowsPerBlock);
+    const int gv_threads = gv_rows == 64 ? 256 : (gv_rows == 128 ? 512 : bevmsda::kGvThreads);
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
     tiled = tiled && 1LL * a.S < (1LL << 23) && a.NQ < (1LL << 30) && 1LL * a.N * (1LL * a.Q * 3 / 512 + 4) * 256 < (1LL << 30);
@@ -126,7 +126,14 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);                                                    \
     }                                                                                                                   \
   } while (0)
-      if (gv_threads == 512) {
+      if (gv_threads == 256) {
+        auto k1 = bevmsda::msda_gradvalue_sort_kernel<T, 1, false, 256>;
+        auto k2 = bevmsda::msda_gradvalue_sort_kernel<T, 2, false, 256>;
+        auto kern = rpt == 1 ? k1 : k2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);
+      } else if (gv_threads == 512) {
         auto k1 = bevmsda::msda_gradvalue_sort_kernel<T, 1, false, 512>;
         auto k2 = bevmsda::msda_gradvalue_sort_kernel<T, 2, false, 512>;
         auto kern = rpt == 1 ? k1 : k2;

@@ -79,13 +79,18 @@ __device__ __forceinline__ void lds_barrier() {
 template <int THREADS>
 __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* THREADS / 64 ints */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int PER = kGvBuckets / THREADS;
-  static_assert(PER == 4 || PER == 8, "4 or 8 counters per thread");
-  int4 v = reinterpret_cast<int4 *>(cnt)[tid * (PER / 4)];
-  int4 v2 = make_int4(0, 0, 0, 0);
-  if constexpr (PER == 8) v2 = reinterpret_cast<int4 *>(cnt)[tid * 2 + 1];
-  const int s1 = v.x + v.y + v.z + v.w;
-  const int s = s1 + (v2.x + v2.y) + (v2.z + v2.w);
+  constexpr int PER = kGvBuckets / THREADS;          // counters per thread: 4, 8 or 16
+  static_assert(PER == 4 || PER == 8 || PER == 16, "4, 8 or 16 counters per thread");
+  constexpr int NV = PER / 4;
+  int4 v[NV];
+  int part[NV];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = reinterpret_cast<int4 *>(cnt)[tid * NV + i];
+    part[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    s += part[i];
+  }
   int inc = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -101,10 +106,11 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* THREA
     if (w < wave) base += t;
     total += t;
   }
-  reinterpret_cast<int4 *>(cnt)[tid * (PER / 4)] = make_int4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
-  if constexpr (PER == 8) {
-    const int b2 = base + s1;
-    reinterpret_cast<int4 *>(cnt)[tid * 2 + 1] = make_int4(b2, b2 + v2.x, b2 + v2.x + v2.y, b2 + v2.x + v2.y + v2.z);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    reinterpret_cast<int4 *>(cnt)[tid * NV + i] =
+        make_int4(base, base + v[i].x, base + v[i].x + v[i].y, base + v[i].x + v[i].y + v[i].z);
+    base += part[i];
   }
   lds_barrier();
   return total;
