@@ -698,6 +698,40 @@ def main():
                 ok = ok and v["native_fp32"]["parity"]["ok"]
     else:
         line, ok = None, True
+    # N > 1: the same GPUs as independent frame streams — every rank runs whole, untiled frames, no exchange (the
+    # reference's own data parallelism, bevformer/apis/mmdet_train.py:75-79) — measured after the tiled schedule,
+    # all ranks take part.  Reported beside the strong-scaling `value`, never instead of it.
+    replicas = None
+    if tiling and not args.backward and args.queue == 0:
+        try:
+            from bevformer_amd import bev_tiling as _bt
+            _bt.disable_bev_tiling(cfg.enc)
+            ops.set_kernel_timer(None)
+            ops.set_gemm_timer(None)
+            for _ in range(2):
+                cfg.next_rig()
+                cfg.encoder_step()
+            fence()
+            g2 = None
+            if args.graph != "off":
+                try:
+                    g2, _ = capture(cfg.encoder_step, fence)
+                except Exception:       # noqa: BLE001
+                    g2 = None
+                    torch.cuda.synchronize()
+            ts2 = timed_windows(cfg, cfg.encoder_step, fence, args.steps, min(3, args.windows), g2)
+            if world > 1:
+                t2 = torch.tensor(ts2, device=dev, dtype=torch.float64)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                ts2 = [float(v) for v in t2.tolist()]
+            dt2 = statistics.median(ts2)
+            replicas = dict(scaling="weak", frames_per_step=world, ms_per_step=dt2 / args.steps * 1e3,
+                            value=Q * world * args.steps / dt2, unit="BEV queries/s",
+                            note="one untiled frame per GPU per step, no collective")
+        except Exception as e:          # noqa: BLE001 — never lose the main line to the extra one
+            replicas = dict(error=f"{type(e).__name__}: {str(e)[:160]}")
+    if line is not None and replicas is not None:
+        line["frames_in_parallel"] = replicas
     if world > 1 or args.force_tiling:
         dist.destroy_process_group()
     if line is not None:
