@@ -250,3 +250,28 @@ def test_encoder_when_no_camera_sees_anything(temporal):
     out.sum().backward()
     assert torch.isfinite(qd.grad).all()
     torch.testing.assert_close(out.detach().cpu(), want, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("name,world,temporal", [("micro4", 2, True), ("tiny", 5, True), ("micro4", 3, False)])
+def test_simulated_rank_on_the_gpu_equals_its_rows_of_the_untiled_encoder(name, world, temporal):
+    """The N > 1 schedule on the HIP path, one rank at a time in one process (``BevTiling.simulate``): device plan
+    of the rank's tile (tile-local row tables), fused kernels over the tile's rows, hoisted projections — the
+    rows of the rank's shard must be the untiled encoder's rows.  (With history only: without it TemporalSelfAttention
+    samples the CURRENT grid, which a simulated rank does not have beyond layer 0 — there the first layer's rows
+    are what can be compared, so that case runs a 1-layer encoder.)"""
+    from bevformer_amd import bev_tiling
+    enc, _ = build_pair(name, device=DEV)
+    if not temporal:
+        enc.layers = enc.layers[:1]
+        enc.num_layers = 1
+    q, f, kw = S.make_inputs(name, seed=0, temporal=temporal, device=DEV)
+    w = S.WORKLOADS[name]
+    with torch.no_grad():
+        want = enc(q, f, f, **kw)
+        for rank in range(world):
+            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+            got = enc(q, f, f, **kw)
+            bev_tiling.disable_bev_tiling(enc)
+            h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+            q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
+            torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-4, atol=1e-4)
