@@ -17,6 +17,7 @@ constexpr int kLinearAregMinN = 0;               // linear_areg.h as the default
                                                  // inside the bench step it measured 640-665 us against 600-605 us for the first kernel)
 constexpr long long kLinearAregMinM = 1LL << 17; // (the camera-value projection of all layers; the 80 k-row BEV-value one loses: 1.22 rounds)
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
+constexpr long long kLinearPipeMaxRows = 8192;   // ... and always for M <= this
 constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
 constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -145,7 +146,9 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
                          (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) &&
                          (nch == 8 || nch == 16);
     if (d->variant == 131 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
-    if (covered && (d->variant == 131 || (d->variant == 0 && d->reserved[1] == 0 && kLinearPipeDefault))) {
+    // default for tile-sized row counts (a rank's share of a BEV-tiled frame: one workgroup per CU, where its two-chunk
+    // lead is worth 8-13 %: profiles/r2/r2_gemm_small_m.txt); at base size the first kernel's 4 workgroups per CU win
+    if (covered && (d->variant == 131 || (d->variant == 0 && d->reserved[1] == 0 && (kLinearPipeDefault || d->M <= kLinearPipeMaxRows)))) {
       const long long nbm = (d->M + 127) / 128, nbn = (d->N + 127) / 128;
       const long long grid = ((nbm + 7) / 8) * 8 * nbn;
       if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
