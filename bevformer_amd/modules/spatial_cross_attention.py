@@ -304,9 +304,15 @@ class SpatialCrossAttention(BaseModule):
                 q_rows = query.reshape(bs * Q, C).index_select(0, row_query)
                 out_rows = da.forward_ragged(q_rows, projected_value, row_ref, row_batch,
                                              spatial_shapes, level_start_index)
-            slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
-            slots.index_add_(0, row_query, out_rows)
-            slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
+            qr = frame_plan.q_rows if frame_plan is not None and not frame_plan.dynamic else None
+            if qr is not None and out_rows.is_cuda and out_rows.dtype == torch.float32 and qr.shape[0] == bs * Q \
+                    and ops._FUSED_TRAIN["enabled"] and C % 4 == 0 and out_rows.shape[0] > 0:
+                # camera sum + division by the camera count as one gather kernel (its backward is a gather too)
+                slots = ops.gather_mean_autograd(out_rows, qr, inv_count, row_query).view(bs, Q, C)
+            else:
+                slots = torch.zeros(bs * Q, C, dtype=out_rows.dtype, device=query.device)
+                slots.index_add_(0, row_query, out_rows)
+                slots = slots.view(bs, Q, C) * inv_count.to(slots.dtype)
         if not projected:
             slots = ops.linear_or_torch(slots, self.output_proj.weight, self.output_proj.bias,
                                         tag="sca_output_proj")

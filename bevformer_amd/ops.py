@@ -517,6 +517,29 @@ def gather_mean(rows, idx, scale):
     return out
 
 
+class _GatherMeanFunction(Function):
+    """``gather_mean`` under autograd: SpatialCrossAttention's per-camera scatter-add + camera-count division
+    (spatial_cross_attention.py:165-172) as one gather kernel forward; backward: every row takes its slot's
+    gradient times the slot's scale (a gather by ``row_slot``)."""
+
+    @staticmethod
+    def forward(ctx, rows, idx, scale, row_slot):
+        ctx.save_for_backward(scale.reshape(-1).float(), row_slot)
+        return gather_mean(rows.detach().contiguous(), idx, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        scale, row_slot = ctx.saved_tensors
+        return (g * scale[:, None]).index_select(0, row_slot), None, None, None
+
+
+def gather_mean_autograd(rows, idx, scale, row_slot):
+    """``gather_mean(rows, idx, scale)`` with a gradient w.r.t. ``rows``; ``row_slot`` (R,) int64 = the slot every
+    row belongs to (``idx`` inverted: the frame plan's ``row_query``)."""
+    return _GatherMeanFunction.apply(rows, idx, scale, row_slot)
+
+
 # ---------------------------------------------------------------------------
 # Dense projections on the matrix cores (csrc/linear_mfma.h)
 # ---------------------------------------------------------------------------
