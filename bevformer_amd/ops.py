@@ -222,7 +222,7 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     desc = _lib.FusedDesc(R=R, proj_row=proj.stride(0), N=N, S=S, M=M, D=D, L=L, P=P, Q=Q, K=K, A=A,
                           ref_mode=ref_mode, off_head=off_head, off_k=off_k, lg_head=lg_head,
                           lg_k=lg_k, vmul=vmul, vadd=vadd)
-    if os.environ.get("BEVMSDA_FUSED_WPE"):           # benchmark sweeps: register budget of the kernel
+    if os.environ.get("BEVMSDA_FUSED_WPE") and nrows is None:   # benchmark sweeps: register budget of the kernel
         desc.reserved[0] = int(os.environ["BEVMSDA_FUSED_WPE"])
     lib = _lib.load()
     if store == torch.bfloat16 and not os.environ.get("BEVMSDA_BF16_LANES8"):
