@@ -111,6 +111,11 @@ SIGNATURES = {
                                           ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_layernorm_packed_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
                                                              _c_void_p, _c_void_p], _c_int),
+    "bevmsda_linear_panel_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
+    "bevmsda_linear_panel_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
+                                             _c_int),
+    "bevmsda_linear_panel_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
+                                                  _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,
                                   _c_void_p, ctypes.c_int64, _c_void_p, _c_int, _c_void_p], _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),

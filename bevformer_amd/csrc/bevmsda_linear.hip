@@ -6,6 +6,7 @@
 #include "linear_ws.h"
 #include "linear_pipe.h"
 #include "linear_areg.h"
+#include "linear_panel.h"
 #include "wgrad_mfma.h"
 
 namespace {
@@ -358,6 +359,94 @@ int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, ui
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+// ---- row-panel projection (linear_panel.h)
+int64_t bevmsda_linear_panel_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % bevmsda::kPanelK != 0) return 0;
+  return static_cast<int64_t>((N + 63) / 64) * 2 * (K / 16) * 2 * 1024;
+}
+
+int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream) {
+  if (N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (K % bevmsda::kPanelK != 0 || ldw % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldw < K) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!w || !blob) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(w) || misaligned(blob)) return BEVMSDA_ERR_MISALIGNED;
+  const int tiles32 = ((N + 63) / 64) * 2;
+  const long long threads = 1LL * tiles32 * (K / 16) * 64;
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_panel_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, tiles32, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
+                             const float *scale, const uint16_t *wpanel, const float *bias,
+                             const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0 || d->group_cols < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->M == 0 || d->N == 0) return BEVMSDA_OK;
+  const int K = d->K0 + d->K1;
+  if ((K != 256 && K != 512) || (d->K0 != 256 && d->K0 != 512) || (d->K1 != 0 && d->K1 != 256)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (!x0 || !wpanel || !y || (d->K1 > 0 && !x1)) return BEVMSDA_ERR_NULL_POINTER;
+  if ((idx == nullptr) != (scale == nullptr)) return BEVMSDA_ERR_NULL_POINTER;
+  if (idx && (d->K1 != 0 || a0)) return BEVMSDA_ERR_BAD_SHAPE;
+  const int gcols = d->group_cols;
+  if (d->N % 4 != 0 || d->ldy % 4 != 0 || d->ldx0 % 4 != 0 || (a0 && d->lda0 % 4 != 0) ||
+      (d->K1 > 0 && (d->ldx1 % 4 != 0 || (a1 && d->lda1 % 4 != 0))) || (gcols > 0 && (gcols % 64 != 0 || d->N % gcols != 0)))
+    return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->ldx0 < d->K0 || d->ldy < (gcols > 0 ? gcols : d->N) || (d->K1 > 0 && d->ldx1 < d->K1)) return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(x0) || misaligned(wpanel) || misaligned(y) || (bias && misaligned(bias)) || (a0 && misaligned(a0)) ||
+      (d->K1 > 0 && (misaligned(x1) || (a1 && misaligned(a1)))))
+    return BEVMSDA_ERR_MISALIGNED;
+  const int64_t wbytes = bevmsda_linear_panel_packed_bytes(d->N, K);
+  if (wbytes >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::PanelArgs a;
+  a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
+  a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
+  a.gidx = idx; a.gscale = scale;
+  a.wp = wpanel; a.wp_bytes = static_cast<unsigned>(wbytes);
+  a.bias = bias; a.y = y; a.ldy = d->ldy; a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1;
+  a.relu = d->relu ? 1 : 0; a.group_cols = gcols; a.out_bf16 = d->out_bf16 ? 1 : 0;
+  a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
+  if (ln) {
+    if (d->N != 256 || gcols != 0 || d->relu || d->out_bf16) return BEVMSDA_ERR_UNSUPPORTED;
+    if (!ln->gamma || !ln->beta) return BEVMSDA_ERR_NULL_POINTER;
+    if (misaligned(ln->gamma) || misaligned(ln->beta) || (ln->res && (misaligned(ln->res) || ln->ldres % 4 != 0 || ln->ldres < d->N)))
+      return BEVMSDA_ERR_MISALIGNED;
+    a.res = ln->res; a.ldres = ln->ldres; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
+  }
+  // workgroup shape (desc->reserved[2]): 1 = 64-row panels, 4 wavefronts of 64 x 64 tiles, two workgroups per CU;
+  // 2 = 128-row panels, 8 wavefronts of 128 x 32 tiles, one workgroup per CU (half the weight traffic per MFMA);
+  // 0 = by shape.  Two panel passes (K = 512) and the LayerNorm epilogue need one column tile per wavefront: N <= 256
+  int shape = d->reserved[2];
+  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
+  if ((K == 512 || ln) && d->N > 256) return BEVMSDA_ERR_UNSUPPORTED;
+  if (shape == 0) shape = d->N >= 1024 && d->M >= 65536 ? 2 : 1;
+  const int bm = shape == 1 ? 64 : 128;
+  const long long nb = (d->M + bm - 1) / bm;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(nb));
+#define BEVMSDA_PANEL2(NP_, LN_, PRE_)                                                                                   \
+  do {                                                                                                                   \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, LN_, PRE_>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, LN_, PRE_>), grid, dim3(512), 0, st, a);           \
+  } while (0)
+#define BEVMSDA_PANEL(NP_, LN_)                              \
+  do {                                                       \
+    if (idx) BEVMSDA_PANEL2(NP_, LN_, 2);                    \
+    else if (a.a0 || a.a1) BEVMSDA_PANEL2(NP_, LN_, 1);      \
+    else BEVMSDA_PANEL2(NP_, LN_, 0);                        \
+  } while (0)
+  if (d->precision == 0) { if (ln) BEVMSDA_PANEL(3, true); else BEVMSDA_PANEL(3, false); }
+  else { if (ln) BEVMSDA_PANEL(1, true); else BEVMSDA_PANEL(1, false); }
+#undef BEVMSDA_PANEL2
+#undef BEVMSDA_PANEL
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

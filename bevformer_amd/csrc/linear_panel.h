@@ -1,0 +1,435 @@
+// Dense projections, row-panel form (K3r): y = act([x0 (+ a0) | x1 (+ a1)] W^T + b) [-> + res -> LayerNorm].
+//
+// Same contract and arithmetic as linear_splitbf16_kernel (linear_mfma.h): fp32 operands split into two bf16
+// terms, three v_mfma_f32_32x32x16_bf16 per product (NPROD = 3) or one over rounded operands (NPROD = 1),
+// fp32 accumulation — the Linear layers of BEVFormerLayer (temporal_self_attention.py:198,206-211,267;
+// spatial_cross_attention.py:173,334-348; mmcv FFN) whose K is 256 or 512.  What differs is the schedule,
+// built on what tools/gemm_diag measured on the 128 x 128 x 32 kernels (their per-chunk phases — stage,
+// barrier, fragment reads, MFMAs, barrier — add up instead of overlapping, and the epilogue stores of a launch
+// march in phase):
+//
+//   * a workgroup owns a PANEL of BM = 32 MT complete rows and sweeps all N columns.  The panel (BM x 256 fp32
+//     = BM KB) is fetched ONCE, whole, by LDS-DMA (every row's eight 128-byte lines in flight at the same time:
+//     the memory-level parallelism a K loop of 8 dependent chunk loads never has), split ONCE into [hi | lo]
+//     bf16 planes in place by the lanes that fetched it, and followed by ONE barrier;
+//   * after that barrier the wavefronts never synchronise again: each walks its own column tiles (32 NT
+//     columns), reading activation fragments from the LDS planes (conflict-free ds_read_b128) and WEIGHT
+//     fragments straight from L2 into registers — the weight image is stored in MFMA fragment order, so a
+//     fragment is one fully coalesced 1 KiB buffer load; no LDS staging, no ds_write, no barrier for W;
+//   * wavefronts therefore drift out of phase on their own and one wavefront's epilogue stores overlap the
+//     other wavefronts' MFMAs on the same SIMD; the first weight fragments of the next column tile are
+//     requested BEFORE the stores (the vector-memory counter retires in order);
+//   * K = 512 (two sources, or FFN fc2) runs as two panel passes over the same accumulators;
+//   * a workgroup holds complete rows, so the residual add + LayerNorm that follow output_proj / fc2
+//     (encoder.py:376-404) are an epilogue (LN) instead of a second launch over the grid.
+//
+// K order: an MFMA only needs A and B to agree on which k sits in which operand slot.  DMA wants full
+// 128-byte lines per 8 lanes and the split wants 8 values per lane, so a lane's two 16-byte DMA slots hold
+// k = 32 (2p) + 4c .. +3 and 32 (2p + 1) + 4c .. +3 of its row (line pair p, 16-byte column c); these 8 values
+// are "group" j = 8 p + c, and k16-step s of the MFMA consumes groups 2s (lanes 0-31) and 2s + 1 (lanes
+// 32-63).  lin_panel_pack_weight_kernel writes W in exactly that order.  Results therefore agree with the
+// first kernel to fp32 summation order, not bit for bit.
+//
+// LDS image (one __shared__ array): pair (q, p) = 2 KiB at ((q * 4 + p) * 2048): [1 KiB hi slots | 1 KiB lo
+// slots] (during the DMA: the fp32 granules of line 2p | line 2p + 1); q = row block (row bits 2, 4, 5, 6), the 8
+// rows of a block are row bits 0, 1, 3; slot of (row, c) inside a 1 KiB half = rl * 8 + (c ^ (row & 7)) with
+// rl = (row & 3) * 2 + bit 3 of row.  With that map the 16 lanes of every ds_read_b128 service group
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) hit 16 distinct 16-byte slots of the 256-byte bank row
+// (tests/test_linear_layout_model.py replays the arithmetic).
+#pragma once
+#include "linear_mfma.h"
+
+namespace bevmsda {
+
+struct PanelArgs {
+  const float *x0, *a0, *x1, *a1;   // A sources (a* optional addends); x1 for k >= K0
+  long ldx0, lda0, ldx1, lda1;
+  const int32_t *gidx;              // gather mode: A[m, :] = gscale[m] * (x0[gidx[m, 0]] + x0[gidx[m, 1]]), -1 = absent
+  const float *gscale;
+  const uint16_t *wp;               // fragment-order weight image (lin_panel_pack_weight_kernel)
+  unsigned wp_bytes;
+  const float *bias;
+  float *y;
+  long ldy;
+  long M;
+  int N, K0, K1;
+  int relu, group_cols, out_bf16;
+  const float *res;                 // LN: residual (M, ldres) or nullptr
+  long ldres;
+  const float *gamma, *beta;
+  float eps;
+};
+
+constexpr int kPanelK = 256;        // k per panel pass (8 lines of 128 bytes per row)
+
+__device__ __forceinline__ int panel_row_of(int q, int rl) {
+  return ((rl >> 1) & 3) | ((rl & 1) << 3) | ((q & 1) << 2) | ((q >> 1) << 4);
+}
+
+__device__ __forceinline__ float4 panel_gsum(const float4 &r0, bool h0, const float4 &r1, bool h1, float sc) {
+  return make_float4(((h0 ? r0.x : 0.f) + (h1 ? r1.x : 0.f)) * sc, ((h0 ? r0.y : 0.f) + (h1 ? r1.y : 0.f)) * sc,
+                     ((h0 ? r0.z : 0.f) + (h1 ? r1.z : 0.f)) * sc, ((h0 ? r0.w : 0.f) + (h1 ? r1.w : 0.f)) * sc);
+}
+
+// MT x NT MFMA tiles of 32 x 32 per wavefront tile, NW wavefronts, BM = 32 MT rows per workgroup.
+// PRE: what the split pass adds to the fetched rows: 0 nothing, 1 an addend matrix (a0 / a1, each optional), 2 gather mode.
+template <int NPROD, int MT, int NT, int NW, bool LN, int PRE>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+linear_panel_kernel(const PanelArgs a) {
+  static_assert(NPROD == 1 || NPROD == 3, "NPROD");
+  static_assert((MT == 2 || MT == 4) && (NT == 1 || NT == 2), "wavefront tile");
+  constexpr bool LO = NPROD == 3;
+  constexpr int NPL = LO ? 2 : 1;
+  constexpr int BM = MT * 32;
+  constexpr int NPAIR = (BM / 8) * 4;          // (row block q, line pair p)
+  constexpr int TW = NT * 32;                  // columns per wavefront tile
+  constexpr int PANEL_BYTES = NPAIR * 2048;
+  constexpr int STAT_FLOATS = LN ? NW * BM : 0;
+  static_assert(NPAIR % NW == 0, "pairs per wavefront");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PANEL_BYTES + STAT_FLOATS * 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA bases and buffer soffsets are scalar operands
+  const long m0 = static_cast<long>(blockIdx.x) * BM;
+  const int K = a.K0 + a.K1;
+  const int nhalf = K / kPanelK;
+  const int nstep = K / 16;                    // k16 steps of the whole K axis (weight image stride)
+  const int nct = (a.N + TW - 1) / TW;         // column tiles
+
+  // ---- DMA / split assignment of this lane: slot l of every pair the wavefront owns
+  const int d_rl = lane >> 3, d_cc = lane & 7;
+
+  // ---- fragment read addresses (bytes): lane -> row (lane & 31) of MFMA tile i, k half h = lane >> 5
+  const int f_r = lane & 31, f_h = lane >> 5;
+  const int f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1);             // row bits 2, 4 (tile i adds bits 5, 6)
+  const int f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1);
+  const int f_x = f_r & 7;
+  unsigned f_addr[4];                          // per (s & 3): base of tile 0, pair p = 0, hi plane
+#pragma unroll
+  for (int sc = 0; sc < 4; ++sc)
+    f_addr[sc] = static_cast<unsigned>(f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * sc + f_h) ^ f_x))) * 16);
+
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.wp), 0,
+                                                                   static_cast<int>(a.wp_bytes), 0x00020000);
+  const int wlane = lane * 16;
+
+  lin_f32x16 acc[MT][NT];
+  lin_bf16x8 wf[3][NT][NPL];                   // weight fragments: ring over k16 steps (two in flight)
+
+  // weight fragments of (column tile ct, global step sg) -> ring stage st
+  auto wload = [&](int st, int ct, int sg) {
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const int so = (((ct * NT + jn) * nstep + sg) * 2 + pl) * 1024;     // wave-uniform byte offset
+        wf[st][jn][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+      }
+  };
+
+  for (int half = 0; half < nhalf; ++half) {
+    // ---------------------------------------------------------------- panel pass: fetch, split, one barrier
+    const int kb = half * kPanelK;
+    const bool second = kb >= a.K0;
+    const float *xs = second ? a.x1 + (kb - a.K0) : a.x0 + kb;
+    const long ldx = second ? a.ldx1 : a.ldx0;
+    const float *as = second ? a.a1 : a.a0;
+    const long lda = second ? a.lda1 : a.lda0;
+    if (as) as += second ? (kb - a.K0) : kb;
+    if (half > 0) __syncthreads();             // every wavefront is done with the previous pass's planes
+    constexpr int PPW = NPAIR / NW;            // pairs per wavefront = QPW row blocks x 4 line pairs
+    constexpr int QPW = PPW / 4;
+    const bool add = PRE == 1 && as != nullptr;
+    long srow[QPW], arow[QPW];                 // DMA source row; addend row / second gathered row
+    int g0[QPW], g1[QPW];
+    float gs[QPW];
+    int cx[QPW];                               // 16-byte column of this lane's slot: c = d_cc ^ (row & 7)
+#pragma unroll
+    for (int u = 0; u < QPW; ++u) {
+      const int row = panel_row_of(wave * QPW + u, d_rl);
+      cx[u] = d_cc ^ (row & 7);
+      long gm = m0 + row;
+      if (gm >= a.M) gm = a.M - 1;             // clamped rows are computed and never stored
+      srow[u] = arow[u] = gm;
+      g0[u] = 0; g1[u] = -1; gs[u] = 1.f;
+      if (PRE == 2) {
+        g0[u] = a.gidx[gm * 2];
+        g1[u] = a.gidx[gm * 2 + 1];
+        gs[u] = a.gscale[gm];
+      }
+    }
+    if (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < QPW; ++u) {
+        srow[u] = g0[u] < 0 ? 0 : g0[u];
+        arow[u] = g1[u] < 0 ? 0 : g1[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < QPW; ++u)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float *src = xs + srow[u] * ldx + (2 * p) * 32 + cx[u] * 4;
+        unsigned char *dst = lds + ((wave * QPW + u) * 4 + p) * 2048;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32),
+                                         (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+      }
+    float4 ad[PRE ? PPW : 1][2];               // addend / second gathered row: plain loads, under the DMA
+    if (PRE == 2 || add) {
+#pragma unroll
+      for (int u = 0; u < QPW; ++u)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float *s1 = (PRE == 2 ? xs + arow[u] * ldx : as + arow[u] * lda) + (2 * p) * 32 + cx[u] * 4;
+          ad[PRE ? u * 4 + p : 0][0] = *reinterpret_cast<const float4 *>(s1);
+          ad[PRE ? u * 4 + p : 0][1] = *reinterpret_cast<const float4 *>(s1 + 32);
+        }
+    }
+    // the first weight fragments travel under the panel fetch too
+    int ct = wave;
+    if (half == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    if (ct < nct) {
+      wload(0, ct, half * 16 + 0);
+      wload(1, ct, half * 16 + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my own DMA slots have landed (no other lane reads them yet)
+#pragma unroll
+    for (int u = 0; u < QPW; ++u)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned char *slot = lds + ((wave * QPW + u) * 4 + p) * 2048 + lane * 16;
+        float4 va = *reinterpret_cast<const float4 *>(slot);
+        float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
+        if (PRE == 2) {                        // (row0 + row1) * scale, absent rows as zeros: gather_mean's arithmetic
+          va = panel_gsum(va, g0[u] >= 0, ad[PRE ? u * 4 + p : 0][0], g1[u] >= 0, gs[u]);
+          vb = panel_gsum(vb, g0[u] >= 0, ad[PRE ? u * 4 + p : 0][1], g1[u] >= 0, gs[u]);
+        } else if (add) {
+          va = lin_add4(va, ad[PRE ? u * 4 + p : 0][0]);
+          vb = lin_add4(vb, ad[PRE ? u * 4 + p : 0][1]);
+        }
+        uint4 hi, lo;
+        lin_split8<LO>(va, vb, hi, lo);
+        *reinterpret_cast<uint4 *>(slot) = hi;
+        if (LO) *reinterpret_cast<uint4 *>(slot + 1024) = lo;
+      }
+    __syncthreads();                           // planes complete
+
+    // ---------------------------------------------------------------- column sweep: no synchronisation
+    const bool last_half = half == nhalf - 1;
+    for (; ct < nct; ct += NW) {
+      const int ct_next = ct + NW;
+      lin_bf16x8 af[2][MT][NPL];               // activation fragments: step s in set s & 1
+      auto aload = [&](int set, int s) {
+        const unsigned base = f_addr[s & 3] + (s >> 2) * 2048;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl)
+            af[set][i][pl] = *reinterpret_cast<const lin_bf16x8 *>(lds + base + i * (4 * 4 * 2048) + pl * 1024);
+      };
+      aload(0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        // weight fragments two steps ahead (ring stage (s + 2) % 3); past the tile's end: the next tile's first two
+        if (s + 2 < 16) {
+          wload((s + 2) % 3, ct, half * 16 + s + 2);
+        } else if (ct_next < nct) {
+          wload((s + 2) % 3, ct_next, half * 16 + s + 2 - 16);
+        }
+        if (s + 1 < 16) aload((s + 1) & 1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);     // requests first: left alone, hipcc sinks them to the end of the step
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            // D[n][m]: the W fragment is the MFMA's A operand (4 consecutive output columns per lane -> float4 stores)
+            if (LO) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][0], af[s & 1][i][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][1], af[s & 1][i][0], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][0], af[s & 1][i][0], acc[i][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);     // ... and hoists every fragment read of the tile to its top
+      }
+      // 16 % 3 == 1: the next tile's steps 0, 1 sit in ring stages 1, 2 -> rotate them to 0, 1
+      if (ct_next < nct) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            wf[0][jn][pl] = wf[1][jn][pl];
+            wf[1][jn][pl] = wf[2][jn][pl];
+          }
+      }
+      if (!last_half) continue;                // (two passes: one column tile per wavefront, checked by the launcher)
+
+      // ------------------------------------------------------------ epilogue of column tile ct
+      const int n0 = ct * TW;
+      if constexpr (!LN) {
+        const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
+        float *const yg = a.y + static_cast<long>(grp) * a.M * a.ldy;
+        const int ncol0 = grp * a.group_cols;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const long m = m0 + i * 32 + (lane & 31);
+          float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int nb = n0 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = nb + 8 * g;
+              float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+              acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+              if (m < a.M && n < a.N) {         // N % 4 == 0: n < N covers n .. n + 3
+                if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+                if (a.relu) {                   // NaN stays NaN, as torch.relu
+                  v.x = v.x < 0.f ? 0.f : v.x;
+                  v.y = v.y < 0.f ? 0.f : v.y;
+                  v.z = v.z < 0.f ? 0.f : v.z;
+                  v.w = v.w < 0.f ? 0.f : v.w;
+                }
+                if (a.out_bf16) {
+                  uint2 pk;
+                  pk.x = lin_pack2(v.x, v.y);
+                  pk.y = lin_pack2(v.z, v.w);
+                  uint16_t *yb = reinterpret_cast<uint16_t *>(a.y) + (yrow - a.y) + n;
+                  *reinterpret_cast<uint2 *>(yb) = pk;
+                } else {
+                  *reinterpret_cast<float4 *>(yrow + n) = v;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (LN) {
+    // y = LayerNorm(acc + bias + res) * gamma + beta over the 256 columns of a row (N = NW * TW: one column tile per
+    // wavefront, checked by the launcher).  A row lives in 2 lanes (l, l ^ 32) of each of the NW wavefronts; two-pass
+    // statistics (mean, then centred sum of squares) exchanged through LDS; torch.nn.LayerNorm semantics.
+    float *stat = reinterpret_cast<float *>(lds + PANEL_BYTES);      // [wave][BM]
+    const int n0 = wave * TW;
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const long m = m0 + i * 32 + (lane & 31);
+      const bool mok = m < a.M;
+      const float *rrow = a.res ? a.res + (mok ? m : 0) * a.ldres : nullptr;
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nb = n0 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+          if (rrow) v = lin_add4(v, *reinterpret_cast<const float4 *>(rrow + n));
+          acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w;
+          sum += (v.x + v.y) + (v.z + v.w);
+        }
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      mean[i] = sum;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) stat[wave * BM + i * 32 + lane] = mean[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
+      mean[i] = t * (1.0f / static_cast<float>(NW * TW));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][j][r] - mean[i];
+          ss = fmaf(d, d, ss);
+        }
+      ss += __shfl_xor(ss, 32, 64);
+      rstd[i] = ss;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) stat[wave * BM + i * 32 + lane] = rstd[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
+      rstd[i] = rsqrtf(t * (1.0f / static_cast<float>(NW * TW)) + a.eps);
+      const long m = m0 + i * 32 + (lane & 31);
+      if (m >= a.M) continue;
+      float *yrow = a.y + m * a.ldy;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nb = n0 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + n);
+          const float4 be = *reinterpret_cast<const float4 *>(a.beta + n);
+          float4 v;
+          v.x = (acc[i][j][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
+          v.y = (acc[i][j][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
+          v.z = (acc[i][j][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
+          v.w = (acc[i][j][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
+          *reinterpret_cast<float4 *>(yrow + n) = v;
+        }
+      }
+    }
+  }
+}
+
+// Weight image of the row-panel kernel: for every 32-row tile T of w (N, K), k16 step sg and plane (hi, lo) the
+// 64 lanes x 8 bf16 of one MFMA operand, contiguous (1 KiB):
+//   blob[(((T * K/16 + sg) * 2 + plane) * 64 + lane) * 8 + e] = plane(w[T*32 + (lane & 31)][k])
+//   k = 256 (sg / 16) + 32 (2 p + (e >> 2)) + 4 c + (e & 3),  8 p + c = 2 (sg % 16) + (lane >> 5)
+// Rows >= N are zero (N is padded to the launcher's column-tile width).  One thread per (T, sg, lane).
+__global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float *__restrict__ w, long ldw, int N, int K,
+                                                                   int n_tiles32, uint16_t *__restrict__ blob) {
+  const int nstep = K / 16;
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= static_cast<long>(n_tiles32) * nstep * 64) return;
+  const int lane = static_cast<int>(t & 63);
+  const int sg = static_cast<int>((t >> 6) % nstep);
+  const int T = static_cast<int>((t >> 6) / nstep);
+  const int n = T * 32 + (lane & 31);
+  const int j = 2 * (sg % 16) + (lane >> 5);
+  const int p = j >> 3, c = j & 7;
+  const int k = (sg / 16) * kPanelK + (2 * p) * 32 + 4 * c;
+  uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
+  if (n < N) {
+    const float *src = w + static_cast<long>(n) * ldw + k;
+    lin_split8<true>(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 32), hi, lo);
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(blob) + ((static_cast<long>(T) * nstep + sg) * 2) * 64 + lane;
+  dst[0] = hi;
+  dst[64] = lo;
+}
+
+}  // namespace bevmsda

@@ -554,7 +554,11 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
          "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "1") == "1",
          # second projection kernel (csrc/linear_dma.h: activations by LDS-DMA, one barrier per chunk) for the
          # calls it covers (packed weights, no addend / gather); None = library default
-         "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None)}
+         "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None),
+         # row-panel kernel (csrc/linear_panel.h) for the calls it covers: True / False; panel_shape 0 = by problem
+         # shape, 1 = 64-row panels, 2 = 128-row panels
+         "panel": os.environ.get("BEVMSDA_GEMM_PANEL", "1") == "1",
+         "panel_shape": int(os.environ.get("BEVMSDA_GEMM_PANEL_SHAPE", "0"))}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
 
@@ -610,6 +614,65 @@ def packed_weight(weight):
     return blob
 
 
+def panel_weight(weight):
+    """Fragment-order bf16 image of an (N, K) fp32 weight for the row-panel kernel
+    (``bevmsda_linear_panel_pack_weight_f32``), cached on the tensor until it is written to or moved."""
+    key = (weight._version, weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    hit = getattr(weight, "_bevmsda_panel", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = _lib.load()
+    N, K = weight.shape
+    nbytes = lib.bevmsda_linear_panel_packed_bytes(N, K)
+    if nbytes == 0:
+        return None
+    blob = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.bevmsda_linear_panel_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
+                                                      torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear_panel_pack_weight")
+    try:
+        weight._bevmsda_panel = (key, blob)
+    except AttributeError:
+        pass
+    return blob
+
+
+def _panel_covers(N, K0, K1, groups, ln):
+    """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h)."""
+    K = K0 + K1
+    if not _GEMM["panel"] or _GEMM["variant"] is not None or K not in (256, 512) or K0 not in (256, 512) \
+            or K1 not in (0, 256) or N % 4:
+        return False
+    if (K == 512 or ln) and N > 256:
+        return False
+    if ln and N != 256:
+        return False
+    return groups == 1 or (N // groups) % 64 == 0
+
+
+def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbytes):
+    """One launch of the row-panel kernel; returns False when the library declines the call."""
+    blob = panel_weight(w)
+    if blob is None:
+        return False
+    desc.reserved[2] = _GEMM["panel_shape"]
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
+    p = lambda t: _ptr(t) if t is not None else None
+    with torch.cuda.device(x0.device), ctx:
+        rc = lib.bevmsda_linear_panel_f32(p(x0), p(a0), p(x1), p(a1), p(idx), p(scale), _ptr(blob), p(b),
+                                          ctypes.byref(desc), ctypes.byref(ln) if ln is not None else None, _ptr(y),
+                                          torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return False
+    _lib.check(rc, "linear_panel")
+    return True
+
+
 def set_gemm_dma(flag):
     """True / False: use / avoid the LDS-DMA projection kernel where it applies; None: library default."""
     _GEMM["dma"] = flag
@@ -617,10 +680,13 @@ def set_gemm_dma(flag):
 
 def set_gemm_kernel(name):
     """Which projection kernel serves the calls several of them cover: ``None`` (library default), ``"first"``
-    (linear_mfma.h), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined), ``"areg"`` (linear_areg.h,
+    (linear_mfma.h), ``"panel"`` / ``"panel64"`` / ``"panel128"`` (linear_panel.h, row panels; the default where it
+    applies), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined), ``"areg"`` (linear_areg.h,
     activation rows resident in registers)."""
-    assert name in (None, "first", "dma", "ws", "pipe", "areg")
-    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe", "areg": "areg"}[name]
+    assert name in (None, "first", "dma", "ws", "pipe", "areg", "panel", "panel64", "panel128")
+    _GEMM["panel"] = name in (None, "panel", "panel64", "panel128")
+    _GEMM["panel_shape"] = {"panel64": 1, "panel128": 2}.get(name, 0)
+    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(name)
 
 
 def _ws_covers(M, N, K0, K1, a0, a1, mode):
@@ -698,6 +764,10 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
                            precision=0 if mode == "split" else 1,
                            group_cols=ncol if groups > 1 else 0,
                            out_bf16=int(out_dtype == torch.bfloat16))
+    if _GEMM["pack"] and _panel_covers(N, K0, K1, groups, False):
+        nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
+        if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes):
+            return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     variant = _GEMM["variant"]
     blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):
@@ -755,15 +825,19 @@ def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
         return None
     w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0
                    and weight.data_ptr() % 16 == 0) else weight.contiguous()
-    blob = packed_weight(w)
-    if blob is None:
-        return None
     b = bias.contiguous() if bias is not None else None
     y = torch.empty((Qn, N), dtype=torch.float32, device=rows.device)
     if Qn == 0:
         return y
     desc = _lib.LinearDesc(M=Qn, ldx0=rows.stride(0), ldw=K, ldy=N, N=N, K0=K, K1=0, relu=0,
                            precision=0 if mode == "split" else 1)
+    if _panel_covers(N, K, 0, 1, False) and rows.data_ptr() % 16 == 0 and _panel_call(
+            desc, rows, None, None, None, idx, scale, w, b, None, y, tag, 2.0 * Qn * N * K,
+            4.0 * (min(rows.shape[0], 2 * Qn) * K + N * K + Qn * N)):
+        return y
+    blob = packed_weight(w)
+    if blob is None:
+        return None
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     # algorithmic bytes: at most two source rows per output row (not the capacity of `rows`)
@@ -836,21 +910,27 @@ def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
         r2, ldres = _rows2d(res, 256)
     w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0) \
         else weight.contiguous()
-    blob = packed_weight(w)
-    if blob is None or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256)):
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256):
         return None
     y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
     if M == 0:
         return y.view(*lead, 256)
     desc = _lib.LinearDesc(M=M, ldx0=ldx0, ldw=K, ldy=256, N=256, K0=K, K1=0, relu=0,
                            precision=0 if mode == "split" else 1)
-    if os.environ.get("BEVMSDA_LN_BM") == "128":        # benchmark knob: 128-row tiles (half the workgroups)
-        desc.reserved[0] = 1
     ln = _lib.LayerNormDesc(res=_ptr(r2) if r2 is not None else None, ldres=ldres, gamma=_ptr(norm.weight),
                             beta=_ptr(norm.bias), eps=float(norm.eps))
+    nbytes = 4.0 * ((min(x0.shape[0], 2 * M) if gather is not None else M) * K + 256 * K + M * 256 * (2 if res is not None else 1))
+    if _panel_covers(256, K, 0, 1, True) and _panel_call(
+            desc, x0, None, None, None, idx if gather is not None else None, scale if gather is not None else None,
+            w, bias.contiguous() if bias is not None else None, ln, y, tag, 2.0 * M * 256 * K, nbytes):
+        return y.view(*lead, 256)
+    blob = packed_weight(w)
+    if blob is None:
+        return None
+    if os.environ.get("BEVMSDA_LN_BM") == "128":        # benchmark knob: 128-row tiles (half the workgroups)
+        desc.reserved[0] = 1
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
-    nbytes = 4.0 * ((min(x0.shape[0], 2 * M) if gather is not None else M) * K + 256 * K + M * 256 * (2 if res is not None else 1))
     ctx = cb(tag, 2.0 * M * 256 * K, nbytes) if cb is not None else _NoTimer()
     with torch.cuda.device(x.device), ctx:
         rc = lib.bevmsda_linear_layernorm_packed_f32(

@@ -411,6 +411,26 @@ int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const 
                                         const float *bias, const bevmsda_linear_desc *desc,
                                         const bevmsda_layernorm_desc *ln, float *y, void *stream);
 
+/* Row-panel form of the projections (csrc/linear_panel.h): the same contract and arithmetic as
+ * bevmsda_linear_packed_f32 / _gather_packed_f32 / _layernorm_packed_f32 behind one entry point, for the
+ * layer shapes K0 + K1 in {256, 512} (K0 in {256, 512}, K1 in {0, 256}).  A workgroup fetches a panel of 64 or
+ * 128 complete rows once (LDS-DMA), splits it once, and its wavefronts sweep the N columns without further
+ * synchronisation, weight fragments coming straight from L2 in MFMA operand order.  The weight image is its own
+ * format: bevmsda_linear_panel_pack_weight_f32 writes bevmsda_linear_panel_packed_bytes(N, K) bytes (0 when
+ * K % 256 != 0).  idx / scale: optional two-row gather (then a0 / x1 must be NULL); ln: optional residual +
+ * LayerNorm epilogue (N = 256).  desc->reserved[2]: 0 = panel shape by problem shape, 1 = 64-row panels (4
+ * wavefronts, 64 x 64 tiles, two workgroups per CU), 2 = 128-row panels (8 wavefronts, 128 x 32 tiles).
+ * K = 512 and ln need N <= 256; N % 4 == 0, group_cols % 64 == 0, all pointers 16-byte aligned, row strides
+ * multiples of 4; anything else returns BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and the caller uses the entry
+ * points above.  The k order inside an MFMA differs from the first kernel's: results agree to fp32 summation
+ * order, not bit for bit. */
+int64_t bevmsda_linear_panel_packed_bytes(int N, int K);
+int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream);
+int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
+                             const float *scale, const uint16_t *wpanel, const float *bias,
+                             const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,
+                             void *stream);
+
 /* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
  *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)
  * g (M, ldg) = gradient w.r.t. the layer's output (N columns), x (M, ldx) = the layer's input (K columns).

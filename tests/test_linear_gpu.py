@@ -471,3 +471,105 @@ def test_linear_activation_stationary_kernel(M, N, relu, groups, out, mode):
     assert ((y.double() - want).abs() / scale).max().item() < tol
     torch.testing.assert_close(res["areg"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
                                atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)
+
+
+@pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
+    (1000, 256, 0, 256, False, 1, torch.float32), (4099, 256, 256, 192, False, 1, torch.float32),
+    (777, 256, 0, 512, True, 1, torch.float32), (130, 512, 0, 256, False, 1, torch.float32),
+    (3001, 256, 0, 1536, False, 6, torch.float32), (3001, 256, 0, 1536, False, 6, torch.bfloat16),
+    (5000, 256, 0, 768, False, 1, torch.float32), (1, 256, 0, 64, False, 1, torch.float32),
+    (63, 256, 0, 100, True, 1, torch.float32), (40000, 256, 0, 256, False, 1, torch.float32)])
+@pytest.mark.parametrize("kernel", ["panel64", "panel128"])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_row_panel_kernel(gemm_mode, mode, kernel, M, K0, K1, N, relu, groups, out):
+    """``bevmsda_linear_panel_f32`` (csrc/linear_panel.h), both panel shapes: against the fp64 statement and against
+    the first kernel (same arithmetic, another k order inside the MFMAs: fp32 summation-order differences only)."""
+    gemm_mode(mode)
+    x0 = _rand(M, K0, seed=61)
+    x1 = _rand(M, K1, seed=62) if K1 else None
+    a1 = _rand(M, K1, seed=63) if K1 else None
+    a0 = _rand(M, K0, seed=64) if K1 else None          # addends on both sources in the two-source case
+    w, b = _rand(N, K0 + K1, seed=65) * 0.05, _rand(N, seed=66)
+    try:
+        with torch.no_grad():
+            ops.set_gemm_kernel(kernel)
+            called = []
+            ops.set_gemm_timer(lambda tag, f, n: (called.append(tag), ops._NoTimer())[1])
+            y = ops.linear(x0, w, b, relu=relu, x_add=a0, x2=x1, x2_add=a1, groups=groups, out_dtype=out, tag="panel")
+            ops.set_gemm_timer(None)
+            ops.set_gemm_kernel("first")
+            y1 = ops.linear(x0, w, b, relu=relu, x_add=a0, x2=x1, x2_add=a1, groups=groups, out_dtype=out)
+    finally:
+        ops.set_gemm_kernel(None)
+        ops.set_gemm_timer(None)
+    assert y is not None and called == ["panel"]
+    xa = x0 if not K1 else torch.cat([x0 + a0, x1 + a1], -1)
+    want = _ref64(xa, w, b, relu=relu)
+    if groups > 1:
+        want = want.view(M, groups, N // groups).transpose(0, 1)
+    bound = BOUND[mode] if out == torch.float32 else 8e-3
+    sc = _scale(xa, w) + (b.abs().double() if out != torch.float32 else 0)
+    if groups > 1:
+        sc = sc.view(M, groups, N // groups).transpose(0, 1)
+    err = ((y.double() - want).abs() / sc).max().item()
+    assert err < bound, f"{kernel} {mode}: scaled error {err:.3e}"
+    if out == torch.float32:
+        d = ((y.double() - y1.double()).abs() / sc).max().item()
+        assert d < (2e-6 if mode == "split" else 1e-6), f"{kernel} vs the first kernel: {d:.3e}"
+
+
+@pytest.mark.parametrize("kernel", ["panel64", "panel128"])
+def test_linear_row_panel_identity_with_asymmetric_weight(gemm_mode, kernel):
+    """A = I picks single weights: catches a permuted k order between the activation image and the weight image,
+    or a transposed accumulator map."""
+    gemm_mode("split")
+    K = 256
+    x = torch.eye(K, device=DEV)
+    w = torch.arange(320 * K, device=DEV, dtype=torch.float32).reshape(320, K) * 1.0009765625 + 0.3
+    try:
+        ops.set_gemm_kernel(kernel)
+        with torch.no_grad():
+            y = ops.linear(x, w)
+    finally:
+        ops.set_gemm_kernel(None)
+    torch.testing.assert_close(y, w.t().contiguous(), rtol=2 ** -16, atol=0)
+
+
+@pytest.mark.parametrize("kernel", ["panel64", "panel128"])
+def test_linear_row_panel_layernorm_and_gather(gemm_mode, kernel):
+    """LayerNorm epilogue (K = 256 and 512) and the camera gather of the row-panel kernel against the unfused
+    sequence on the same kernel."""
+    gemm_mode("split")
+    g = torch.Generator().manual_seed(7)
+    R, Q = 900, 641
+    rows = _rand(R, 256, seed=71)
+    idx = torch.randint(0, R, (Q, 2), generator=g, dtype=torch.int32)
+    idx[torch.rand(Q, generator=g) < 0.6, 1] = -1
+    idx[:7] = -1
+    idx[7:9, 0] = -1                                           # only the second slot filled
+    scale = (1.0 / (idx >= 0).sum(1).clamp(min=1).float()).to(DEV)
+    idx = idx.to(DEV)
+    w, b, res = _rand(256, 256, seed=72) / 16, _rand(256, seed=73) * 0.1, _rand(Q, 256, seed=74)
+    w5, x5 = _rand(256, 512, seed=75) / 22, _rand(Q, 512, seed=76)
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(_rand(256, seed=77) * 0.2 + 1.0)
+        norm.bias.copy_(_rand(256, seed=78) * 0.1)
+    try:
+        ops.set_gemm_kernel(kernel)
+        ops.set_layernorm_fusion(True)
+        with torch.no_grad():
+            got = ops.linear_layernorm(rows, w, b, res, norm, gather=(idx, scale))
+            two = ops.linear_gather_mean(rows, idx, scale, w, b)
+            three = ops.linear(ops.gather_mean(rows, idx, scale), w, b)
+            got5 = ops.linear_layernorm(x5, w5, b, res, norm)
+            lin5 = ops.linear(x5, w5, b)
+    finally:
+        ops.set_layernorm_fusion(False)
+        ops.set_gemm_kernel(None)
+    assert got is not None and two is not None and got5 is not None
+    assert torch.equal(two, three)                             # gather in the split pass == gather_mean + projection
+    want = torch.nn.functional.layer_norm(two.double() + res.double(), (256,), norm.weight.double(), norm.bias.double(), norm.eps)
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5)
+    want5 = torch.nn.functional.layer_norm(lin5.double() + res.double(), (256,), norm.weight.double(), norm.bias.double(), norm.eps)
+    torch.testing.assert_close(got5.double(), want5, rtol=1e-5, atol=1e-5)

@@ -174,3 +174,152 @@ def test_transposed_tile_epilogue_and_grouped_output_cover_every_element_once():
                                 if m < M and n < N:
                                     seen[grp, m, n - ncol0:n - ncol0 + 4] += 1
     assert (seen == 1).all()
+
+
+# -- row-panel kernel (csrc/linear_panel.h): DMA slot map, in-place split, fragment reads, fragment-order weights ------
+
+def _panel_row_of(q, rl):
+    return ((rl >> 1) & 3) | ((rl & 1) << 3) | ((q & 1) << 2) | ((q >> 1) << 4)
+
+
+def _panel_pack_weight(w, n_tiles32):
+    """lin_panel_pack_weight_kernel: blob[T][sg][plane][lane][e]; one plane modelled (values, not bf16)."""
+    N, K = w.shape
+    nstep = K // 16
+    blob = np.zeros((n_tiles32, nstep, 64, 8))
+    for T in range(n_tiles32):
+        for sg in range(nstep):
+            for lane in range(64):
+                n = T * 32 + (lane & 31)
+                j = 2 * (sg % 16) + (lane >> 5)
+                p, c = j >> 3, j & 7
+                k = (sg // 16) * 256 + (2 * p) * 32 + 4 * c
+                if n < N:
+                    blob[T, sg, lane, :4] = w[n, k:k + 4]
+                    blob[T, sg, lane, 4:] = w[n, k + 32:k + 36]
+    return blob
+
+
+def _panel_block(x, w, m0, MT, NT, NW):
+    """One workgroup of linear_panel_kernel<., MT, NT, NW>: returns the (rows, N) outputs it stores (NaN elsewhere)."""
+    M, K = x.shape
+    N = w.shape[0]
+    BM, TW = MT * 32, NT * 32
+    NPAIR = (BM // 8) * 4
+    nct = (N + TW - 1) // TW
+    nstep = K // 16
+    blob = _panel_pack_weight(w, ((N + 63) // 64) * 2)
+    y = np.full((M, N), np.nan)
+    acc = np.zeros((NW * 8, MT, NT, 64, 16))           # [column tile][i][j][lane][reg] (more than enough tiles)
+    for half in range(K // 256):
+        # LDS as 16-byte granules of 8 values: [pair][hi half (64 slots) | lo half]; the model keeps the 8 values of a
+        # lane's two DMA slots together in the hi slot (the split writes hi8 there; lo8 goes to the same slot + 1 KiB)
+        lds = np.zeros((NPAIR, 64, 8))
+        PPW = NPAIR // NW
+        QPW = PPW // 4
+        for wave in range(NW):
+            for lane in range(64):
+                d_rl, d_cc = lane >> 3, lane & 7
+                for u in range(QPW):
+                    q = wave * QPW + u
+                    row = _panel_row_of(q, d_rl)
+                    assert 0 <= row < BM
+                    c = d_cc ^ (row & 7)
+                    gm = min(m0 + row, M - 1)
+                    for p in range(4):
+                        k = half * 256 + (2 * p) * 32 + c * 4
+                        lds[q * 4 + p, lane, :4] = x[gm, k:k + 4]           # DMA slot A: line 2p
+                        lds[q * 4 + p, lane, 4:] = x[gm, k + 32:k + 36]     # DMA slot B: line 2p + 1
+        for wave in range(NW):
+            for ct in range(wave, nct, NW):
+                for s in range(16):
+                    af = np.zeros((MT, 64, 8))
+                    bf = np.zeros((NT, 64, 8))
+                    for lane in range(64):
+                        f_r, f_h = lane & 31, lane >> 5
+                        f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1)
+                        f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1)
+                        f_x = f_r & 7
+                        addr = f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * (s & 3)) + f_h) ^ f_x)) * 16 + (s >> 2) * 2048
+                        for i in range(MT):
+                            a = addr + i * (4 * 4 * 2048)
+                            pair, slot = a // 2048, (a % 2048) // 16
+                            assert slot < 64 and a % 16 == 0             # hi half of the pair
+                            af[i, lane] = lds[pair, slot]
+                        for j in range(NT):
+                            bf[j, lane] = blob[ct * NT + j, half * 16 + s, lane]
+                    for i in range(MT):
+                        for j in range(NT):
+                            # D[n][m]: W fragment as the MFMA's A operand
+                            acc[ct, i, j] = _mfma_32x32x16(bf[j], af[i], acc[ct, i, j])
+    for wave in range(NW):
+        for ct in range(wave, nct, NW):
+            n0 = ct * TW
+            for lane in range(64):
+                for i in range(MT):
+                    m = m0 + i * 32 + (lane & 31)
+                    for j in range(NT):
+                        nb = n0 + j * 32 + 4 * (lane >> 5)
+                        for g in range(4):
+                            n = nb + 8 * g
+                            if m < M and n < N:
+                                assert np.isnan(y[m, n:n + 4]).all()
+                                y[m, n:n + 4] = acc[ct, i, j, lane, 4 * g:4 * g + 4]
+    return y
+
+
+def test_panel_kernel_indexing_reproduces_gemm():
+    rng = np.random.default_rng(2)
+    for (MT, NT, NW), (M, N, K) in (((2, 2, 4), (150, 200, 256)), ((4, 1, 8), (150, 328, 256)),
+                                    ((2, 2, 4), (70, 192, 512)), ((4, 1, 8), (130, 256, 512))):
+        x = rng.standard_normal((M, K))
+        w = rng.standard_normal((N, K))
+        want = x @ w.T
+        got = np.full((M, N), np.nan)
+        BM = MT * 32
+        for m0 in range(0, M, BM):
+            t = _panel_block(x, w, m0, MT, NT, NW)
+            mask = ~np.isnan(t)
+            assert not (mask & ~np.isnan(got)).any(), "two workgroups wrote the same element"
+            got[mask] = t[mask]
+        assert not np.isnan(got).any(), "an output element was never written"
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11)
+
+
+def test_panel_dma_slots_cover_the_panel_once_in_full_lines():
+    for MT, NW in ((2, 4), (4, 8)):
+        BM = MT * 32
+        NPAIR = (BM // 8) * 4
+        QPW = NPAIR // NW // 4
+        seen = set()
+        for wave in range(NW):
+            for u in range(QPW):
+                q = wave * QPW + u
+                for p in range(4):
+                    lines = {}
+                    for lane in range(64):
+                        row = _panel_row_of(q, lane >> 3)
+                        c = (lane & 7) ^ (row & 7)
+                        assert (row, p, c) not in seen
+                        seen.add((row, p, c))
+                        lines.setdefault(row, set()).add(c)
+                    # one DMA instruction = 8 rows x one full 128-byte line (8 lanes of 16 bytes per row)
+                    assert len(lines) == 8 and all(v == set(range(8)) for v in lines.values())
+        assert len(seen) == BM * 4 * 8
+
+
+def test_panel_lds_image_is_conflict_free_for_b128_fragment_reads():
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for s in range(16):
+        for g in groups:
+            banks = set()
+            for lane in g:
+                f_r, f_h = lane & 31, lane >> 5
+                f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1)
+                f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1)
+                byte = f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * (s & 3)) + f_h) ^ (f_r & 7))) * 16 + (s >> 2) * 2048
+                for d in range(4):
+                    banks.add((byte // 4 + d) % 64)
+            assert len(banks) == 64, (s, g)
