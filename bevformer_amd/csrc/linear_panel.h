@@ -58,7 +58,16 @@ struct PanelArgs {
   long ldres;
   const float *gamma, *beta;
   float eps;
+#ifdef BEVMSDA_PANEL_DIAG
+  int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
+                                    //   3 activation fragments of step 0 only, 4 no panel fetch / split
+#endif
 };
+#ifdef BEVMSDA_PANEL_DIAG
+#define PANEL_DIAG(a, bit) (((a).diag >> (bit)) & 1)
+#else
+#define PANEL_DIAG(a, bit) 0
+#endif
 
 constexpr int kPanelK = 256;        // k per panel pass (8 lines of 128 bytes per row)
 
@@ -71,9 +80,41 @@ __device__ __forceinline__ float4 panel_gsum(const float4 &r0, bool h0, const fl
                      ((h0 ? r0.z : 0.f) + (h1 ? r1.z : 0.f)) * sc, ((h0 ? r0.w : 0.f) + (h1 ? r1.w : 0.f)) * sc);
 }
 
+typedef unsigned panel_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned panel_u32x2 __attribute__((ext_vector_type(2)));
+// 16- / 8-byte global store with cache policy bits (the raw-buffer builtin carries them; a null-offset descriptor over the
+// whole address space would need 64-bit offsets, so the descriptor is rebuilt on the element's own address: base = p, offset 0)
+template <int AUX>
+__device__ __forceinline__ void panel_store(float *p, const float4 &v) {
+  if constexpr (AUX == 0) {
+    *reinterpret_cast<float4 *>(p) = v;
+  } else {
+    const panel_u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    if constexpr (AUX == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    else if constexpr (AUX == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  }
+}
+template <int AUX>
+__device__ __forceinline__ void panel_store(uint16_t *p, const uint2 &v) {
+  if constexpr (AUX == 0) {
+    *reinterpret_cast<uint2 *>(p) = v;
+  } else {
+    const panel_u32x2 d = {v.x, v.y};
+    if constexpr (AUX == 2) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    else if constexpr (AUX == 16) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  }
+}
+
 // MT x NT MFMA tiles of 32 x 32 per wavefront tile, NW wavefronts, BM = 32 MT rows per workgroup.
 // PRE: what the split pass adds to the fetched rows: 0 nothing, 1 an addend matrix (a0 / a1, each optional), 2 gather mode.
-template <int NPROD, int MT, int NT, int NW, bool LN, int PRE>
+// STAUX / LDAUX: cache policy bits of the epilogue stores / the panel fetch (0 = default, 2 = nt, 16 = sc1, 18 = both).  The
+// output streams through once; left at the default policy its lines stay in the XCD's L2 and push out the weight image
+// every wavefront re-reads (tools/gemm_diag/panel_run.py).
+// DRIP: a finished column tile's accumulators move to a second register set and are stored ONE 16-byte piece per k16 step
+// of the next tile instead of as a burst of 16 stores at the tile's end.
+template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_panel_kernel(const PanelArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -119,6 +160,7 @@ linear_panel_kernel(const PanelArgs a) {
 
   // weight fragments of (column tile ct, global step sg) -> ring stage st
   auto wload = [&](int st, int ct, int sg) {
+    if (PANEL_DIAG(a, 2) && (sg & 15) > 1) return;
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
@@ -127,6 +169,40 @@ linear_panel_kernel(const PanelArgs a) {
         wf[st][jn][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
       }
   };
+
+  // one 16-byte piece of a finished column tile: piece pc = (MFMA tile i, j, register group g): bias, ReLU, store.
+  // MFMA D tile (W fragment as the A operand): lane holds output row m = lane & 31 and, in registers 4g .. 4g + 3,
+  // columns nb + 8g .. + 3 with nb = 4 (lane >> 5)
+  constexpr int NPIECE = MT * NT * 4;
+  auto store_piece = [&](const lin_f32x16 (&t)[MT][NT], int tct, int pc) {
+    const int i = pc / (NT * 4), j = (pc / 4) % NT, g = pc % 4;
+    const int n0 = tct * TW;
+    const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
+    const long m = m0 + i * 32 + (lane & 31);
+    const int n = n0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+    if (m >= a.M || n >= a.N) return;          // N % 4 == 0: n < N covers n .. n + 3
+    float4 v = make_float4(t[i][j][4 * g], t[i][j][4 * g + 1], t[i][j][4 * g + 2], t[i][j][4 * g + 3]);
+    if (PANEL_DIAG(a, 1) && v.x != 1.2345e30f) return;
+    if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+    if (a.relu) {                              // NaN stays NaN, as torch.relu
+      v.x = v.x < 0.f ? 0.f : v.x;
+      v.y = v.y < 0.f ? 0.f : v.y;
+      v.z = v.z < 0.f ? 0.f : v.z;
+      v.w = v.w < 0.f ? 0.f : v.w;
+    }
+    const long off = (static_cast<long>(grp) * a.M + m) * a.ldy + (n - grp * a.group_cols);
+    if (a.out_bf16) {
+      uint2 pk;
+      pk.x = lin_pack2(v.x, v.y);
+      pk.y = lin_pack2(v.z, v.w);
+      panel_store<STAUX>(reinterpret_cast<uint16_t *>(a.y) + off, pk);
+    } else {
+      panel_store<STAUX>(a.y + off, v);
+    }
+  };
+  lin_f32x16 prev[DRIP ? MT : 1][DRIP ? NT : 1];
+  int prev_ct = 0;
+  bool have_prev = false;
 
   for (int half = 0; half < nhalf; ++half) {
     // ---------------------------------------------------------------- panel pass: fetch, split, one barrier
@@ -170,12 +246,13 @@ linear_panel_kernel(const PanelArgs a) {
     for (int u = 0; u < QPW; ++u)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        if (PANEL_DIAG(a, 4)) break;
         const float *src = xs + srow[u] * ldx + (2 * p) * 32 + cx[u] * 4;
         unsigned char *dst = lds + ((wave * QPW + u) * 4 + p) * 2048;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
-                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, LDAUX);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32),
-                                         (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, LDAUX);
       }
     float4 ad[PRE ? PPW : 1][2];               // addend / second gathered row: plain loads, under the DMA
     if (PRE == 2 || add) {
@@ -207,6 +284,7 @@ linear_panel_kernel(const PanelArgs a) {
     for (int u = 0; u < QPW; ++u)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        if (PANEL_DIAG(a, 4)) break;
         unsigned char *slot = lds + ((wave * QPW + u) * 4 + p) * 2048 + lane * 16;
         float4 va = *reinterpret_cast<const float4 *>(slot);
         float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
@@ -230,6 +308,7 @@ linear_panel_kernel(const PanelArgs a) {
       const int ct_next = ct + NW;
       lin_bf16x8 af[2][MT][NPL];               // activation fragments: step s in set s & 1
       auto aload = [&](int set, int s) {
+        if (PANEL_DIAG(a, 3) && s > 1) return;
         const unsigned base = f_addr[s & 3] + (s >> 2) * 2048;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -247,11 +326,20 @@ linear_panel_kernel(const PanelArgs a) {
           wload((s + 2) % 3, ct_next, half * 16 + s + 2 - 16);
         }
         if (s + 1 < 16) aload((s + 1) & 1, s + 1);
+        if constexpr (DRIP && !LN) {
+          static_assert(!DRIP || 16 % NPIECE == 0, "pieces per tile must divide the 16 steps");
+          if ((s % (16 / NPIECE)) == 0 && have_prev) store_piece(prev, prev_ct, s / (16 / NPIECE));
+        }
         __builtin_amdgcn_sched_barrier(0);     // requests first: left alone, hipcc sinks them to the end of the step
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
+            if (PANEL_DIAG(a, 0) && s > 0) {   // operands stay live, the matrix pipe idles
+              asm volatile("" ::"v"(wf[s % 3][j][0]), "v"(af[s & 1][i][0]));
+              if (LO) asm volatile("" ::"v"(wf[s % 3][j][1]), "v"(af[s & 1][i][1]));
+              continue;
+            }
             // D[n][m]: the W fragment is the MFMA's A operand (4 consecutive output columns per lane -> float4 stores)
             if (LO) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][0], af[s & 1][i][1], acc[i][j], 0, 0, 0);
@@ -272,47 +360,35 @@ linear_panel_kernel(const PanelArgs a) {
           }
       }
       if (!last_half) continue;                // (two passes: one column tile per wavefront, checked by the launcher)
-
-      // ------------------------------------------------------------ epilogue of column tile ct
-      const int n0 = ct * TW;
       if constexpr (!LN) {
-        const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
-        float *const yg = a.y + static_cast<long>(grp) * a.M * a.ldy;
-        const int ncol0 = grp * a.group_cols;
+        if constexpr (DRIP) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const long m = m0 + i * 32 + (lane & 31);
-          float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int nb = n0 + j * 32 + 4 * (lane >> 5);
+            for (int j = 0; j < NT; ++j) {
+              prev[i][j] = acc[i][j];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int n = nb + 8 * g;
-              float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-              acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
-              if (m < a.M && n < a.N) {         // N % 4 == 0: n < N covers n .. n + 3
-                if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
-                if (a.relu) {                   // NaN stays NaN, as torch.relu
-                  v.x = v.x < 0.f ? 0.f : v.x;
-                  v.y = v.y < 0.f ? 0.f : v.y;
-                  v.z = v.z < 0.f ? 0.f : v.z;
-                  v.w = v.w < 0.f ? 0.f : v.w;
-                }
-                if (a.out_bf16) {
-                  uint2 pk;
-                  pk.x = lin_pack2(v.x, v.y);
-                  pk.y = lin_pack2(v.z, v.w);
-                  uint16_t *yb = reinterpret_cast<uint16_t *>(a.y) + (yrow - a.y) + n;
-                  *reinterpret_cast<uint2 *>(yb) = pk;
-                } else {
-                  *reinterpret_cast<float4 *>(yrow + n) = v;
-                }
-              }
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
-          }
+          prev_ct = ct;
+          have_prev = true;
+        } else {
+#pragma unroll
+          for (int pc = 0; pc < NPIECE; ++pc) store_piece(acc, ct, pc);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
       }
+    }
+  }
+  if constexpr (DRIP && !LN) {
+    if (have_prev) {
+#pragma unroll
+      for (int pc = 0; pc < NPIECE; ++pc) store_piece(prev, prev_ct, pc);
     }
   }
 
@@ -398,7 +474,7 @@ linear_panel_kernel(const PanelArgs a) {
           v.y = (acc[i][j][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
           v.z = (acc[i][j][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
           v.w = (acc[i][j][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
-          *reinterpret_cast<float4 *>(yrow + n) = v;
+          panel_store<STAUX>(yrow + n, v);
         }
       }
     }

@@ -557,7 +557,9 @@ _GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
          "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None),
          # row-panel kernel (csrc/linear_panel.h) for the calls it covers: True / False; panel_shape 0 = by problem
          # shape, 1 = 64-row panels, 2 = 128-row panels
-         "panel": os.environ.get("BEVMSDA_GEMM_PANEL", "1") == "1",
+         # None = by measurement (profiles/r3: the hoisted N >= 1024 projections and every LayerNorm-fused projection),
+         # True = wherever it applies, False = never
+         "panel": {"1": True, "0": False}.get(os.environ.get("BEVMSDA_GEMM_PANEL", ""), None),
          "panel_shape": int(os.environ.get("BEVMSDA_GEMM_PANEL_SHAPE", "0"))}
 assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 _GEMM_TIMER = {"cb": None}
@@ -641,9 +643,15 @@ def panel_weight(weight):
 
 
 def _panel_covers(N, K0, K1, groups, ln):
-    """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h)."""
+    """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h) and, unless a kernel is forced, the ones it is
+    faster on (tools/gemm_ab.py, profiles/r3): the hoisted value projections (N >= 1024: 510-570 vs 630 us and 254 vs
+    270 us per frame in split mode) and the LayerNorm-fused projections (45 vs 52 us, 59 vs 66 us); the plain
+    per-layer projections (N <= 768, 40 k rows) stay on the first kernel (30-70 us, 5-10 % ahead)."""
     K = K0 + K1
-    if not _GEMM["panel"] or _GEMM["variant"] is not None or K not in (256, 512) or K0 not in (256, 512) \
+    want = _GEMM["panel"]
+    if want is None:
+        want = ln or N >= 1024
+    if not want or _GEMM["variant"] is not None or K not in (256, 512) or K0 not in (256, 512) \
             or K1 not in (0, 256) or N % 4:
         return False
     if (K == 512 or ln) and N > 256:
@@ -658,7 +666,8 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     blob = panel_weight(w)
     if blob is None:
         return False
-    desc.reserved[2] = _GEMM["panel_shape"]
+    # panel shape: 128-row panels (half the weight traffic per MFMA, one workgroup per CU) pay from ~128 k rows on
+    desc.reserved[2] = _GEMM["panel_shape"] or (2 if desc.M >= (1 << 17) and ln is None else 1)
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
@@ -684,7 +693,7 @@ def set_gemm_kernel(name):
     applies), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined), ``"areg"`` (linear_areg.h,
     activation rows resident in registers)."""
     assert name in (None, "first", "dma", "ws", "pipe", "areg", "panel", "panel64", "panel128")
-    _GEMM["panel"] = name in (None, "panel", "panel64", "panel128")
+    _GEMM["panel"] = None if name is None else name in ("panel", "panel64", "panel128")
     _GEMM["panel_shape"] = {"panel64": 1, "panel128": 2}.get(name, 0)
     _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(name)
 
@@ -861,27 +870,26 @@ class Normed:
         self.t = t
 
 
-# Measured (profiles/r2, base frame): fused 54.6 / 62.9 / 72.4 us for tsa_output_proj / sca_output_proj /
-# ffn_fc2 against 33 + 20.6 / 38.5 + 20.6 / 51 + 20.6 us for projection + add_layernorm as two launches —
-# the epilogue's residual read and three barriers sit on a workgroup's critical path and cost what the
-# separate, 75 %-of-HBM-peak row kernel costs.  Off by default; BEVMSDA_FUSE_LN=1 turns it on.
-_LN_FUSE = {"enabled": os.environ.get("BEVMSDA_FUSE_LN", "0") == "1"}
+# Residual add + LayerNorm in the epilogue of the projection that precedes them: the row-panel kernel holds complete
+# rows per workgroup, so the norm costs one exchange through LDS instead of a second launch over the grid
+# (profiles/r3/gemm_ab: output_proj + LN 45.4 vs 51.6 us, fc2 + LN 59.3 vs 66.1 us, 24.7 vs 33.2 us at 5,000 rows).
+# Round 2's form of this on 128 x 256 tiles of the first kernel lost to two launches and is retired.
+_LN_FUSE = {"enabled": os.environ.get("BEVMSDA_FUSE_LN", "1") == "1"}
 
 
 def set_layernorm_fusion(flag):
-    """Residual add + LayerNorm in the epilogue of the projection that precedes them (off by default:
-    no faster than projection and ``add_layernorm`` as two launches, see above)."""
+    """Residual add + LayerNorm in the epilogue of the projection that precedes them (row-panel kernel)."""
     _LN_FUSE["enabled"] = bool(flag)
 
 
 def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
-    """``LayerNorm(linear(A, weight, bias) + res)`` in one kernel (``bevmsda_linear_layernorm_packed_f32``),
+    """``LayerNorm(linear(A, weight, bias) + res)`` in one kernel (``bevmsda_linear_panel_f32`` with a LayerNorm descriptor),
     A = ``x`` or, with ``gather = (idx (Q, 2) int32, scale (Q,))``, the camera mean of SpatialCrossAttention
     over the rows of ``x``.  ``norm``: an ``nn.LayerNorm`` over N = 256.  Returns ``None`` when not covered
     (then the caller runs the projection and ``add_layernorm``)."""
     mode = _GEMM["mode"]
-    if not _LN_FUSE["enabled"] or mode == "native" or not _GEMM["pack"] or _GEMM["variant"] is not None \
-            or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None \
+    if not _LN_FUSE["enabled"] or _GEMM["panel"] is False or mode == "native" or not _GEMM["pack"] \
+            or _GEMM["variant"] is not None or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None \
             or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
             or weight.shape[0] != 256 or tuple(norm.normalized_shape) != (256,) \
             or not fused_wanted(x, weight, bias, res, norm.weight):
@@ -924,23 +932,7 @@ def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
             desc, x0, None, None, None, idx if gather is not None else None, scale if gather is not None else None,
             w, bias.contiguous() if bias is not None else None, ln, y, tag, 2.0 * M * 256 * K, nbytes):
         return y.view(*lead, 256)
-    blob = packed_weight(w)
-    if blob is None:
-        return None
-    if os.environ.get("BEVMSDA_LN_BM") == "128":        # benchmark knob: 128-row tiles (half the workgroups)
-        desc.reserved[0] = 1
-    lib = _lib.load()
-    cb = _GEMM_TIMER["cb"]
-    ctx = cb(tag, 2.0 * M * 256 * K, nbytes) if cb is not None else _NoTimer()
-    with torch.cuda.device(x.device), ctx:
-        rc = lib.bevmsda_linear_layernorm_packed_f32(
-            _ptr(x0), None, None, None, _ptr(idx) if gather is not None else None,
-            _ptr(scale) if gather is not None else None, _ptr(blob), _ptr(bias.contiguous()) if bias is not None else None,
-            ctypes.byref(desc), ctypes.byref(ln), _ptr(y), torch.cuda.current_stream().cuda_stream)
-    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
-        return None
-    _lib.check(rc, "linear_layernorm")
-    return y.view(*lead, 256)
+    return None
 
 
 def transposed_weight(weight):
