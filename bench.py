@@ -57,8 +57,6 @@ def parse():
     ap.add_argument("--value-storage", default="fp32", choices=["fp32", "bf16"],
                     help="storage of the projected value tensors (bf16: written by the projection "
                          "kernel, sampled by the 16-byte-lane bf16 kernel; arithmetic stays fp32)")
-    ap.add_argument("--sca-lds", default=None, choices=["on", "off"],
-                    help="SCA sampling kernel with the coarsest level staged in LDS (host-built plans only)")
     ap.add_argument("--queue", type=int, default=0,
                     help="N > 0: a step is N consecutive frames through PerceptionTransformer.get_bev_features "
                          "(ego-motion shift, prev-BEV rotation, can-bus MLP, flatten + embeddings, encoder), each "
@@ -509,8 +507,6 @@ def main():
     gemm = args.gemm or ops.gemm_mode()
     cfg = Config(args, dev, args.workload, gemm, args.value_storage, args.backward, args.first_frame, world, tiling)
     cfg.modes()
-    if args.sca_lds:
-        ops.set_sca_lds_level(args.sca_lds == "on")
     timer = KernelTimer()
     if not args.no_kernel_timers:
         ops.set_kernel_timer(timer)
@@ -641,7 +637,6 @@ def main():
                                     "rebuilt by the HIP plan kernels inside the timed step" if cfg.fresh else
                                     "same camera matrices every step: frame plan built once (static rig)"),
                        "sca_row_order": row_order_used,
-                       "sca_coarse_level_from_lds": bool(ops._FUSED["lds_level"]),
                        "value_storage": args.value_storage,
                        "gemm": gemm_desc,
                        "global_batch": 1, "parallelism": f"bev-row-tiles x{world}" if world > 1 else "single GPU",

@@ -12,7 +12,7 @@ from .build import LIB_PATH
 _c_int = ctypes.c_int
 _c_void_p = ctypes.c_void_p
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Tuning(ctypes.Structure):
@@ -93,10 +93,6 @@ SIGNATURES = {
     "bevmsda_frame_plan_f32": ([_c_void_p] * 3 + [ctypes.POINTER(PlanDesc)] + [_c_void_p] * 12, _c_int),
     "bevmsda_fold_extra_rows_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int,
                                      _c_void_p, _c_void_p], _c_int),
-    "bevmsda_fused_forward_lds2_f32": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
-                                       _c_int),
-    "bevmsda_fused_forward_lds_f32": ([_c_void_p] * 8 + [ctypes.POINTER(FusedDesc), _c_int, _c_int, _c_void_p,
-                                                          _c_void_p], _c_int),
     "bevmsda_add_layernorm_f32": ([_c_void_p] * 4 + [ctypes.c_float, ctypes.c_int64, _c_int,
                                                      _c_void_p, _c_void_p], _c_int),
     "bevmsda_add_layernorm_backward_partials": ([ctypes.c_int64], ctypes.c_int64),
@@ -109,8 +105,6 @@ SIGNATURES = {
                                   _c_int),
     "bevmsda_linear_gather_packed_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
-    "bevmsda_linear_layernorm_packed_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
-                                                             _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_panel_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_panel_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                              _c_int),

@@ -7,7 +7,6 @@
 #include "msda_d32.h"
 #include "msda_bwd_lds.h"
 #include "msda_bwd_gather.h"
-#include "msda_lds2.h"
 #include "rowops.h"
 #include "prologue.h"
 
@@ -21,10 +20,7 @@ constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
 constexpr int kGvRowsPerBlock = 256;         // rows of one head per workgroup of the LDS-tiled grad_value kernel
 constexpr long kDynGridBlocks = 2048;        // grid of the device-row-count sampling launches (multiple of 8)
-constexpr int kLds2RowsPerBlock = 256;       // msda_lds2.h: rows of one head per workgroup
-constexpr int kLds2Cap2 = 704, kLds2Cap3 = 384;   // its LDS tiles (pixels): (704 + 384 + 128 slack) x 128 B = 152 KB, one workgroup per CU
                                              // (128 rows with 320 + 128 pixels, two workgroups per CU: 320 us vs 270 us)
-constexpr int kLdsLevelRowsPerBlock = 256;   // rows of one (camera, head) per block of the LDS-level kernel
 
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -87,8 +83,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     // 256 rows / 1024 threads per workgroup (one per CU) for single-level calls (TemporalSelfAttention: the
     // 16 x 16 grid tiles), 128 rows / 512 threads (two per CU: one sorts while the other's flushes drain) for
     // multi-level calls — measured on the padded base SCA call, image-ordered rows: 1.13 vs 1.27 ms (raster rows:
-    // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  BEVMSDA_GV_ROWS=128 / 256 forces one.
-    static const int gv_forced = [] { const char *e = getenv("BEVMSDA_GV_ROWS"); return e ? atoi(e) : 0; }();
+    // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  tuning->reserved[0] = 64 / 128 / 256 forces one.
+    const int gv_forced = a.gv_rows;           // bevmsda_tuning.reserved[0]
     const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? 128 : kGvRowsPerBlock);
     const int gv_threads = gv_rows == 64 ? 256 : (gv_rows == 128 ? 512 : bevmsda::kGvThreads);
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
@@ -109,9 +105,9 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       const size_t lds_bytes = (static_cast<size_t>(bevmsda::kGvBuckets) + static_cast<size_t>(s.rows_per_block) * a.P * 8 +
                                 static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4;
       const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(gv_threads);
-      // BEVMSDA_GV_PROFILE=<hex device address of 8 uint64>: phase clocks of the sort kernel (tools/gvprof.py)
-      const char *pe = getenv("BEVMSDA_GV_PROFILE");
-      if (pe) s.prof = reinterpret_cast<unsigned long long *>(strtoull(pe, nullptr, 16));
+      // tuning->reserved[1..2] = device address of 8 uint64 (low, high word): phase clocks of the sort kernel (tools/gvprof.py)
+      unsigned long long *const pe = a.gv_prof;
+      if (pe) s.prof = pe;
 #define BEVMSDA_GV(RPT_)                                                                                                \
   do {                                                                                                                  \
     if (pe) {                                                                                                           \
@@ -147,8 +143,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       // else the first-generation kernel without its scatter
       if (d32_fwd_eligible<T>(a)) {
         // (P = 8 in fp32 needs 140 VGPRs for two batches of 16 taps in flight: 3 waves / SIMD)
-        // bf16 storage: the 16-byte-lane form (2 requests per point); BEVMSDA_BF16_LANES8 keeps the 8-byte-lane one
-        static const bool lanes8 = getenv("BEVMSDA_BF16_LANES8") != nullptr;
+        // bf16 storage: the 16-byte-lane form (2 requests per point); tuning->reserved[3] = 1 keeps the 8-byte-lane one
+        const bool lanes8 = a.bf16_lanes8 != 0;
         if (sizeof(T) == 2 && !lanes8 && (reinterpret_cast<uintptr_t>(a.grad_out) & 15u) == 0) {
           if (a.P == 8) hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_bf16x8_kernel<8, 4>), dim3(grid8), dim3(256), 0, stream, b);
           else hipLaunchKernelGGL((bevmsda::msda_gradloc_d32_bf16x8_kernel<4, 4>), dim3(grid8), dim3(256), 0, stream, b);
@@ -308,6 +304,11 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   if (variant < 0 || variant > 5) return BEVMSDA_ERR_BAD_OPTION;
   if (variant > 3) variant = 0;  // 4, 5 select forward kernels only; 3 = first-generation D = 32 backward
   a.variant = variant;
+  a.gv_rows = tuning ? tuning->reserved[0] : 0;
+  a.gv_prof = tuning ? reinterpret_cast<unsigned long long *>((static_cast<unsigned long long>(static_cast<uint32_t>(tuning->reserved[2])) << 32) |
+                                                              static_cast<uint32_t>(tuning->reserved[1]))
+                     : nullptr;
+  a.bf16_lanes8 = tuning ? tuning->reserved[3] : 0;
   a.mshift = ilog2_exact(M);
   a.qshift = ilog2_exact(a.qtile);
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
@@ -425,113 +426,6 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   } else {
     if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 4>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 1, 8>), grid, dim3(256), 0, st, f);
-  }
-  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-}
-
-// SCA forward with the coarsest level staged in LDS (msda_d32.h, msda_fused_d32_ldslevel_kernel)
-int fused_lds_impl(const float *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
-                   const float *logits, const float *ref, const int32_t *row_src, const int32_t *cam_start,
-                   const bevmsda_fused_desc *d, int lds_pixels, int max_cam_rows, float *out, void *stream) {
-  if (!d) return BEVMSDA_ERR_NULL_POINTER;
-  if (d->R < 0 || d->N <= 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->A <= 0 || lds_pixels < 0 || max_cam_rows < 0)
-    return BEVMSDA_ERR_BAD_SHAPE;
-  const unsigned long long bytes = 1ULL * d->N * d->S * d->M * d->D * sizeof(float);
-  if (d->D != 32 || d->P != 8 || d->K != 1 || d->L < 1 || d->L > 4 || d->ref_mode != 0 || d->vmul != 1 ||
-      d->vadd != 0 || bytes >= (1ULL << 31) || (d->proj_row & 1) || (d->off_head & 1) || lds_pixels == 0 ||
-      lds_pixels > 512)                                   // 512 pixels x 128 B = the 64 KB a block may take
-    return BEVMSDA_ERR_UNSUPPORTED;
-  if (d->R == 0 || max_cam_rows == 0) return BEVMSDA_OK;
-  if (!value || !shapes || !lstart || !offs || !logits || !ref || !out || !cam_start) return BEVMSDA_ERR_NULL_POINTER;
-  if (misaligned(value) || misaligned(out) || (reinterpret_cast<uintptr_t>(offs) & 7u) ||
-      (reinterpret_cast<uintptr_t>(ref) & 7u) || (reinterpret_cast<uintptr_t>(logits) & 3u))
-    return BEVMSDA_ERR_MISALIGNED;
-  bevmsda::FusedLdsArgs g{};
-  bevmsda::FusedArgs &f = g.f;
-  KArgs &a = f.k;
-  a.value = value; a.shapes = shapes; a.lstart = lstart; a.out = out; a.row_batch = nullptr;
-  a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = 1; a.P = d->P;
-  f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
-  f.off_head = d->off_head; f.off_k = 0; f.lg_head = d->lg_head; f.lg_k = 0;
-  f.K = 1; f.A = d->A; f.ref_mode = 0; f.vmul = 1; f.vadd = 0; f.out_scale = 1.0f;
-  g.cam_start = cam_start;
-  g.rows_per_block = kLdsLevelRowsPerBlock;
-  g.chunks = (max_cam_rows + g.rows_per_block - 1) / g.rows_per_block;
-  g.lds_pixels = lds_pixels;
-  const long long nb = 1LL * d->N * d->M * g.chunks;
-  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  const size_t lds_bytes = static_cast<size_t>(lds_pixels) * 32 * sizeof(float);
-  hipLaunchKernelGGL((bevmsda::msda_fused_d32_ldslevel_kernel<3>), dim3(static_cast<unsigned>(nb)), dim3(256), lds_bytes,
-                     static_cast<hipStream_t>(stream), g);
-  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-}
-
-// SCA forward with the two coarse levels of a (camera, head) patch in LDS (msda_lds2.h)
-int fused_lds2_impl(const float *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
-                    const float *logits, const float *ref, const int32_t *row_batch, const int32_t *row_src,
-                    const int32_t *nrows, const bevmsda_fused_desc *d, float *out, void *stream) {
-  if (!d) return BEVMSDA_ERR_NULL_POINTER;
-  if (d->R < 0 || d->N <= 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->A <= 0) return BEVMSDA_ERR_BAD_SHAPE;
-  const unsigned long long bytes = 1ULL * d->N * d->S * d->M * d->D * sizeof(float);
-  if (d->D != 32 || d->P != 8 || d->K != 1 || d->L != 4 || d->ref_mode != 0 || d->vmul != 1 || d->vadd != 0 ||
-      bytes >= (1ULL << 31) || (d->proj_row & 1) || (d->off_head & 1) || d->R >= (1LL << 27) || d->reserved[0] != 0)
-    return BEVMSDA_ERR_UNSUPPORTED;
-  if (d->R == 0) return BEVMSDA_OK;
-  if (!value || !shapes || !lstart || !offs || !logits || !ref || !out) return BEVMSDA_ERR_NULL_POINTER;
-  if (!row_batch && d->Q <= 0) return BEVMSDA_ERR_BAD_SHAPE;
-  if (misaligned(value) || misaligned(out) || (reinterpret_cast<uintptr_t>(offs) & 7u) ||
-      (reinterpret_cast<uintptr_t>(ref) & 7u) || (reinterpret_cast<uintptr_t>(logits) & 3u))
-    return BEVMSDA_ERR_MISALIGNED;
-  bevmsda::Lds2Args g{};
-  bevmsda::FusedArgs &f = g.f;
-  KArgs &a = f.k;
-  a.value = value; a.shapes = shapes; a.lstart = lstart; a.out = out; a.row_batch = row_batch;
-  a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = d->Q > 0 ? d->Q : 1; a.P = d->P;
-  a.qtile = kDefaultQtileFwd; a.xcd_remap = 1;
-  a.mshift = ilog2_exact(a.M); a.qshift = ilog2_exact(a.qtile);
-  f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
-  f.off_head = d->off_head; f.off_k = 0; f.lg_head = d->lg_head; f.lg_k = 0;
-  f.K = 1; f.A = d->A; f.ref_mode = 0; f.vmul = 1; f.vadd = 0; f.out_scale = 1.0f; f.out_f32 = 0;
-  g.rows_per_block = kLds2RowsPerBlock;
-  g.cap2 = kLds2Cap2;
-  g.cap3 = kLds2Cap3;
-  const size_t lds_bytes = (static_cast<size_t>(g.cap2 + 64 + g.cap3 + 64) * 32 + 12) * sizeof(float);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  long long rows = d->R;
-  if (nrows) {
-    long long hint = d->reserved[3];
-    if (hint < 0) return BEVMSDA_ERR_BAD_OPTION;
-    if (hint > d->R) hint = d->R;
-    f.nrows = nrows;
-    f.launch_rows = static_cast<int>(hint);
-    rows = hint;
-  }
-  if (rows > 0) {
-    const long long chunks = (rows + g.rows_per_block - 1) / g.rows_per_block;
-    if (chunks * d->M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-    const dim3 grid(static_cast<unsigned>(chunks * d->M)), block(bevmsda::kLds2Threads);
-    if (nrows) {
-      auto kern = bevmsda::msda_fused_d32_lds2_kernel<true>;
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
-      hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, g);
-    } else {
-      auto kern = bevmsda::msda_fused_d32_lds2_kernel<false>;
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
-      hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, g);
-    }
-  }
-  if (nrows && rows < d->R) {
-    // rows beyond the hint: the strided tail launch of the plain fused kernel (msda_d32.h, DynRows)
-    const long tiles = (d->R + a.qtile - 1) / a.qtile;
-    const long nb = (tiles * a.qtile * a.M + 31) / 32;
-    const long htiles = (rows + a.qtile - 1) / a.qtile;
-    const long hnb = (htiles * a.qtile * a.M + 31) / 32;
-    const long rest = ((nb - hnb + 7) / 8) * 8;
-    const dim3 tgrid(static_cast<unsigned>(rest < 8 ? 8 : (rest < kDynGridBlocks ? rest : kDynGridBlocks)));
-    a.nblocks = static_cast<int>(nb);
-    hipLaunchKernelGGL((bevmsda::msda_fused_d32_dyn_kernel<float, 8, 1, 4>), tgrid, dim3(256), 0, st, f);
   }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
@@ -678,23 +572,6 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
   if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
   return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out,
                             stream, nrows);
-}
-
-int bevmsda_fused_forward_lds2_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
-                                   const float *offs, const float *logits, const float *ref,
-                                   const int32_t *row_batch, const int32_t *row_src, const int32_t *nrows,
-                                   const bevmsda_fused_desc *desc, float *out, void *stream) {
-  return fused_lds2_impl(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, nrows, desc, out,
-                         stream);
-}
-
-int bevmsda_fused_forward_lds_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
-                                  const float *offs, const float *logits, const float *ref,
-                                  const int32_t *row_src, const int32_t *cam_start,
-                                  const bevmsda_fused_desc *desc, int lds_pixels, int max_cam_rows, float *out,
-                                  void *stream) {
-  return fused_lds_impl(value, spatial_shapes, level_start, offs, logits, ref, row_src, cam_start, desc,
-                        lds_pixels, max_cam_rows, out, stream);
 }
 
 int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,

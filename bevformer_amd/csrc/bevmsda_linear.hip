@@ -1,26 +1,14 @@
 // C ABI of libbevmsda.so, dense projections (declared in include/bevmsda.h): argument checks and
-// launches of the MFMA projection kernel (linear_mfma.h).  No torch, no allocation, no global state.
+// launches of the MFMA projection kernels (linear_mfma.h, linear_pipe.h, linear_panel.h, wgrad_mfma.h).  No torch, no allocation, no global state.
 #include "../../include/bevmsda.h"
 #include "linear_mfma.h"
-#include "linear_dma.h"
-#include "linear_ws.h"
 #include "linear_pipe.h"
-#include "linear_areg.h"
 #include "linear_panel.h"
 #include "wgrad_mfma.h"
 
 namespace {
-// projection GEMM launch variants (sweep: profiles/r1/r1h_gbench_variants.txt)
-constexpr int kLinearDefaultVariant = 0;         // fp32 weight: 32-deep chunks, transposed-tile float4 epilogue
-constexpr int kLinearDefaultPackedVariant = 12;  // packed weight: LDS-DMA into a single W area, float4 epilogue
-constexpr bool kLinearDmaDefault = false;        // linear_dma.h as the default where it applies (set from measurements)
-constexpr int kLinearAregMinN = 0;               // linear_areg.h as the default for N >= this and M >= kLinearAregMinM (0: never:
-                                                 // inside the bench step it measured 640-665 us against 600-605 us for the first kernel)
-constexpr long long kLinearAregMinM = 1LL << 17; // (the camera-value projection of all layers; the 80 k-row BEV-value one loses: 1.22 rounds)
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
 constexpr long long kLinearPipeMaxRows = 8192;   // ... and always for M <= this
-constexpr bool kLinearWsDefault = false;         // linear_ws.h (weight-stationary) as the default where it applies
-constexpr long long kLinearWsMinWork = 1LL << 24;  // M * N below this: too few rows per wavefront to pay for the W copy
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 }  // namespace
 
@@ -28,8 +16,7 @@ extern "C" {
 
 static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
                          const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
-                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr,
-                         const bevmsda_layernorm_desc *ln = nullptr) {
+                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -54,93 +41,16 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;
   a.w = w; a.ldw = d->ldw; a.wpack = wpack; a.bias = bias; a.y = y; a.ldy = d->ldy;
   a.gidx = gidx; a.gscale = gscale;
-  a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
   a.out_bf16 = d->out_bf16 ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool add = a.a0 != nullptr || a.a1 != nullptr || gidx != nullptr;
-  // launch variant v (desc->reserved[0] = 1 + v; 0 = library default):
-  //   bit 0: 64-deep K chunks (fp32 weight only; needs K0 % 64 == 0 when a second source follows)
-  //   bit 1: dword-row epilogue instead of the transposed-tile float4 one
-  //   bits 2-3: packed-weight copy mode 1 = registers, 2 = LDS-DMA double-buffered, 3 = LDS-DMA single
-  //   bit 4: 256-column block tiles (copy mode 3 only; N and group_cols multiples of 256, else 128)
-  //   bit 5: fragments-first schedule (copy mode 3, 128-column tiles): see linear_mfma.h FRAGS
-  //   bit 6: 64-row block tiles, 5 blocks / CU (copy mode 3, 128-column tiles): see linear_mfma.h BM
-  if (ln) {
-    // y = LayerNorm(A W^T + bias + res): 128 x 256 tiles (whole rows per workgroup), packed weights
-    if (d->N != 256 || !wpack || gcols != 0 || d->relu || d->out_bf16 || d->ldy % 4 != 0 || d->variant != 0)
-      return BEVMSDA_ERR_UNSUPPORTED;
-    if (!ln->gamma || !ln->beta) return BEVMSDA_ERR_NULL_POINTER;
-    if (misaligned(ln->gamma) || misaligned(ln->beta) || misaligned(y) || (bias && misaligned(bias)) ||
-        (ln->res && (misaligned(ln->res) || ln->ldres % 4 != 0 || ln->ldres < d->N)))
-      return BEVMSDA_ERR_MISALIGNED;
-    a.res = ln->res; a.ldres = ln->ldres; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
-    // 64-row tiles (four wavefronts side by side, 64 columns each): twice the workgroups of the 128-row
-    // form — M = 40 k rows give 625 of them, which fills the chip; desc->reserved[0] = 1 selects 128 rows
-    const int bm = d->reserved[0] == 1 ? 128 : 64;
-    const long long nbm = (d->M + bm - 1) / bm;
-    if (nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
-    a.nblk_m = static_cast<int>(nbm);
-    a.nblk_n = 1;
-    const dim3 g(static_cast<unsigned>(((nbm + 7) / 8) * 8)), b(256);
-#define BEVMSDA_LNK(NP_, BM_)                                                                                               \
-  do {                                                                                                                      \
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, true, 3, 256, false, BM_, true>), g, b, 0, st, a);  \
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, true, 3, 256, false, BM_, true>), g, b, 0, st, a);     \
-  } while (0)
-    if (d->precision == 0) { if (bm == 64) BEVMSDA_LNK(3, 64); else BEVMSDA_LNK(3, 128); }
-    else { if (bm == 64) BEVMSDA_LNK(1, 64); else BEVMSDA_LNK(1, 128); }
-#undef BEVMSDA_LNK
-    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-  }
-  // second kernel (linear_dma.h): activations by LDS-DMA.  Default for the calls it covers — packed weights, no
-  // addends / gather, float4-epilogue conditions — unless desc->variant picks a variant of the first kernel;
-  // desc->variant = 129 forces it (BEVMSDA_ERR_UNSUPPORTED when not covered), desc->reserved[1] = 1 disables it
-  {
-    const bool covered = wpack && !add && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
-                         (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
-    if (d->variant == 129 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
-    if (covered && (d->variant == 129 || (d->variant == 0 && d->reserved[1] == 0 && kLinearDmaDefault))) {
-      const long long nbm = (d->M + 127) / 128, nbn = (d->N + 127) / 128;
-      const long long grid = ((nbm + 7) / 8) * 8 * nbn;
-      if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
-      a.nblk_m = static_cast<int>(nbm);
-      a.nblk_n = static_cast<int>(nbn);
-      if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_dma_kernel<3>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((bevmsda::linear_dma_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, a);
-      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-    }
-  }
-  // activation-stationary kernel (linear_areg.h): desc->variant = 132 forces it (BEVMSDA_ERR_UNSUPPORTED when not
-  // covered), desc->reserved[1] = 1 disables it
-  {
-    const bool covered = wpack && !add && d->K0 == 256 && d->K1 == 0 && (d->N % 128) == 0 && (d->ldy % 4) == 0 &&
-                         (gcols % 4) == 0 && !misaligned(y) && (!bias || !misaligned(bias)) &&
-                         (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
-    if (d->variant == 132 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
-    if (covered && (d->variant == 132 || (d->variant == 0 && d->reserved[1] == 0 && kLinearAregMinN > 0 &&
-                                          d->N >= kLinearAregMinN && d->M >= kLinearAregMinM))) {
-      const long long nb = (d->M + bevmsda::kAregRows - 1) / bevmsda::kAregRows;
-      if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-      a.nblk_n = d->N / 128;
-      a.nblk_m = static_cast<int>(nb);
-      const dim3 grid(static_cast<unsigned>(nb)), block(bevmsda::kAregThreads);
-#define BEVMSDA_AREG(NP_)                                                                                             \
-  do {                                                                                                                \
-    auto kern = bevmsda::linear_areg_kernel<NP_>;                                                                     \
-    const int dyn = 6 * ((NP_) == 3 ? 2 : 1) * bevmsda::kAregPlane * 2;                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != \
-        hipSuccess) return BEVMSDA_ERR_LAUNCH;                                                                        \
-    hipLaunchKernelGGL(kern, grid, block, dyn, st, a);                                                                \
-  } while (0)
-      if (d->precision == 0) BEVMSDA_AREG(3); else BEVMSDA_AREG(1);
-#undef BEVMSDA_AREG
-      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-    }
-  }
-  // software-pipelined kernel (linear_pipe.h): desc->variant = 131 forces it (BEVMSDA_ERR_UNSUPPORTED when not
-  // covered), desc->reserved[1] = 1 disables it
+  // desc->variant: 0 = library default; 1 = the first kernel over the fp32 weight matrix, 13 = over the packed weight
+  // image (LDS-DMA into a single W area); 131 = the software-pipelined kernel (BEVMSDA_ERR_UNSUPPORTED when it does not
+  // cover the call).  desc->reserved[1] = 1 keeps the default off the software-pipelined kernel.
+  if (d->variant != 0 && d->variant != 1 && d->variant != 13 && d->variant != 131) return BEVMSDA_ERR_BAD_OPTION;
+  // software-pipelined kernel (linear_pipe.h)
   {
     const int nch = (d->K0 + d->K1) / 32;
     const bool covered = wpack && !add && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
@@ -169,110 +79,26 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
       return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
     }
   }
-  // third kernel (linear_ws.h): weight-stationary, activations straight into MFMA fragments.  desc->variant = 130
-  // forces it (BEVMSDA_ERR_UNSUPPORTED when not covered), desc->reserved[1] = 1 disables it
-  {
-    const int nprod = d->precision == 0 ? 3 : 1;
-    const long lds_bytes = bevmsda::ws_lds_bytes(d->K0, nprod);
-    const bool covered = wpack && !add && d->K1 == 0 && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 &&
-                         !misaligned(y) && (!bias || !misaligned(bias)) &&
-                         (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) && lds_bytes <= bevmsda::kWsLdsLimit;
-    if (d->variant == 130 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
-    if (covered && (d->variant == 130 || (d->variant == 0 && d->reserved[1] == 0 && kLinearWsDefault &&
-                                          1LL * d->M * d->N >= kLinearWsMinWork))) {
-      const long long nbn = (d->N + bevmsda::kWsBN - 1) / bevmsda::kWsBN;
-      constexpr int wpb = bevmsda::kWsThreads / 64;
-      long long slabs = nbn >= 256 ? 1 : 256 / nbn;
-      long long rows = (d->M + slabs * wpb - 1) / (slabs * wpb);
-      rows = ((rows + 31) / 32) * 32;
-      slabs = (d->M + rows * wpb - 1) / (rows * wpb);
-      const long long grid = ((slabs + 7) / 8) * 8 * nbn;
-      if (grid >= (1LL << 31) || rows >= (1LL << 30)) return BEVMSDA_ERR_TOO_LARGE;
-      bevmsda::WsArgs g;
-      g.l = a;
-      g.l.nblk_n = static_cast<int>(nbn);
-      g.l.nblk_m = 0;
-      g.rows_per_wave = static_cast<int>(rows);
-      g.slabs = static_cast<int>(slabs);
-#define BEVMSDA_WS(NP_)                                                                                               \
-  do {                                                                                                                \
-    auto kern = bevmsda::linear_ws_kernel<NP_>;                                                                       \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                            static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;                    \
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(bevmsda::kWsThreads), lds_bytes, st, g);         \
-  } while (0)
-      if (nprod == 3) BEVMSDA_WS(3); else BEVMSDA_WS(1);
-#undef BEVMSDA_WS
-      return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-    }
-  }
-  int v = d->variant > 0 ? d->variant - 1 : (wpack ? kLinearDefaultPackedVariant : kLinearDefaultVariant);
-  // 256-column tiles (2 blocks / CU) and the fragments-first schedule (3 blocks / CU) stay opt-in: both
-  // measured within noise of, or behind, the 4-blocks-per-CU default on every layer shape (r1j / r1l
-  // sweeps; the hoisted N = 1536 projection got 11 % slower with 256-column tiles, r1k vs r1i)
-  if (v < 0 || v > 127) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 112) && (v >> 2 & 3) != 3) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 112) != 0 && (v & 112) != 16 && (v & 112) != 32 && (v & 112) != 64) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 16) && (d->N % 256 != 0 || gcols % 256 != 0)) v &= ~16;
-  const int bn = (v & 16) ? 256 : bevmsda::kLinBN;
-  const int wmode = (v >> 2) & 3;
-  const int bm = (v & 64) ? 64 : bevmsda::kLinBM;
-  const long long nbm = (d->M + bm - 1) / bm;
-  const long long nbn = (d->N + bn - 1) / bn;
+  if ((d->variant == 1 && wpack) || (d->variant == 13 && !wpack)) return BEVMSDA_ERR_BAD_OPTION;
+  const long long nbm = (d->M + bevmsda::kLinBM - 1) / bevmsda::kLinBM;
+  const long long nbn = (d->N + bevmsda::kLinBN - 1) / bevmsda::kLinBN;
   const long long grid = ((nbm + 7) / 8) * 8 * nbn;
   if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
   a.nblk_m = static_cast<int>(nbm);
   a.nblk_n = static_cast<int>(nbn);
   const dim3 g(static_cast<unsigned>(grid)), b(256);
-  if ((wmode > 0) != (wpack != nullptr)) return BEVMSDA_ERR_BAD_OPTION;
-  if (wmode > 0 && (v & 1)) return BEVMSDA_ERR_BAD_OPTION;
-  if ((v & 1) && ((d->K0 + d->K1) % 64 != 0 || (d->K1 > 0 && d->K0 % 64 != 0))) v &= ~1;
-  // bf16 output: only the transposed-tile epilogue packs it (4 consecutive columns per lane)
-  if (d->out_bf16 && ((v & 2) || d->N % 4 != 0 || d->ldy % 4 != 0 || (gcols % 4) != 0 ||
+  // bf16 output: the transposed-tile epilogue packs 4 consecutive columns per lane
+  if (d->out_bf16 && (d->N % 4 != 0 || d->ldy % 4 != 0 || (gcols % 4) != 0 ||
                       (reinterpret_cast<uintptr_t>(y) & 7u) != 0 || (bias && misaligned(bias))))
     return BEVMSDA_ERR_UNSUPPORTED;
-#define BEVMSDA_LIN3(NP_, BK_, SW_, WM_, BN_)                                                                      \
-  do {                                                                                                             \
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, BK_, SW_, WM_, BN_>), g, b, 0, st, a);   \
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, BK_, SW_, WM_, BN_>), g, b, 0, st, a);      \
+#define BEVMSDA_LIN(NP_, WM_)                                                                                     \
+  do {                                                                                                            \
+    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, true, WM_>), g, b, 0, st, a);    \
+    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, true, WM_>), g, b, 0, st, a);       \
   } while (0)
-#define BEVMSDA_LIN2(NP_, BK_, SW_, WM_) BEVMSDA_LIN3(NP_, BK_, SW_, WM_, 128)
-#define BEVMSDA_LIN5(NP_, SW_)                                                                                               \
-  do {                                                                                                                       \
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);  \
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, false, 64>), g, b, 0, st, a);     \
-  } while (0)
-#define BEVMSDA_LIN4(NP_, SW_)                                                                                          \
-  do {                                                                                                                  \
-    if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, true, 32, SW_, 3, 128, true>), g, b, 0, st, a);  \
-    else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<NP_, false, 32, SW_, 3, 128, true>), g, b, 0, st, a);     \
-  } while (0)
-#define BEVMSDA_LIN1(NP_)                                                       \
-  switch (v) {                                                                  \
-    case 0: BEVMSDA_LIN2(NP_, 32, true, 0); break;                              \
-    case 1: BEVMSDA_LIN2(NP_, 64, true, 0); break;                              \
-    case 2: BEVMSDA_LIN2(NP_, 32, false, 0); break;                             \
-    case 3: BEVMSDA_LIN2(NP_, 64, false, 0); break;                             \
-    case 4: BEVMSDA_LIN2(NP_, 32, true, 1); break;                              \
-    case 6: BEVMSDA_LIN2(NP_, 32, false, 1); break;                             \
-    case 8: BEVMSDA_LIN2(NP_, 32, true, 2); break;                              \
-    case 10: BEVMSDA_LIN2(NP_, 32, false, 2); break;                            \
-    case 12: BEVMSDA_LIN2(NP_, 32, true, 3); break;                             \
-    case 14: BEVMSDA_LIN2(NP_, 32, false, 3); break;                            \
-    case 28: BEVMSDA_LIN3(NP_, 32, true, 3, 256); break;                        \
-    case 30: BEVMSDA_LIN3(NP_, 32, false, 3, 256); break;                       \
-    case 44: BEVMSDA_LIN4(NP_, true); break;                                    \
-    case 76: BEVMSDA_LIN5(NP_, true); break;                                    \
-    case 78: BEVMSDA_LIN5(NP_, false); break;                                   \
-    case 46: BEVMSDA_LIN4(NP_, false); break;                                   \
-    default: return BEVMSDA_ERR_BAD_OPTION;                                     \
-  }
-  if (d->precision == 0) { BEVMSDA_LIN1(3) } else { BEVMSDA_LIN1(1) }
-#undef BEVMSDA_LIN1
-#undef BEVMSDA_LIN2
-#undef BEVMSDA_LIN3
-#undef BEVMSDA_LIN4
-#undef BEVMSDA_LIN5
+  if (d->precision == 0) { if (wpack) BEVMSDA_LIN(3, 3); else BEVMSDA_LIN(3, 0); }
+  else { if (wpack) BEVMSDA_LIN(1, 3); else BEVMSDA_LIN(1, 0); }
+#undef BEVMSDA_LIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
@@ -298,17 +124,6 @@ int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const i
   bevmsda_linear_desc dd = *d;
   dd.ldx0 = ld_rows;
   return linear_launch(rows, nullptr, nullptr, nullptr, nullptr, wpack, bias, &dd, y, stream, idx, scale);
-}
-
-int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
-                                        const int32_t *idx, const float *scale, const uint16_t *wpack,
-                                        const float *bias, const bevmsda_linear_desc *d,
-                                        const bevmsda_layernorm_desc *ln, float *y, void *stream) {
-  if (!d || !ln) return BEVMSDA_ERR_NULL_POINTER;
-  if (!wpack) return BEVMSDA_ERR_NULL_POINTER;
-  if ((idx == nullptr) != (scale == nullptr)) return BEVMSDA_ERR_NULL_POINTER;
-  if (idx && (d->K1 != 0 || a0)) return BEVMSDA_ERR_BAD_SHAPE;
-  return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream, idx, scale, ln);
 }
 
 int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_t ldx, int64_t M, int N, int K,

@@ -61,11 +61,6 @@ struct LinArgs {
   int group_cols;                  // > 0: output column n goes to matrix n / group_cols (each (M, ldy))
   int out_bf16;                    // 1: y holds bf16 (round-to-nearest-even of the fp32 result), ldy in elements
   int nblk_m, nblk_n;
-  // LN kernels: y = LayerNorm(A W^T + bias + res) * gamma + beta over the N = 256 columns of a row
-  const float *res;                // (M, ldres) residual ("identity") or nullptr
-  long ldres;
-  const float *gamma, *beta;       // (N)
-  float eps;
 #ifdef BEVMSDA_LIN_DIAG
   int diag;                        // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 A loads of chunk 0 only,
                                    //   3 W copy of chunk 0 only, 4 no A split / LDS write after chunk 0
@@ -133,13 +128,9 @@ constexpr int lin_waves_per_eu(int bk, int wmode, bool add, int bn) {
 // along N (wavefront tile 64 x 32, 32 accumulator VGPRs), the activation tile is 64 rows (10 KB):
 // 30 KB of LDS and < 100 VGPRs let 5 blocks = 20 waves share a CU, and twice as many, smaller
 // blocks even out the last wave of blocks on the short (M = 40 k) projections.
-// LN: the epilogue adds the residual and applies LayerNorm over the row (N = BN = 256: one column tile
-// holds whole rows) — the "+ identity" and the norm that follow every attention / FFN step of the
-// encoder layer (encoder.py:360-404) without a second pass over the grid.  Two-pass statistics in
-// registers (mean, then centred sum of squares), exchanged between the two wavefronts that share a
-// row through LDS; torch.nn.LayerNorm semantics (biased variance, eps inside the square root).
-template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128, bool FRAGS = false, int BM = 128,
-          bool LN = false>
+// (The residual + LayerNorm epilogue of round 2 lived here on 128 / 64 x 256 tiles; it lost to two launches and is
+// retired — tools/experimental/linear_mfma_layernorm_epilogue.inc; the row-panel kernel carries that fusion now.)
+template <int NPROD, bool ADD, int BK, bool SWAP, int WMODE, int BN = 128, bool FRAGS = false, int BM = 128>
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(BM == 64 ? (BN == 256 ? 3 : (ADD ? 4 : 5)) : (FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN)),
                                    BM == 64 ? (BN == 256 ? 3 : (ADD ? 4 : 5)) : (FRAGS ? 3 : lin_waves_per_eu(BK, WMODE, ADD, BN)))))
@@ -148,7 +139,6 @@ linear_splitbf16_kernel(const LinArgs a) {
                 "BM = 64: packed weights by LDS-DMA, 64 x (128 | 256) x 32");
   static_assert(!FRAGS || (WMODE == 3 && BN == 128 && BK == 32), "FRAGS: packed weights by LDS-DMA, 128 x 128 x 32");
   static_assert(BN == 128 || (BN == 256 && WMODE == 3), "BN = 256 needs the packed weight image by LDS-DMA");
-  static_assert(!LN || (BN == 256 && SWAP && !FRAGS), "LN: whole rows (256 columns) per workgroup, transposed-tile epilogue");
   constexpr int NTW = BN / 128;             // packed 128-row weight tiles per block
   constexpr int WNW = BM == 64 ? 4 : 2;     // wavefronts along N (x 4 / WNW along M)
   constexpr int NJ = BN / WNW / 32;         // 32-column MFMA tiles per wavefront
@@ -443,96 +433,6 @@ linear_splitbf16_kernel(const LinArgs a) {
   const int ncol0 = grp * a.group_cols;     // column of y that output column 0 of this group maps to
 
   // Epilogue.  MFMA D tile: lane holds (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31).
-  if constexpr (LN) {
-    // my rows: m = m0 + wm * 64 + i * 32 + (lane & 31); my columns of such a row: wn * 128 + j * 32 +
-    // 4 * (lane >> 5) + 8 * g + e (acc[i][j][4 g + e]) — a row lives in 2 lanes (l, l ^ 32) of each of the
-    // 2 wavefronts wn = 0, 1
-    float *stat = reinterpret_cast<float *>(lds);      // [WNW (wn)][BM rows]: the staging areas are free now
-    float mean[2], rstd[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long m = m0 + wm * 64 + i * 32 + (lane & 31);
-      const bool mok = m < a.M;
-      const float *rrow = a.res ? a.res + (mok ? m : 0) * a.ldres : nullptr;
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int nb = wn * (BN / WNW) + j * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g;
-          float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
-          if (rrow && mok) v = lin_add4(v, *reinterpret_cast<const float4 *>(rrow + n));
-          acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w;
-          sum += (v.x + v.y) + (v.z + v.w);
-        }
-      }
-      sum += __shfl_xor(sum, 32, 64);
-      mean[i] = sum;
-    }
-    __syncthreads();            // (every wavefront is past its last fragment read)
-    if (lane < 32) {
-      stat[wn * BM + wm * 64 + lane] = mean[0];
-      stat[wn * BM + wm * 64 + 32 + lane] = mean[1];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = wm * 64 + i * 32 + (lane & 31);
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < WNW; ++w) t += stat[w * BM + r];
-      mean[i] = t * (1.0f / 256.0f);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = acc[i][j][r] - mean[i];
-          ss = fmaf(d, d, ss);
-        }
-      ss += __shfl_xor(ss, 32, 64);
-      rstd[i] = ss;
-    }
-    if (lane < 32) {
-      stat[wn * BM + wm * 64 + lane] = rstd[0];
-      stat[wn * BM + wm * 64 + 32 + lane] = rstd[1];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = wm * 64 + i * 32 + (lane & 31);
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < WNW; ++w) t += stat[w * BM + r];
-      rstd[i] = rsqrtf(t * (1.0f / 256.0f) + a.eps);
-      const long m = m0 + r;
-      if (m >= a.M) continue;
-      float *yrow = a.y + m * a.ldy;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int nb = wn * (BN / WNW) + j * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g;
-          const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + n);
-          const float4 be = *reinterpret_cast<const float4 *>(a.beta + n);
-          float4 v;
-          v.x = (acc[i][j][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
-          v.y = (acc[i][j][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
-          v.z = (acc[i][j][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
-          v.w = (acc[i][j][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
-          *reinterpret_cast<float4 *>(yrow + n) = v;
-        }
-      }
-    }
-    return;
-  }
   if (SWAP) {
     // D rows are output columns: registers 4g .. 4g+3 of a lane are n = nb + 8g .. +3 of output
     // row m = lane & 31 -> one float4 store per g (16-byte path needs N, ldy multiples of 4 and

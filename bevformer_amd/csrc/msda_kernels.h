@@ -49,6 +49,9 @@ struct KArgs {
   int variant;    // 0 default, 1 generic lane-group kernels only, 2 scalar fallback
   int mshift;     // log2(M) when M is a power of two, else -1
   int qshift;     // log2(qtile) when qtile is a power of two, else -1
+  int gv_rows;    // backward: rows per workgroup of the grad_value sort kernel (0 = default; 64 / 128 / 256)
+  int bf16_lanes8;  // backward, bf16 storage: 1 = the 8-byte-lane gather kernel instead of the 16-byte-lane one
+  unsigned long long *gv_prof;   // backward: phase clocks of the sort kernel (tools/gvprof.py), else nullptr
 };
 
 typedef uint16_t bf16_t;

@@ -14,8 +14,15 @@ import copy
 import torch
 
 
-def obtain_history_bev(bev_fn, feats_queue, img_metas_list):
+def obtain_history_bev(bev_fn, feats_queue, img_metas_list, modules=()):
     """detectors/bevformer.py:158-177.
+
+    ``modules``: the ``nn.Module`` objects behind ``bev_fn`` (e.g. the ``PerceptionTransformer``).  The reference
+    brackets the history frames with ``self.eval()`` / ``self.train()`` (:163, :176): dropout (p = 0.1 in the
+    TSA / SCA / FFN of the BEVFormer configs) must be inactive while the history BEVs are computed.  The modules
+    given here are switched to eval mode for the walk and put back into the mode they were in (the reference
+    calls ``train()`` unconditionally: it only runs this from ``forward_train``); with ``modules=()`` the caller
+    owns the mode — history frames computed by a module in training mode differ from the reference's.
 
     ``feats_queue``: per level a tensor (bs, len_queue, Nc, C, h, w) — the backbone features of
     the queue's earlier frames (the reference slices ``each_scale[:, i]``, :173);
@@ -25,13 +32,20 @@ def obtain_history_bev(bev_fn, feats_queue, img_metas_list):
     for an empty queue."""
     prev_bev = None
     len_queue = feats_queue[0].shape[1] if feats_queue else 0
-    with torch.no_grad():
-        for i in range(len_queue):
-            img_metas = [each[i] for each in img_metas_list]
-            if not img_metas[0]["prev_bev_exists"]:
-                prev_bev = None
-            feats = [lvl[:, i] for lvl in feats_queue]
-            prev_bev = bev_fn(feats, img_metas, prev_bev)
+    was_training = [m.training for m in modules]
+    for m in modules:
+        m.eval()
+    try:
+        with torch.no_grad():
+            for i in range(len_queue):
+                img_metas = [each[i] for each in img_metas_list]
+                if not img_metas[0]["prev_bev_exists"]:
+                    prev_bev = None
+                feats = [lvl[:, i] for lvl in feats_queue]
+                prev_bev = bev_fn(feats, img_metas, prev_bev)
+    finally:
+        for m, t in zip(modules, was_training):
+            m.train(t)
     return prev_bev
 
 
@@ -115,6 +129,14 @@ class GraphedBevHistory(BevHistory):
         bs = len(metas)
         cb = torch.tensor(np.array([np.asarray(m["can_bus"], dtype=np.float64) for m in metas]), dtype=torch.float64)
         l2i = torch.tensor(np.array([np.asarray(m["lidar2img"], dtype=np.float64) for m in metas]), dtype=torch.float32)
+        # what the captured graphs were built for: later frames must bring the same batch size, camera count and
+        # image shape (static buffers and kernel arguments were sized / baked from the first frame)
+        sig = (bs, tuple(l2i.shape), tuple(tuple(s) for s in metas[0].get("img_shape", ())))
+        if getattr(self, "_capture_sig", None) is None:
+            self._capture_sig = sig
+        elif sig != self._capture_sig:
+            raise RuntimeError(f"GraphedBevHistory: frame signature {sig} differs from the captured one "
+                               f"{self._capture_sig}; build a new GraphedBevHistory for another rig / batch size")
         if self.can_bus is None:
             self.can_bus = cb.to(self.device)
             self.l2i = l2i.to(self.device)

@@ -1,0 +1,81 @@
+"""Execution modes of the host layer (``ops``): which kernel family, arithmetic and storage a call uses.
+
+One ``Modes`` object holds every switch.  ``current()`` is what a call sees: the innermost ``using(...)`` block of
+the CALLING THREAD, else the process-wide defaults (initialised from ``BEVMSDA_*`` environment variables once, at
+import; the ``ops.set_*`` functions edit those defaults).  The autograd Functions of ``ops`` snapshot ``current()``
+in ``forward`` and re-activate it in ``backward`` — the autograd engine runs backward on its own thread, which
+would otherwise see the process defaults instead of the caller's modes.  The C library keeps no state: every
+switch travels in a descriptor field of the call (include/bevmsda.h)."""
+import contextlib
+import copy
+import os
+import threading
+
+import torch
+
+GEMM_MODES = ("split", "bf16", "native")
+GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128")
+
+
+class Modes:
+    __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe")
+
+    def __init__(self):
+        env = os.environ.get
+        self.value_storage = torch.float32      # storage of the projected value tensors sampled by the kernels
+        self.fused = True                        # fused softmax + location + sampling kernel on the no-grad path
+        self.fused_train = env("BEVMSDA_FUSED_TRAIN", "1") == "1"   # ... and under autograd (three-step backward)
+        self.gemm = env("BEVMSDA_GEMM", "split")                    # split | bf16 | native
+        self.gemm_variant = int(env("BEVMSDA_GEMM_VARIANT")) if env("BEVMSDA_GEMM_VARIANT") else None  # None, 0, 12
+        self.gemm_pack = env("BEVMSDA_GEMM_PACK", "1") == "1"       # pre-split weight images
+        self.train_forward_mfma = env("BEVMSDA_TRAIN_FWD_MFMA", "1") == "1"
+        k = env("BEVMSDA_GEMM_KERNEL", "")
+        self.gemm_kernel = k if k in GEMM_KERNELS[1:] else None     # None = by measurement (ops._panel_covers)
+        self.ln_fuse = env("BEVMSDA_FUSE_LN", "1") == "1"           # residual + LayerNorm in the projection's epilogue
+        self.wgrad = env("BEVMSDA_WGRAD", "1") == "1"               # weight gradients on the TN MFMA kernel
+        self.bf16_lanes8 = env("BEVMSDA_BF16_LANES8") is not None   # benchmark knob: 8-byte-lane bf16 kernels
+        self.fused_wpe = int(env("BEVMSDA_FUSED_WPE", "0"))         # benchmark knob: register budget of the fused kernel
+        assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
+
+    def snapshot(self):
+        return copy.copy(self)
+
+
+_PROCESS = Modes()
+_TLS = threading.local()
+
+
+def process_defaults():
+    """The process-wide defaults (what ``ops.set_*`` edit)."""
+    return _PROCESS
+
+
+def current():
+    stack = getattr(_TLS, "stack", None)
+    return stack[-1] if stack else _PROCESS
+
+
+@contextlib.contextmanager
+def activate(modes):
+    """Make ``modes`` (a snapshot) the calling thread's modes for the block."""
+    stack = getattr(_TLS, "stack", None)
+    if stack is None:
+        stack = _TLS.stack = []
+    stack.append(modes)
+    try:
+        yield modes
+    finally:
+        stack.pop()
+
+
+@contextlib.contextmanager
+def using(**overrides):
+    """``with modes.using(gemm="bf16", value_storage=torch.bfloat16): ...`` — thread-local overrides."""
+    m = current().snapshot()
+    for k, v in overrides.items():
+        if k not in Modes.__slots__:
+            raise AttributeError(f"unknown mode {k!r}")
+        setattr(m, k, v)
+    with activate(m):
+        yield m

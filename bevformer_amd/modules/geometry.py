@@ -131,9 +131,16 @@ class FramePlan:
         q_rows = self.q_rows_all
         if c[2] == 0:
             q_rows = self.q_rows                      # at most two cameras per query: the (.., 2) table
-        plan = replace(self, row_query32=self.row_query32[:R], row_batch=self.row_batch[:R],
-                       row_ref=self.row_ref[:R], row_query=self.row_query32[:R].long(),
-                       q_rows=q_rows, hits=[starts[i + 1] - starts[i] for i in range(nc)],
+        # COPIES, not views: the planner's buffers are rewritten in place by its next plan() through raw pointers
+        # (no version counter moves), and the autograd Functions of this path save these arrays for backward — a
+        # second differentiable frame before the first one's backward would otherwise hand it the later geometry
+        rq32 = self.row_query32[:R].clone()
+        plan = replace(self, row_query32=rq32, row_batch=self.row_batch[:R].clone(),
+                       row_ref=self.row_ref[:R].clone(), row_query=rq32.long(),
+                       q_rows=q_rows.clone(), q_rows_all=self.q_rows_all.clone() if self.q_rows_all is not None else None,
+                       inv_count=self.inv_count.clone(), reference_points_cam=self.reference_points_cam.clone(),
+                       bev_mask=self.bev_mask.clone(), cam_start=self.cam_start.clone(),
+                       hits=[starts[i + 1] - starts[i] for i in range(nc)],
                        max_cam_rows=max([starts[i + 1] - starts[i] for i in range(n_entries)] or [0]),
                        nrows_dev=None, n_extra_dev=None)
         self._materialized = plan
@@ -371,7 +378,8 @@ class DevicePlanner:
             key = (arr.tobytes(), int(shp[0]), int(shp[1]))
             if self._last is not None and self._last[0] == key:
                 return self._last[1]            # same rig as the previous frame: the buffers already hold its plan
-            self._last = (key, None)
+            self._last = None                   # (set again only once the kernels of THIS rig were launched)
+            pending_key = key
             self.l2i.copy_(torch.from_numpy(arr.astype(np.float32)), non_blocking=True)
         d = _lib.PlanDesc(B=self.bs, Nc=self.Nc, Q=self.Q, D=self.D, img_w=float(shp[1]), img_h=float(shp[0]),
                           q_lo=self.q_lo, q_hi=self.q_hi, row_capacity=self.cap)
@@ -407,6 +415,6 @@ class DevicePlanner:
             cam_start=self.counters[4:], max_cam_rows=0, nrows_dev=self.counters[0:1],
             n_extra_dev=self.counters[2:3], counters=self.counters, ref_2d_full=self.ref_2d,
             launch_rows=self.launch_rows)
-        if self._last is not None:
-            self._last = (self._last[0], plan)
+        if not torch.is_tensor(first):
+            self._last = (pending_key, plan)
         return plan

@@ -160,12 +160,6 @@ class MSDeformableAttention3D(BaseModule):
         if frame_plan is not None and frame_plan.dynamic:
             # row count on the device (geometry.DevicePlanner); launch sized by the planner's hint
             lds = dict(nrows=frame_plan.nrows_dev, launch_rows=frame_plan.launch_rows)
-        elif ops._FUSED["lds_level"] and frame_plan is not None and frame_plan.cam_start is not None:
-            px = getattr(frame_plan, "_last_level_pixels", None)
-            if px is None:                      # one host read per plan (shapes live on the device)
-                px = frame_plan._last_level_pixels = int(spatial_shapes[-1].prod().item())
-            lds = dict(cam_start=frame_plan.cam_start, max_cam_rows=frame_plan.max_cam_rows,
-                       lds_pixels=px)
         out = ops.msda_fused(value, spatial_shapes, level_start_index, proj, n_off,
                              row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M, L=L, P=P, K=1,
                              off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0,

@@ -17,7 +17,26 @@ from . import _lib
 from .ext import _ptr, _req
 from .functions import MultiScaleDeformableAttnFunction_fp32
 
-_STORAGE = {"dtype": torch.float32}
+from . import modes as _modes
+
+
+def _forward_modes(backward):
+    """Decorator of an autograd Function's ``backward``: runs it under the modes its ``forward`` saw (``ctx.modes``) —
+    the autograd engine calls backward on its own thread, outside any ``using`` block of the caller."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        with _modes.activate(ctx.modes):
+            return backward(ctx, *grads)
+    return wrapped
+
+
+def _m():
+    """The modes of this call (bevformer_amd/modes.py): the calling thread's ``using`` block or the process defaults."""
+    return _modes.current()
+
+
 _TIMER = {"cb": None}
 
 
@@ -46,14 +65,20 @@ def _timed(tag, value, loc, attn, out_elems):
 
 
 def value_storage():
-    return _STORAGE["dtype"]
+    return _m().value_storage
+
+
+def using(**overrides):
+    """``with ops.using(gemm="bf16", value_storage=torch.bfloat16): ...`` — modes for the calling thread only
+    (``bevformer_amd.modes.using``); the ``set_*`` functions below edit the process-wide defaults instead."""
+    return _modes.using(**overrides)
 
 
 def set_value_storage(dtype):
     """fp32 (reference semantics, default) or bf16 storage of the projected
     value tensor inside the sampling kernels (fp32 arithmetic either way)."""
     assert dtype in (torch.float32, torch.bfloat16)
-    _STORAGE["dtype"] = dtype
+    _modes.process_defaults().value_storage = dtype
 
 
 def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
@@ -70,7 +95,7 @@ def msda(value, spatial_shapes, level_start_index, sampling_locations, attention
 
 def _msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
           im2col_step=64):
-    if _STORAGE["dtype"] == torch.bfloat16:
+    if _m().value_storage == torch.bfloat16:
         from .functions import MultiScaleDeformableAttnFunction_bf16
         return MultiScaleDeformableAttnFunction_bf16.apply(
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
@@ -106,8 +131,9 @@ class _RaggedFunction(Function):
 
     @staticmethod
     def forward(ctx, value, shapes, start, loc, attn, row_batch, tag="msda_fwd"):
+        ctx.modes = _m().snapshot()
         ctx.in_dtype = value.dtype
-        store = _STORAGE["dtype"]
+        store = _m().value_storage
         value = value.to(store).contiguous()
         loc = loc.float().contiguous()
         attn = attn.float().contiguous()
@@ -125,6 +151,7 @@ class _RaggedFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_forward_modes
     def backward(ctx, grad_out):
         value, shapes, start, loc, attn, row_batch = ctx.saved_tensors
         N, S, M, D = value.shape
@@ -152,42 +179,22 @@ def msda_ragged(value, spatial_shapes, level_start_index, sampling_locations, at
                                  attention_weights, row_batch, tag)
 
 
-_FUSED = {"enabled": True,
-          # SCA sampling with the coarsest feature level staged in LDS (csrc/msda_d32.h,
-          # msda_fused_d32_ldslevel_kernel): opt-in, BEVMSDA_SCA_LDS=1 / set_sca_lds_level(True)
-          "lds_level": os.environ.get("BEVMSDA_SCA_LDS", "0") == "1",
-          # SCA sampling with the two coarse levels of a (camera, head) patch in LDS (csrc/msda_lds2.h)
-          "lds2": os.environ.get("BEVMSDA_SCA_LDS2", "0") == "1"}
-
-
-def set_sca_lds_level(flag):
-    """SpatialCrossAttention's sampling kernel with the last feature level of a (camera, head)
-    staged in LDS (rows grouped by camera; fp32)."""
-    _FUSED["lds_level"] = bool(flag)
-
-
-def set_sca_lds2(flag):
-    """SpatialCrossAttention's sampling kernel with levels L-2 and L-1 of a (camera, head) patch served from
-    LDS (fp32, 4 levels, rows grouped by camera)."""
-    _FUSED["lds2"] = bool(flag)
-
-
 def set_fused_front_end(flag):
     """Enable / disable the fused softmax + location + sampling kernel on the
     no-grad path (on by default; the autograd path always uses the unfused
     operator, whose backward kernels exist)."""
-    _FUSED["enabled"] = bool(flag)
+    _modes.process_defaults().fused = bool(flag)
 
 
 def fused_wanted(*tensors):
     """The fused kernel is forward-only: use it when nothing asks for a gradient."""
-    return _FUSED["enabled"] and not (torch.is_grad_enabled()
+    return _m().fused and not (torch.is_grad_enabled()
                                       and any(t is not None and t.requires_grad for t in tensors))
 
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", cam_start=None, max_cam_rows=0, lds_pixels=0, nrows=None, launch_rows=0):
+               tag="msda_fwd", nrows=None, launch_rows=0, **_retired):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -203,7 +210,7 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``);
     ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint)."""
     _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
-    store = _STORAGE["dtype"]
+    store = _m().value_storage
     value = value.to(store)
     _req(value.is_contiguous() and value.dim() == 4, "bevmsda: value must be contiguous (N,S,M,D)")
     _req(proj.dtype == torch.float32 and proj.dim() == 2 and proj.stride(1) == 1,
@@ -222,10 +229,10 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     desc = _lib.FusedDesc(R=R, proj_row=proj.stride(0), N=N, S=S, M=M, D=D, L=L, P=P, Q=Q, K=K, A=A,
                           ref_mode=ref_mode, off_head=off_head, off_k=off_k, lg_head=lg_head,
                           lg_k=lg_k, vmul=vmul, vadd=vadd)
-    if os.environ.get("BEVMSDA_FUSED_WPE") and nrows is None:   # benchmark sweeps: register budget of the kernel
-        desc.reserved[0] = int(os.environ["BEVMSDA_FUSED_WPE"])
+    if _m().fused_wpe and nrows is None:   # benchmark sweeps: register budget of the kernel
+        desc.reserved[0] = _m().fused_wpe
     lib = _lib.load()
-    if store == torch.bfloat16 and not os.environ.get("BEVMSDA_BF16_LANES8"):
+    if store == torch.bfloat16 and not _m().bf16_lanes8:
         desc.reserved[2] = 1            # 16-byte-lane kernel writes fp32 rows for the fp32 output projection
         out = torch.empty((R, M * D), dtype=torch.float32, device=value.device)
     else:
@@ -242,35 +249,6 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
             alg = ("per_row", value.numel() * value.element_size(), M * K * L * P * 12 + M * D * out.element_size())
         cb = _TIMER["cb"]
         ctx = cb(tag, alg) if cb is not None else _NoTimer()
-        rc = _lib.ERR_UNSUPPORTED
-        if _FUSED["lds_level"] and cam_start is not None and store == torch.float32 and K == 1 \
-                and ref_mode == 0 and 0 < lds_pixels <= 512 and max_cam_rows > 0:
-            with ctx:
-                rc = lib.bevmsda_fused_forward_lds_f32(
-                    _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
-                    logits.data_ptr(), _ptr(ref), _ptr(row_src) if row_src is not None else None,
-                    _ptr(cam_start), ctypes.byref(desc), int(lds_pixels), int(max_cam_rows), _ptr(out),
-                    torch.cuda.current_stream().cuda_stream)
-            if rc == 0:
-                return out
-            if rc != _lib.ERR_UNSUPPORTED:
-                _lib.check(rc, "msda_fused forward (LDS level)")
-            ctx = cb(tag, alg) if cb is not None else _NoTimer()
-        if _FUSED["lds2"] and store == torch.float32 and K == 1 and ref_mode == 0 and L == 4 and P == 8 \
-                and row_batch is not None and vmul == 1 and vadd == 0:
-            with ctx:
-                if nrows is not None:
-                    desc.reserved[3] = int(max(0, min(launch_rows, R)))
-                rc = lib.bevmsda_fused_forward_lds2_f32(
-                    _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(), logits.data_ptr(),
-                    _ptr(ref), _ptr(row_batch), _ptr(row_src) if row_src is not None else None,
-                    nrows.data_ptr() if nrows is not None else None, ctypes.byref(desc), _ptr(out),
-                    torch.cuda.current_stream().cuda_stream)
-            if rc == 0:
-                return out
-            if rc != _lib.ERR_UNSUPPORTED:
-                _lib.check(rc, "msda_fused forward (LDS2)")
-            ctx = cb(tag, alg) if cb is not None else _NoTimer()
         with ctx:
             if nrows is not None:
                 _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
@@ -292,17 +270,16 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     return out
 
 
-_FUSED_TRAIN = {"enabled": os.environ.get("BEVMSDA_FUSED_TRAIN", "1") == "1"}
 
 
 def set_fused_training(flag):
     """Autograd path of the attention modules through the fused sampling kernel + its three-step backward
     (default) or through the unfused operator with the softmax / location arithmetic as torch ops."""
-    _FUSED_TRAIN["enabled"] = bool(flag)
+    _modes.process_defaults().fused_train = bool(flag)
 
 
 def fused_training_wanted(*tensors):
-    return _FUSED["enabled"] and _FUSED_TRAIN["enabled"] and torch.is_grad_enabled() and all(t is None or t.is_cuda for t in tensors) \
+    return _m().fused and _m().fused_train and torch.is_grad_enabled() and all(t is None or t.is_cuda for t in tensors) \
         and any(t is not None and t.requires_grad for t in tensors) and not torch.is_autocast_enabled()
 
 
@@ -315,8 +292,9 @@ class _FusedSampleFunction(Function):
 
     @staticmethod
     def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None):
+        ctx.modes = _m().snapshot()
         # bf16 storage: ONE rounded copy of the value serves the forward kernel and, saved, the backward kernels
-        vs = value.detach().to(_STORAGE["dtype"]).contiguous()
+        vs = value.detach().to(_m().value_storage).contiguous()
         out = msda_fused(vs, shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
                          tag=tag, **meta)
         if out is None:
@@ -326,12 +304,13 @@ class _FusedSampleFunction(Function):
                               row_batch if row_batch is not None else shapes.new_empty(0),
                               row_src if row_src is not None else shapes.new_empty(0))
         ctx.n_off, ctx.meta = n_off, meta
-        ctx.store = _STORAGE["dtype"]     # the value storage the forward sampled (bf16: rounded copy of `value`)
+        ctx.store = _m().value_storage     # the value storage the forward sampled (bf16: rounded copy of `value`)
         ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
         return out
 
     @staticmethod
     @once_differentiable
+    @_forward_modes
     def backward(ctx, grad_out):
         value, proj, shapes, start, ref, row_batch, row_src = ctx.saved_tensors
         row_batch = row_batch if row_batch.numel() else None
@@ -458,6 +437,7 @@ class _AddLayerNormFunction(Function):
 
     @staticmethod
     def forward(ctx, x, res, weight, bias, eps):
+        ctx.modes = _m().snapshot()
         x = x.contiguous()
         res = res.contiguous()
         y = add_layernorm(x.detach(), res.detach(), weight.detach(), bias.detach(), eps)
@@ -469,6 +449,7 @@ class _AddLayerNormFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_forward_modes
     def backward(ctx, g):
         x, res, weight = ctx.saved_tensors
         C = x.shape[-1]
@@ -489,7 +470,7 @@ class _AddLayerNormFunction(Function):
 def add_layernorm_autograd(x, res, norm):
     """``norm(x + res)`` with gradients, or ``None`` when the kernels do not cover the call."""
     C = x.shape[-1]
-    if not (_FUSED_TRAIN["enabled"] and x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32
+    if not (_m().fused_train and x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32
             and res.shape == x.shape and C in (256, 512) and isinstance(norm, torch.nn.LayerNorm)
             and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32
             and tuple(norm.normalized_shape) == (C,) and not torch.is_autocast_enabled()):
@@ -524,11 +505,13 @@ class _GatherMeanFunction(Function):
 
     @staticmethod
     def forward(ctx, rows, idx, scale, row_slot):
+        ctx.modes = _m().snapshot()
         ctx.save_for_backward(scale.reshape(-1).float(), row_slot)
         return gather_mean(rows.detach().contiguous(), idx, scale)
 
     @staticmethod
     @once_differentiable
+    @_forward_modes
     def backward(ctx, g):
         scale, row_slot = ctx.saved_tensors
         return (g * scale[:, None]).index_select(0, row_slot), None, None, None
@@ -543,25 +526,7 @@ def gather_mean_autograd(rows, idx, scale, row_slot):
 # ---------------------------------------------------------------------------
 # Dense projections on the matrix cores (csrc/linear_mfma.h)
 # ---------------------------------------------------------------------------
-GEMM_MODES = ("split", "bf16", "native")
-_GEMM = {"mode": os.environ.get("BEVMSDA_GEMM", "split"),
-         # launch variant of the MFMA kernel: None = library default; an int v selects variant v
-         # (include/bevmsda.h, bevmsda_linear_desc.reserved[0]); v >= 4 uses the pre-split weight image
-         "variant": (int(os.environ["BEVMSDA_GEMM_VARIANT"]) if os.environ.get("BEVMSDA_GEMM_VARIANT")
-                     else None),
-         "pack": os.environ.get("BEVMSDA_GEMM_PACK", "1") == "1",
-         # autograd path: forward projections on the MFMA kernel too (see _LinearFunction)
-         "train_forward_mfma": os.environ.get("BEVMSDA_TRAIN_FWD_MFMA", "1") == "1",
-         # second projection kernel (csrc/linear_dma.h: activations by LDS-DMA, one barrier per chunk) for the
-         # calls it covers (packed weights, no addend / gather); None = library default
-         "dma": {"1": True, "0": False, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(os.environ.get("BEVMSDA_GEMM_DMA", ""), None),
-         # row-panel kernel (csrc/linear_panel.h) for the calls it covers: True / False; panel_shape 0 = by problem
-         # shape, 1 = 64-row panels, 2 = 128-row panels
-         # None = by measurement (profiles/r3: the hoisted N >= 1024 projections and every LayerNorm-fused projection),
-         # True = wherever it applies, False = never
-         "panel": {"1": True, "0": False}.get(os.environ.get("BEVMSDA_GEMM_PANEL", ""), None),
-         "panel_shape": int(os.environ.get("BEVMSDA_GEMM_PANEL_SHAPE", "0"))}
-assert _GEMM["mode"] in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
+GEMM_MODES = _modes.GEMM_MODES
 _GEMM_TIMER = {"cb": None}
 
 
@@ -573,21 +538,22 @@ def set_gemm_mode(mode):
     ``native`` torch.nn.functional.linear (hipBLASLt fp32 MFMA at the fp32 vector rate).
     The autograd path always uses ``native``."""
     assert mode in GEMM_MODES
-    _GEMM["mode"] = mode
+    _modes.process_defaults().gemm = mode
 
 
 def gemm_mode():
-    return _GEMM["mode"]
+    return _m().gemm
 
 
 def set_gemm_variant(variant=None, pack=None):
     """Benchmark hook: force a launch variant of the MFMA kernel (None = library default);
     ``pack`` selects the pre-split weight image for the default variant."""
-    _GEMM["variant"] = variant
+    assert variant in (None, 0, 12), "launch variants: None (default), 0 (fp32 weight matrix), 12 (packed weight image)"
+    _modes.process_defaults().gemm_variant = variant
     if pack is not None:
-        _GEMM["pack"] = bool(pack)
+        _modes.process_defaults().gemm_pack = bool(pack)
     elif variant is not None:
-        _GEMM["pack"] = variant >= 4
+        _modes.process_defaults().gemm_pack = variant >= 4
 
 
 def packed_weight(weight):
@@ -648,10 +614,9 @@ def _panel_covers(N, K0, K1, groups, ln):
     270 us per frame in split mode) and the LayerNorm-fused projections (45 vs 52 us, 59 vs 66 us); the plain
     per-layer projections (N <= 768, 40 k rows) stay on the first kernel (30-70 us, 5-10 % ahead)."""
     K = K0 + K1
-    want = _GEMM["panel"]
-    if want is None:
-        want = ln or N >= 1024
-    if not want or _GEMM["variant"] is not None or K not in (256, 512) or K0 not in (256, 512) \
+    kern = _m().gemm_kernel
+    want = (ln or N >= 1024) if kern is None else kern.startswith("panel")
+    if not want or _m().gemm_variant is not None or K not in (256, 512) or K0 not in (256, 512) \
             or K1 not in (0, 256) or N % 4:
         return False
     if (K == 512 or ln) and N > 256:
@@ -667,7 +632,7 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     if blob is None:
         return False
     # panel shape: 128-row panels (half the weight traffic per MFMA, one workgroup per CU) pay from ~128 k rows on
-    desc.reserved[2] = _GEMM["panel_shape"] or (2 if desc.M >= (1 << 17) and ln is None else 1)
+    desc.reserved[2] = {"panel64": 1, "panel128": 2}.get(_m().gemm_kernel) or (2 if desc.M >= (1 << 17) and ln is None else 1)
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
@@ -682,25 +647,14 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     return True
 
 
-def set_gemm_dma(flag):
-    """True / False: use / avoid the LDS-DMA projection kernel where it applies; None: library default."""
-    _GEMM["dma"] = flag
-
-
 def set_gemm_kernel(name):
-    """Which projection kernel serves the calls several of them cover: ``None`` (library default), ``"first"``
-    (linear_mfma.h), ``"panel"`` / ``"panel64"`` / ``"panel128"`` (linear_panel.h, row panels; the default where it
-    applies), ``"dma"`` (linear_dma.h), ``"ws"`` (linear_ws.h, weight-stationary), ``"pipe"`` (linear_pipe.h, software-pipelined), ``"areg"`` (linear_areg.h,
-    activation rows resident in registers)."""
-    assert name in (None, "first", "dma", "ws", "pipe", "areg", "panel", "panel64", "panel128")
-    _GEMM["panel"] = None if name is None else name in ("panel", "panel64", "panel128")
-    _GEMM["panel_shape"] = {"panel64": 1, "panel128": 2}.get(name, 0)
-    _GEMM["dma"] = {None: None, "first": False, "dma": True, "ws": "ws", "pipe": "pipe", "areg": "areg"}.get(name)
-
-
-def _ws_covers(M, N, K0, K1, a0, a1, mode):
-    planes = 2 if mode == "split" else 1
-    return K1 == 0 and a0 is None and a1 is None and planes * 128 * (K0 + 8) * 2 <= 150 * 1024 and M * N >= 1 << 24
+    """Which projection kernel serves the calls several of them cover: ``None`` (by measurement: the row-panel
+    kernel for the hoisted N >= 1024 projections and the LayerNorm-fused ones, the software-pipelined kernel for
+    M <= 8192, the first kernel otherwise), ``"first"`` (linear_mfma.h), ``"pipe"`` (linear_pipe.h),
+    ``"panel"`` / ``"panel64"`` / ``"panel128"`` (linear_panel.h wherever it applies, panel shape by problem
+    shape / 64 / 128 rows)."""
+    assert name in _modes.GEMM_KERNELS
+    _modes.process_defaults().gemm_kernel = name
 
 
 def set_gemm_timer(cb):
@@ -727,7 +681,7 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
 
     ``groups = G > 1``: ``weight`` is the row-wise concatenation of G Linear layers that share
     the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x."""
-    mode = _GEMM["mode"]
+    mode = _m().gemm
     if mode == "native" or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
             or not (_inside_autograd or fused_wanted(x, weight, bias, x_add, x2, x2_add)):
         return None
@@ -773,28 +727,19 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
                            precision=0 if mode == "split" else 1,
                            group_cols=ncol if groups > 1 else 0,
                            out_bf16=int(out_dtype == torch.bfloat16))
-    if _GEMM["pack"] and _panel_covers(N, K0, K1, groups, False):
+    if _m().gemm_pack and _panel_covers(N, K0, K1, groups, False):
         nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
         if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes):
             return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
-    variant = _GEMM["variant"]
-    blob = packed_weight(w) if _GEMM["pack"] and (variant is None or variant >= 4) else None
+    variant = _m().gemm_variant
+    blob = packed_weight(w) if _m().gemm_pack and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
-    elif _GEMM["dma"] is not None and blob is not None:
-        if _GEMM["dma"] == "areg":
-            if a0 is None and a1 is None and K0 == 256 and K1 == 0 and N % 128 == 0:
-                desc.variant = 132          # force the activation-stationary kernel
-        elif _GEMM["dma"] == "pipe":
-            if a0 is None and a1 is None and (K0 + K1) // 32 in (8, 16):
-                desc.variant = 131          # force the software-pipelined kernel
-        elif _GEMM["dma"] == "ws":
-            if _ws_covers(M, N, K0, K1, a0, a1, mode):
-                desc.variant = 130          # force the weight-stationary kernel
-        elif _GEMM["dma"] and a0 is None and a1 is None:
-            desc.variant = 129              # force the LDS-DMA kernel (it covers this call)
-        elif not _GEMM["dma"]:
-            desc.reserved[1] = 1            # keep the first kernel
+    elif blob is not None and _m().gemm_kernel == "pipe":
+        if a0 is None and a1 is None and (K0 + K1) // 32 in (8, 16):
+            desc.variant = 131              # force the software-pipelined kernel
+    elif _m().gemm_kernel == "first":
+        desc.reserved[1] = 1                # keep the first kernel
     lib = _lib.load()
     fn = lib.bevmsda_linear_f32 if blob is None else lib.bevmsda_linear_packed_f32
     cb = _GEMM_TIMER["cb"]
@@ -819,8 +764,8 @@ def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
     (``bevmsda_linear_gather_packed_f32``): the camera mean of SpatialCrossAttention folded into
     the A-load of its output projection.  idx (Q, 2) int32.  Returns ``None`` when not covered
     (GEMM mode ``native``, packing off, autograd, more than two cameras per query)."""
-    mode = _GEMM["mode"]
-    if mode == "native" or not _GEMM["pack"] or _GEMM["variant"] is not None \
+    mode = _m().gemm
+    if mode == "native" or not _m().gemm_pack or _m().gemm_variant is not None \
             or not rows.is_cuda or rows.dtype != torch.float32 or weight.dtype != torch.float32 \
             or not fused_wanted(rows, weight, bias) or idx.dim() != 2 or idx.shape[1] != 2 \
             or idx.dtype != torch.int32 or rows.dim() != 2 or rows.shape[1] % 32 \
@@ -874,12 +819,11 @@ class Normed:
 # rows per workgroup, so the norm costs one exchange through LDS instead of a second launch over the grid
 # (profiles/r3/gemm_ab: output_proj + LN 45.4 vs 51.6 us, fc2 + LN 59.3 vs 66.1 us, 24.7 vs 33.2 us at 5,000 rows).
 # Round 2's form of this on 128 x 256 tiles of the first kernel lost to two launches and is retired.
-_LN_FUSE = {"enabled": os.environ.get("BEVMSDA_FUSE_LN", "1") == "1"}
 
 
 def set_layernorm_fusion(flag):
     """Residual add + LayerNorm in the epilogue of the projection that precedes them (row-panel kernel)."""
-    _LN_FUSE["enabled"] = bool(flag)
+    _modes.process_defaults().ln_fuse = bool(flag)
 
 
 def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
@@ -887,9 +831,9 @@ def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
     A = ``x`` or, with ``gather = (idx (Q, 2) int32, scale (Q,))``, the camera mean of SpatialCrossAttention
     over the rows of ``x``.  ``norm``: an ``nn.LayerNorm`` over N = 256.  Returns ``None`` when not covered
     (then the caller runs the projection and ``add_layernorm``)."""
-    mode = _GEMM["mode"]
-    if not _LN_FUSE["enabled"] or _GEMM["panel"] is False or mode == "native" or not _GEMM["pack"] \
-            or _GEMM["variant"] is not None or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None \
+    mode = _m().gemm
+    if not _m().ln_fuse or _m().gemm_kernel in ("first", "pipe") or mode == "native" or not _m().gemm_pack \
+            or _m().gemm_variant is not None or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None \
             or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
             or weight.shape[0] != 256 or tuple(norm.normalized_shape) != (256,) \
             or not fused_wanted(x, weight, bias, res, norm.weight):
@@ -951,20 +895,19 @@ def transposed_weight(weight):
     return wt
 
 
-_WGRAD = {"enabled": os.environ.get("BEVMSDA_WGRAD", "1") == "1"}
 
 
 def set_wgrad_kernel(flag):
     """Weight / bias gradients of the Linear layers on the MFMA kernel (csrc/wgrad_mfma.h; default) or on
     the library's TN GEMM + a column-sum reduction."""
-    _WGRAD["enabled"] = bool(flag)
+    _modes.process_defaults().wgrad = bool(flag)
 
 
 def linear_wgrad(g, x, with_bias, *, tag="linear_dw"):
     """(grad_W (N, K), grad_b (N) or None) = (g^T x, g.sum(0)) through ``bevmsda_linear_wgrad_f32``; g (M, N),
     x (M, K) fp32 GPU matrices.  Returns (None, None) when the call is not covered."""
-    mode = _GEMM["mode"]
-    if not _WGRAD["enabled"] or mode == "native" or not g.is_cuda or g.dtype != torch.float32 \
+    mode = _m().gemm
+    if not _m().wgrad or mode == "native" or not g.is_cuda or g.dtype != torch.float32 \
             or x.dtype != torch.float32 or g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0]:
         return None, None
     M, N = g.shape
@@ -1009,7 +952,8 @@ class _LinearFunction(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias, relu, tag):
-        if _GEMM["train_forward_mfma"]:
+        ctx.modes = _m().snapshot()
+        if _m().train_forward_mfma:
             # `weight` itself (not a detached temporary): the packed-weight cache lives on the parameter
             with torch.no_grad():
                 y = linear(x, weight, bias, relu=relu, tag=tag, _inside_autograd=True)
@@ -1027,6 +971,7 @@ class _LinearFunction(Function):
     @staticmethod
     @once_differentiable
     @torch.amp.custom_bwd(device_type="cuda")
+    @_forward_modes
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         gy = gy.float()
@@ -1058,7 +1003,7 @@ def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
     y = linear(x, weight, bias, relu=relu, tag=tag)
     if y is not None:
         return y
-    if _GEMM["mode"] != "native" and torch.is_grad_enabled() and not torch.is_autocast_enabled() \
+    if _m().gemm != "native" and torch.is_grad_enabled() and not torch.is_autocast_enabled() \
             and x.is_cuda and x.dtype == torch.float32 \
             and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] % 32 == 0 \
             and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1] \
@@ -1075,7 +1020,7 @@ def merged_linear_params(owner, *linears, slot="_merged_linear"):
     sampling-offset and attention-weight projections; the value projections of all encoder
     layers), cached on ``owner`` while nothing needs a gradient and the parameters have not
     been written to."""
-    if torch.is_grad_enabled() and any(m.weight.requires_grad for m in linears):
+    if torch.is_grad_enabled() and any(p.requires_grad for m in linears for p in (m.weight, m.bias)):
         return (torch.cat([m.weight for m in linears], 0), torch.cat([m.bias for m in linears], 0))
     key = tuple((m.weight._version, m.bias._version, m.weight.data_ptr(), m.bias.data_ptr())
                 for m in linears)

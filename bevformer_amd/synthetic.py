@@ -34,6 +34,10 @@ WORKLOADS = {
     # projects/configs/bevformer/bevformer_base.py:34-37,54-61,80
     "base": dict(bev_h=200, bev_w=200, layers=6,
                  shapes=[(116, 200), (58, 100), (29, 50), (15, 25)], img=(928, 1600), s=1.0),
+    # one layer of the base geometry: the gradient checks against autograd through the CPU oracle (six layers of
+    # saved grid_sample intermediates do not fit a test's time budget, one does)
+    "base1": dict(bev_h=200, bev_w=200, layers=1,
+                  shapes=[(116, 200), (58, 100), (29, 50), (15, 25)], img=(928, 1600), s=1.0),
 }
 
 EMBED_DIMS = 256

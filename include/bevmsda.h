@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BEVMSDA_ABI_VERSION 1
+#define BEVMSDA_ABI_VERSION 2
 
 enum {
   BEVMSDA_OK = 0,
@@ -51,7 +51,10 @@ typedef struct bevmsda_tuning {
                         channel; 3/4/5 = D=32 forward sized for 4/8/2 waves per SIMD */
   int32_t qtile;     /* 0 = default; queries of one head handled by adjacent lane groups */
   int32_t xcd_remap; /* 0 = default, 1 = off, 2 = on: contiguous row ranges per XCD */
-  int32_t reserved[5];
+  int32_t reserved[5]; /* backward only: [0] = rows per workgroup of the grad_value sort kernel (0 = default; 64 / 128 /
+                          256); [1], [2] = low / high word of a DEVICE address of 8 uint64 that receive the phase clocks
+                          of that kernel (0 = off; tools/gvprof.py); [3] = 1: bf16 storage takes the 8-byte-lane gather
+                          kernel instead of the 16-byte-lane one */
 } bevmsda_tuning;
 
 int bevmsda_abi_version(void);
@@ -228,32 +231,6 @@ int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_a
                                       const bevmsda_fused_desc *desc, float *grad_offs, float *grad_logits,
                                       void *stream);
 
-/* bevmsda_fused_forward_f32 / _rows_f32 for SpatialCrossAttention with the two COARSE feature levels of a
- * (camera, head) patch served from LDS while the two fine levels stream through the vector-memory path
- * (csrc/msda_lds2.h).  Rows must be grouped by value batch entry (camera).  nrows: NULL (desc->R rows), or
- * the DEVICE row count with desc->R the capacity and desc->reserved[3] the host's hint, as for
- * bevmsda_fused_forward_rows_f32.  Requirements: fp32, D = 32, P = 8, K = 1, L = 4, ref_mode 0, vmul = 1,
- * vadd = 0; anything else returns BEVMSDA_ERR_UNSUPPORTED and the caller uses bevmsda_fused_forward_*.
- * Same results up to the order in which the four level sums are added. */
-int bevmsda_fused_forward_lds2_f32(const float *value, const int64_t *spatial_shapes,
-                                   const int64_t *level_start, const float *offs, const float *logits,
-                                   const float *ref, const int32_t *row_batch, const int32_t *row_src,
-                                   const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
-                                   void *stream);
-
-/* bevmsda_fused_forward_f32 for SpatialCrossAttention with the LAST feature level staged in
- * LDS: rows must be grouped by camera (value batch entry), cam_start (N + 1) int32 holds the
- * first row of every camera's run, lds_pixels = H * W of the last level (<= 512: 64 KB of LDS
- * per block), max_cam_rows = the longest run.  Requirements: D = 32, P = 8, K = 1, ref_mode 0
- * (pillar anchors), vmul = 1, vadd = 0; anything else returns BEVMSDA_ERR_UNSUPPORTED and the
- * caller uses bevmsda_fused_forward_f32.  Same results as that entry point (same coefficient
- * arithmetic, taps of the last level read from LDS instead of through the vector-memory path). */
-int bevmsda_fused_forward_lds_f32(const float *value, const int64_t *spatial_shapes,
-                                  const int64_t *level_start, const float *offs, const float *logits,
-                                  const float *ref, const int32_t *row_src, const int32_t *cam_start,
-                                  const bevmsda_fused_desc *desc, int lds_pixels, int max_cam_rows,
-                                  float *out, void *stream);
-
 /* Row-wise helpers of the encoder layer (csrc/rowops.h), fp32, forward only.
  *
  * out = LayerNorm(x + res) * gamma + beta over the last dimension C (res may be NULL):
@@ -302,13 +279,10 @@ typedef struct bevmsda_linear_desc {
   int32_t N, K0, K1;
   int32_t relu;                               /* 1: y = max(y, 0) after the bias */
   int32_t precision;                          /* 0 = split-fp32 (3 products), 1 = bf16 inputs */
-  int32_t variant;                            /* 0 = default launch variant, 1 + v selects variant v
-                                                 (benchmark sweeps): bit 0 of v = 64-deep K chunks,
-                                                 bit 1 = dword-row epilogue, bits 2-3 = packed-weight
-                                                 copy mode (1 registers, 2 LDS-DMA double-buffered,
-                                                 3 LDS-DMA single), bit 4 = 256-column block tiles,
-                                                 bit 5 = fragments-first schedule, bit 6 = 64-row
-                                                 block tiles (one of bits 4-6, copy mode 3 only) */
+  int32_t variant;                            /* 0 = library default; 1 = first kernel over the fp32 weight
+                                                 (bevmsda_linear_f32), 13 = first kernel over the packed weight
+                                                 image, 131 = software-pipelined kernel (packed weight, no
+                                                 addends; BEVMSDA_ERR_UNSUPPORTED when it does not cover the call) */
   int32_t group_cols;                         /* 0, or a multiple of 128 dividing N: output column n
                                                  is written to matrix n / group_cols of
                                                  N / group_cols consecutive (M, ldy) matrices at y,
@@ -319,7 +293,8 @@ typedef struct bevmsda_linear_desc {
                                                  nearest even; ldy / group layout in elements) — the
                                                  projected value of the bf16-storage sampling path;
                                                  float4-epilogue variants only, N and ldy % 4 == 0 */
-  int32_t reserved[4];
+  int32_t reserved[4];                        /* [1] = 1: the default never picks the software-pipelined kernel;
+                                                 [2]: panel shape of bevmsda_linear_panel_f32 */
 } bevmsda_linear_desc;
 
 int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const float *a1,
@@ -388,15 +363,11 @@ int bevmsda_frame_plan_f32(const float *lidar2img, const float *ref_3d, const in
 int bevmsda_fold_extra_rows_f32(float *rows, int64_t ld_rows, const int32_t *q_rows, int64_t slots, int J,
                                 int C, const int32_t *n_extra, void *stream);
 
-/* The packed projection with the residual add and the LayerNorm that follow it fused into its epilogue:
+/* Residual add + LayerNorm that follow a projection (`output_proj` / the FFN's second Linear, "+ identity" and
+ * `norms[i]` of an encoder layer: temporal_self_attention.py:267-272, spatial_cross_attention.py:173-175,
+ * encoder.py:376-404), as the epilogue descriptor of bevmsda_linear_panel_f32:
  *     y = LayerNorm(A w^T + bias + res) * gamma + beta         over the N = 256 columns of every row
- * — `output_proj` / the FFN's second Linear, "+ identity" and `norms[i]` of an encoder layer
- * (temporal_self_attention.py:267-272, spatial_cross_attention.py:173-175, encoder.py:376-404) in one
- * pass.  A as in bevmsda_linear_packed_f32, or, with idx / scale given, the two-row gather of
- * bevmsda_linear_gather_packed_f32 (then a0 / x1 must be NULL).  torch.nn.LayerNorm semantics.
- * Requirements: N = 256, no grouping / ReLU / bf16 output, res (if not NULL), gamma, beta, y 16-byte
- * aligned with row strides multiples of 4; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and the caller
- * runs the projection and bevmsda_add_layernorm_f32 separately. */
+ * torch.nn.LayerNorm semantics (biased variance, eps inside the square root). */
 typedef struct bevmsda_layernorm_desc {
   const float *res;      /* (M, ldres) or NULL */
   int64_t ldres;
@@ -405,11 +376,6 @@ typedef struct bevmsda_layernorm_desc {
   float eps;
   int32_t reserved[3];
 } bevmsda_layernorm_desc;
-
-int bevmsda_linear_layernorm_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
-                                        const int32_t *idx, const float *scale, const uint16_t *wpack,
-                                        const float *bias, const bevmsda_linear_desc *desc,
-                                        const bevmsda_layernorm_desc *ln, float *y, void *stream);
 
 /* Row-panel form of the projections (csrc/linear_panel.h): the same contract and arithmetic as
  * bevmsda_linear_packed_f32 / _gather_packed_f32 / _layernorm_packed_f32 behind one entry point, for the

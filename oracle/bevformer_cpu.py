@@ -308,13 +308,11 @@ def _inverse_affine_matrix(center, angle_deg):
     return [float(v) for v in m]
 
 
-def rotate_source_index(h, w, angle_deg, center, device="cpu"):
-    """Source pixel of every output pixel of ``rotate(img (C,h,w), angle, center=center)``
-    with nearest interpolation, as flat indices (h*w,) int64, -1 where the source falls
-    outside the image (zero fill).  torchvision 0.10 algorithm: ``rotate`` negates the angle
-    and re-centres ``center`` on the image centre; ``_gen_affine_grid`` builds the output
-    grid from pixel centres; ``grid_sample(nearest, zeros, align_corners=False)``
-    un-normalises with ((g + 1) * size - 1) / 2 and rounds half to even."""
+def rotate_affine_grid(h, w, angle_deg, center, device="cpu"):
+    """The normalised sampling grid (h*w, 2) torchvision 0.10's ``rotate(img (C,h,w), angle, center=center)`` hands
+    to ``grid_sample``: ``rotate`` negates the angle and re-centres ``center`` on the image centre,
+    ``_get_inverse_affine_matrix`` gives the 2 x 3 matrix, ``_gen_affine_grid`` builds the output grid from pixel
+    centres (fp32 linspace, bmm with the matrix divided by (w/2, h/2))."""
     center_f = [1.0 * (c - s * 0.5) for c, s in zip(center, [w, h])]
     theta = torch.tensor(_inverse_affine_matrix(center_f, -angle_deg), dtype=torch.float32,
                          device=device).reshape(1, 2, 3)
@@ -326,7 +324,16 @@ def rotate_source_index(h, w, angle_deg, center, device="cpu"):
     base[..., 2].fill_(1)
     rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32,
                                                     device=device)
-    grid = base.view(1, h * w, 3).bmm(rescaled).view(h * w, 2)
+    return base.view(1, h * w, 3).bmm(rescaled).view(h * w, 2)
+
+
+def rotate_source_index(h, w, angle_deg, center, device="cpu"):
+    """Source pixel of every output pixel of ``rotate(img (C,h,w), angle, center=center)``
+    with nearest interpolation, as flat indices (h*w,) int64, -1 where the source falls
+    outside the image (zero fill): ``grid_sample(nearest, zeros, align_corners=False)`` on
+    ``rotate_affine_grid`` un-normalises with ((g + 1) * size - 1) / 2 and rounds half to even
+    (pinned against torch's own grid_sample kernel in tests/test_transformer_cpu.py)."""
+    grid = rotate_affine_grid(h, w, angle_deg, center, device)
     ix = torch.round(((grid[:, 0] + 1) * w - 1) / 2)          # torch.round: half to even
     iy = torch.round(((grid[:, 1] + 1) * h - 1) / 2)
     ok = (ix >= 0) & (ix <= w - 1) & (iy >= 0) & (iy <= h - 1)

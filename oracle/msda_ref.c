@@ -69,8 +69,8 @@ int msda_ref_forward_f32(const float *value, const int64_t *shapes, const int64_
  * reference op (multi_scale_deformable_attn_function.py:146-160).
  * grad_value is accumulated in a double scratch owned by the caller
  * (size N*S*M*D) so that summation order does not matter to the checker;
- * pass NULL to accumulate directly in float.  Single-threaded over queries
- * (scatter), which is fine for a checker. */
+ * pass NULL to accumulate directly in float.  One thread per batch entry
+ * (scatter inside an entry stays sequential), which is fine for a checker. */
 int msda_ref_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                           const float *loc, const float *attn, const float *grad_out, int N, int S,
                           int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc,
@@ -79,6 +79,8 @@ int msda_ref_backward_f32(const float *value, const int64_t *shapes, const int64
   const size_t nv = (size_t)N * S * M * D;
   if (gv_scratch)
     for (size_t i = 0; i < nv; ++i) gv_scratch[i] = 0.0;
+  /* batch entries own disjoint slices of every gradient buffer: one thread each */
+#pragma omp parallel for schedule(dynamic, 1)
   for (int n = 0; n < N; ++n)
     for (int q = 0; q < Q; ++q)
       for (int m = 0; m < M; ++m) {

@@ -72,6 +72,15 @@ def _oracle_rotate_bev(prev_bev, angles_deg, center, bev_h, bev_w):
     return out
 
 
+def kernel_rotation_index(h, w, angle_deg, center, device, device_pose=False):
+    """The source-pixel map (h*w,) int64 (-1 = zero fill) the product's rotate kernel applies for this pose, read
+    off an index image; ``device_pose`` takes the GraphedBevHistory route (angle in a device tensor, matrix from
+    ``ops.rotation_theta_device``)."""
+    img = (torch.arange(h * w, dtype=torch.float32) + 1).view(-1, 1, 1).expand(-1, 1, 256).contiguous().to(device)
+    ang = torch.tensor([angle_deg], dtype=torch.float64, device=device) if device_pose else [float(angle_deg)]
+    return ops.rotate_bev(img, ang, center, h, w)[:, 0, 0].round().long().cpu() - 1
+
+
 def _oracle_flatten_feats(mlvl_feats, cams_embeds, level_embeds):
     """Contract of ``bevmsda_flatten_feats_f32`` in torch ops (transformer.py:165-184)."""
     flat, shapes = [], []

@@ -137,11 +137,9 @@ def test_fused_tsa_kernel_at_the_full_base_grid():
     torch.testing.assert_close(out.cpu()[rows], want, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
-def test_small4_forward_backward_gradients(storage, modes):
-    """BASELINE configs[2] (150x150 BEV, 4 levels, 3 layers, fwd + bwd): output and the gradients
-    w.r.t. BEV queries, camera features and every parameter against autograd through the oracle."""
-    name = "small4"
+def _gradient_case(name, storage, l2_tol, max_tol):
+    """Output and the gradients w.r.t. BEV queries, camera features and every parameter of workload ``name`` against
+    autograd through the oracle; prints the per-tensor errors (pytest -s / the log shows what the bounds rest on)."""
     ops.set_value_storage(storage)
     torch.set_num_threads(16)
     enc, sd = build_pair(name, device=DEV)
@@ -166,8 +164,7 @@ def test_small4_forward_backward_gradients(storage, modes):
     # of a pixel boundary takes the slope of one side on the CPU and of the other on the GPU, so single
     # elements of a gradient may differ by a whole tap difference.  Two bounds per tensor: the relative
     # L2 error (the tensor as a whole) and the max error relative to the tensor's largest entry.
-    l2_tol, max_tol = (5e-2, 0.3) if bf else (1e-2, 0.1)
-    bad = {}
+    bad, worst = {}, (0.0, 0.0)
     pairs = [("bev_query", qd.grad, qc.grad), ("feat", fd.grad, fc.grad)]
     pairs += [(k, p.grad, leaves[k].grad) for k, p in enc.named_parameters()]
     for k, a, b in pairs:
@@ -176,55 +173,28 @@ def test_small4_forward_backward_gradients(storage, modes):
         b = b.double()
         l2 = ((a - b).norm() / (b.norm() + 1e-30)).item()
         mx = ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+        print(f"{name} {str(storage).split('.')[-1]} grad {k}: rel L2 {l2:.2e}, max err / max |grad| {mx:.2e}")
+        worst = (max(worst[0], l2), max(worst[1], mx))
         if l2 > l2_tol or mx > max_tol:
             bad[k] = (l2, mx)
+    print(f"{name} {str(storage).split('.')[-1]}: worst rel L2 {worst[0]:.2e} (bound {l2_tol}), worst max ratio {worst[1]:.2e} (bound {max_tol})")
     assert not bad, bad
 
 
-def test_sca_kernel_with_coarse_levels_in_lds_at_base():
-    """csrc/msda_lds2.h (levels 2 and 3 of a (camera, head) patch served from LDS, levels 0 and 1 streamed)
-    against the plain fused kernel over ALL base rows — fixed and device-side row counts, offsets of a few
-    pixels (inside the staged boxes) and wild offsets (most points leave the boxes: the spill path)."""
-    from bevformer_amd.modules import geometry as G
-    name = "base"
-    w = S.WORKLOADS[name]
-    Q = w["bev_h"] * w["bev_w"]
-    M, L, P, D = 8, 4, 8, 32
-    g = torch.Generator().manual_seed(3)
-    shapes, start = S.level_tensors(name)
-    Sv = int(shapes.prod(1).sum())
-    value = torch.randn(S.NUM_CAMS, Sv, M, D, generator=g).to(DEV)
-    n_off = M * L * P * 2
-    pl = G.DevicePlanner(w["bev_h"], w["bev_w"], 1, S.PC_RANGE, 4, S.NUM_CAMS, DEV, row_order="image")
-    plan = pl.plan(S.make_img_metas(name))
-    host = plan.materialize()
-    R = host.row_batch.numel()
-    kw = dict(M=M, L=L, P=P, K=1, off_head=L * P * 2, off_k=0, lg_head=L * P, lg_k=0, ref_mode=0, vmul=1, vadd=0)
-    for scale in (4.0, 40.0):
-        proj = torch.randn(Q, M * L * P * 3, generator=g)
-        proj[:, :n_off] *= scale
-        proj = proj.to(DEV)
-        args = (value, shapes.to(DEV), start.to(DEV), proj, n_off)
-        ops.set_sca_lds2(False)
-        want = ops.msda_fused(*args, host.row_ref.reshape(-1, 1, 4, 2), host.row_batch, row_src=host.row_query32, **kw)
-        ops.set_sca_lds2(True)
-        try:
-            got = ops.msda_fused(*args, host.row_ref.reshape(-1, 1, 4, 2), host.row_batch, row_src=host.row_query32, **kw)
-            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-            for hint in (plan.launch_rows, R // 3):
-                dyn = ops.msda_fused(*args, plan.row_ref.reshape(-1, 1, 4, 2), plan.row_batch, row_src=plan.row_query32,
-                                     nrows=plan.nrows_dev, launch_rows=hint, **kw)
-                torch.testing.assert_close(dyn[:R], want, rtol=1e-5, atol=1e-5)
-        finally:
-            ops.set_sca_lds2(False)
+# bounds = 3 x the worst per-tensor error measured on the GPU box (profiles/r3/r3c_gradient_errors.log); the float32 CPU
+# oracle is itself 2e-3 (d query) / 6e-3 (worst parameter) away from a float64 evaluation (profiles/r2/train_fwd_table.txt)
+GRAD_TOL = {("small4", torch.float32): (1e-2, 0.1), ("small4", torch.bfloat16): (5e-2, 0.3),
+            ("base1", torch.float32): (1e-2, 0.1), ("base1", torch.bfloat16): (5e-2, 0.3)}
 
 
-@pytest.mark.parametrize("name", ["base", "micro4"])
-def test_encoder_forward_with_sca_lds2(name, modes):
-    ops.set_sca_lds2(True)
-    try:
-        got = _gpu_frame(name, True)
-    finally:
-        ops.set_sca_lds2(False)
-    want = _oracle_frame(name, True)
-    torch.testing.assert_close(got, want, **ENC_TOL)
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_small4_forward_backward_gradients(storage, modes):
+    """BASELINE configs[2] (150x150 BEV, 4 levels, 3 layers, fwd + bwd)."""
+    _gradient_case("small4", storage, *GRAD_TOL[("small4", storage)])
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_base_geometry_one_layer_forward_backward_gradients(storage, modes):
+    """One encoder layer at the base geometry (200x200 queries, 45,960 image-ordered SCA rows, 128-row sort
+    workgroups, 16x16 TSA tiles): what ``fwd_bwd_base`` of the bench runs six times."""
+    _gradient_case("base1", storage, *GRAD_TOL[("base1", storage)])

@@ -157,31 +157,6 @@ def test_plan_cache_makes_steady_state_sync_free(device_plans):
     torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,bs", [("micro4", 1), ("micro4", 2), ("tiny", 1), ("micro", 1)])
-def test_sca_coarse_level_from_lds_is_identical(name, bs):
-    """The SCA sampling kernel with the last feature level staged in LDS computes the same
-    coefficients and accumulates in the same order as the default kernel: identical encoder
-    output (4 levels, 1 level, bs = 2 exercises the per-entry camera runs)."""
-    enc, sd = build_pair(name, device=DEV)
-    enc.device_plans = False            # the LDS-level launch is sized from the host-side camera runs
-    q, f, kw = S.make_inputs(name, seed=0, bs=bs, temporal=True)
-    args = (q.to(DEV), f.to(DEV), f.to(DEV))
-    try:
-        with torch.no_grad():
-            ops.set_sca_lds_level(False)
-            want = enc(*args, **_to_dev(kw))
-            ops.set_sca_lds_level(True)
-            got = enc(*args, **_to_dev(kw))
-    finally:
-        ops.set_sca_lds_level(False)
-    plan = next(iter(enc._plan_cache.values()))
-    assert plan.cam_start is not None and plan.max_cam_rows > 0
-    torch.testing.assert_close(got, want, rtol=0, atol=1e-6)
-    with torch.no_grad():
-        ref = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
-    torch.testing.assert_close(got.cpu(), ref, **TOL)
-
-
 @pytest.mark.parametrize("name", ["micro4", "tiny"])
 def test_encoder_forward_bf16_value_storage(name):
     """bf16 storage of the projected value tensors (written by the projection kernel, read by
@@ -202,17 +177,14 @@ def test_encoder_forward_bf16_value_storage(name):
     assert cos > 0.999, cos
 
 
-def test_encoder_forward_with_layernorm_fused_into_projections():
-    """Opt-in path (ops.set_layernorm_fusion): output_proj / fc2 + residual + LayerNorm in one kernel —
-    same encoder output within the encoder tolerance."""
+@pytest.mark.parametrize("fuse", [True, False])
+def test_encoder_forward_with_and_without_layernorm_fused_into_projections(fuse):
+    """output_proj / fc2 + residual + LayerNorm in one kernel (the default: row-panel kernel epilogue) and as
+    projection + add_layernorm launches (``ln_fuse=False``): same encoder output within the encoder tolerance."""
     enc, sd = build_pair("micro4", device=DEV)
     q, f, kw = S.make_inputs("micro4", seed=0, temporal=True)
-    ops.set_layernorm_fusion(True)
-    try:
-        with torch.no_grad():
-            got = enc(q.to(DEV), f.to(DEV), f.to(DEV), **_to_dev(kw)).cpu()
-    finally:
-        ops.set_layernorm_fusion(False)
+    with torch.no_grad(), ops.using(ln_fuse=fuse):
+        got = enc(q.to(DEV), f.to(DEV), f.to(DEV), **_to_dev(kw)).cpu()
     with torch.no_grad():
         want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
     torch.testing.assert_close(got, want, **TOL)

@@ -8,7 +8,7 @@ from bevformer_amd import history
 from bevformer_amd import synthetic as S
 from oracle import bevformer_cpu as O
 
-from helpers import build_transformer_pair, split_transformer_sd
+from helpers import build_transformer_pair, kernel_rotation_index, split_transformer_sd
 from test_history_cpu import _video
 
 pytestmark = pytest.mark.gpu
@@ -23,24 +23,37 @@ def test_video_through_the_history_queue(name):
     w = S.WORKLOADS[name]
     hist = history.BevHistory()
     info = {"prev_bev": None, "scene_token": None, "prev_pos": 0, "prev_angle": 0}
+    ties, pixels = [], []
     for mlvl, metas, bq, kw in frames:
         def product(f, m, p):
             return t.get_bev_features([x.to(DEV) for x in f], bq.to(DEV), kw["bev_h"], kw["bev_w"],
                                       grid_length=kw["grid_length"], bev_pos=kw["bev_pos"].to(DEV), prev_bev=p,
                                       img_metas=m)
 
+        def rotate_as_the_kernel(img, angle, center):
+            # Nearest-neighbour rotation is an index map, and a coordinate within fp32 round-off of a rounding tie
+            # may pick the other neighbour on the GPU (no fused multiply-adds in the kernel, bmm on the CPU): the
+            # oracle frame takes the KERNEL's map, the pixels where it differs from the oracle's own map are counted
+            # as ties (each must be an adjacent source pixel: tests/test_prologue_gpu.py), and then EVERY row of
+            # the frame has to agree.
+            C, h, ww = img.shape
+            idx = kernel_rotation_index(h, ww, angle, center, DEV)
+            ties.append(int((idx != O.rotate_source_index(h, ww, angle, list(center))).sum()))
+            pixels.append(h * ww)
+            flat = img.reshape(C, h * ww)
+            return (flat[:, idx.clamp(min=0)] * (idx >= 0).to(img.dtype)).view(C, h, ww)
+
         def oracle(f, m, p):
             return O.get_bev_features(own, enc, f, bq, kw["bev_h"], kw["bev_w"], bev_pos=kw["bev_pos"], img_metas=m,
                                       pc_range=S.PC_RANGE, grid_length=kw["grid_length"], prev_bev=p,
-                                      rotate_center=(w["bev_w"] // 2, w["bev_h"] // 2))
+                                      rotate_center=(w["bev_w"] // 2, w["bev_h"] // 2), rotate_fn=rotate_as_the_kernel)
         import copy
         got = hist.step(product, mlvl, metas).cpu()
         with torch.no_grad():
             want = O.forward_test_step(info, oracle, mlvl, copy.deepcopy(metas))
-        # a rotation tie may move single history rows by one pixel (tests/test_prologue_gpu.py): bound
-        # the fraction of rows out of tolerance instead of every element
-        err = (got - want).abs().amax(-1)
-        assert (err > 1e-3).float().mean().item() < 5e-3, err.max().item()
+        torch.testing.assert_close(got, want, rtol=1e-3, atol=1e-3)
+    print(f"{name}: rotation ties over the video: {sum(ties)} of {sum(pixels)} history pixels")
+    assert sum(ties) <= max(1, int(2e-4 * sum(pixels)))
 
 
 @pytest.mark.parametrize("name", ["micro4", "tiny"])
@@ -65,7 +78,13 @@ def test_graph_replayed_history_queue_equals_the_eager_one(name):
         f = [x.to(DEV) for x in mlvl]
         want = eager.step(bev_fn, f, metas).clone()
         got = graphed.step(None, f, metas).clone()
-        # (device float64 cos / sin against the host's: a rotation tie may move single history rows)
+        # device float64 cos / sin against the host's: the two rotation matrices may differ in the last bit and move a
+        # history pixel that sits on a rounding tie.  Count those pixels from the two index maps; without any, every
+        # row must agree, with some, only rows in reach of a moved pixel may differ.
         err = (got - want).abs().amax(-1)
-        assert (err > 1e-3).float().mean().item() < 5e-3, err.max().item()
+        angle = float(eager.rewritten_metas[0]["can_bus"][-1])
+        ctr = (kw["bev_w"] // 2, kw["bev_h"] // 2)
+        moved = int((kernel_rotation_index(kw["bev_h"], kw["bev_w"], angle, ctr, DEV)
+                     != kernel_rotation_index(kw["bev_h"], kw["bev_w"], angle, ctr, DEV, device_pose=True)).sum())
+        assert int((err > 1e-3).sum()) <= 512 * moved, (moved, err.max().item())
     assert set(graphed.graphs) == {False, True}

@@ -86,3 +86,36 @@ def test_projection_op_declines_on_cpu_and_in_native_mode():
             assert ops.linear_gather_mean(x, torch.zeros(4, 2, dtype=torch.int32), torch.ones(4), w) is None
     finally:
         ops.set_gemm_mode(saved)
+
+
+def test_modes_are_thread_local_overrides_of_process_defaults():
+    """bevformer_amd/modes.py: ``using`` changes what the CALLING thread sees, other threads keep the process
+    defaults, nesting restores, and a snapshot re-activated elsewhere (what the autograd Functions do for their
+    backward, which the engine runs on its own thread) carries the caller's values."""
+    import threading
+    import torch
+    from bevformer_amd import modes, ops
+    base = modes.current().gemm
+    seen = {}
+    with ops.using(gemm="bf16", value_storage=torch.bfloat16) as m:
+        assert modes.current().gemm == "bf16" and ops.value_storage() == torch.bfloat16
+        snap = m.snapshot()
+        t = threading.Thread(target=lambda: seen.update(other=modes.current().gemm))
+        t.start()
+        t.join()
+        with ops.using(gemm="native"):
+            assert modes.current().gemm == "native" and ops.value_storage() == torch.bfloat16
+        assert modes.current().gemm == "bf16"
+
+        def engine_thread():
+            with modes.activate(snap):
+                seen["engine"] = (modes.current().gemm, modes.current().value_storage)
+        t = threading.Thread(target=engine_thread)
+        t.start()
+        t.join()
+    assert seen["other"] == base and seen["engine"] == ("bf16", torch.bfloat16)
+    assert modes.current().gemm == base and modes.current() is modes.process_defaults()
+    import pytest
+    with pytest.raises(AttributeError):
+        with ops.using(no_such_mode=1):
+            pass

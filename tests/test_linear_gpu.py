@@ -25,9 +25,10 @@ def gemm_mode():
     ops.set_gemm_variant(None, pack=True)
 
 
-# launch variants of the kernel (include/bevmsda.h): 64-deep chunks, both epilogues, and the
-# three copy modes of the pre-split weight image
-VARIANTS = [None, 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 28, 30, 44, 46, 76, 78]
+# launch variants of the first kernel (include/bevmsda.h): the fp32 weight matrix split in the kernel (0), the
+# pre-split weight image copied by LDS-DMA (12).  The variants that lost (64-deep chunks, dword epilogue, register /
+# double-buffered copies, 256-column and 64-row tiles, fragments-first) went with round 2: profiles/r1, tools/experimental
+VARIANTS = [None, 0, 12]
 
 
 def _ref64(x, w, b, relu=False):
@@ -52,8 +53,6 @@ def test_linear_variants(gemm_mode, mode, variant):
     gemm_mode(mode)
     ops.set_gemm_variant(variant)
     M, K0, K1, N = 391, 128, 64, 332
-    if variant is not None and variant & 16:
-        N = 512            # 256-column tiles need N % 256 == 0 (other N fall back to 128 inside the library)
     x0, x1, a1 = _rand(M, K0, seed=11), _rand(M, K1, seed=12), _rand(M, K1, seed=13)
     w, b = _rand(N, K0 + K1, seed=14) * 0.1, _rand(N, seed=15)
     with torch.no_grad():
@@ -84,7 +83,7 @@ def test_linear_matches_fp64(gemm_mode, mode, M, N, K):
         assert lib < BOUND[mode]
 
 
-@pytest.mark.parametrize("variant", [None, 0, 12, 28, 44, 76])
+@pytest.mark.parametrize("variant", [None, 0, 12])
 def test_linear_identity_with_asymmetric_weight(gemm_mode, variant):
     """A = I picks single weights: catches a transposed / permuted accumulator map, and shows
     that an fp32 weight survives the hi + lo split to 2^-17."""
@@ -130,7 +129,7 @@ def test_linear_not_covered_returns_none(gemm_mode):
         assert ops.linear(_rand(10, 64, seed=1), _rand(7, 64, seed=2)) is None
 
 
-@pytest.mark.parametrize("variant", [None, 0, 2, 12, 14, 28, 30, 44, 76])
+@pytest.mark.parametrize("variant", [None, 0, 12])
 def test_linear_grouped_output(gemm_mode, variant):
     """groups = G: G Linear layers over one input -> (G, M, N / G) contiguous outputs."""
     gemm_mode("split")
@@ -202,9 +201,6 @@ def test_linear_bf16_output_is_the_rounded_fp32_result(gemm_mode, variant):
         y16 = ops.linear(x, w, b, groups=2, out_dtype=torch.bfloat16)
     assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
     assert torch.equal(y16, y32.to(torch.bfloat16))
-    ops.set_gemm_variant(2)                 # dword-row epilogue: no bf16 packing -> not covered
-    with torch.no_grad():
-        assert ops.linear(x, w, b, out_dtype=torch.bfloat16) is None
 
 
 @pytest.mark.parametrize("relu", [False, True])
@@ -233,7 +229,7 @@ def test_linear_autograd_function_matches_torch(gemm_mode, relu):
 @pytest.mark.parametrize("M,K", [(1000, 256), (4099, 512), (128, 256)])
 @pytest.mark.parametrize("with_res", [True, False])
 def test_linear_layernorm_fused_epilogue(M, K, with_res):
-    """``bevmsda_linear_layernorm_packed_f32``: LayerNorm(x W^T + b + res) against the fp64 statement of
+    """``bevmsda_linear_panel_f32`` with a LayerNorm descriptor: LayerNorm(x W^T + b + res) against the fp64 statement of
     the three torch ops; ragged last row tile, K = 256 / 512, with and without residual."""
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g)
@@ -249,12 +245,8 @@ def test_linear_layernorm_fused_epilogue(M, K, with_res):
         y64 = y64 + res.double()
     want = torch.nn.functional.layer_norm(y64, (256,), norm.weight.double(), norm.bias.double(), norm.eps)
     norm = norm.to(DEV)
-    ops.set_layernorm_fusion(True)
-    try:
-        with torch.no_grad():
-            got = ops.linear_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV) if with_res else None, norm)
-    finally:
-        ops.set_layernorm_fusion(False)
+    with torch.no_grad(), ops.using(ln_fuse=True):
+        got = ops.linear_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV) if with_res else None, norm)
     assert got is not None and got.shape == (M, 256)
     # (LayerNorm divides by the row's standard deviation: the split-bf16 product round-off of 4e-6 x
     # |x||w| shows up as ~3e-5 on rows of unit-scale output)
@@ -285,57 +277,11 @@ def test_linear_layernorm_with_camera_gather():
     want = torch.nn.functional.layer_norm(torch.nn.functional.linear(a, w.double(), b.double()) + res.double(), (256,),
                                           norm.weight.double(), norm.bias.double(), norm.eps)
     norm = norm.to(DEV)
-    ops.set_layernorm_fusion(True)
-    try:
-        with torch.no_grad():
-            got = ops.linear_layernorm(rows.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV), norm,
-                                       gather=(idx.to(DEV), scale.to(DEV)))
-    finally:
-        ops.set_layernorm_fusion(False)
+    with torch.no_grad(), ops.using(ln_fuse=True):
+        got = ops.linear_layernorm(rows.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV), norm,
+                                   gather=(idx.to(DEV), scale.to(DEV)))
     assert got is not None
     torch.testing.assert_close(got.cpu().double(), want, rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
-    (1000, 256, 0, 256, False, 1, torch.float32), (4099, 256, 256, 192, False, 1, torch.float32),
-    (513, 256, 0, 512, True, 1, torch.float32), (2050, 256, 0, 768, False, 3, torch.float32),
-    (300, 512, 0, 256, False, 1, torch.float32), (1111, 256, 0, 256, False, 2, torch.bfloat16)])
-@pytest.mark.parametrize("mode", ["split", "bf16"])
-def test_linear_dma_kernel(M, K0, K1, N, relu, groups, out, mode):
-    """csrc/linear_dma.h (activations by LDS-DMA, swizzled fp32 image, in-register split) against the fp64
-    statement of F.linear: ragged row tiles, two K sources, ReLU, grouped output, bf16 output; and against
-    the first kernel (same arithmetic: bit-identical)."""
-    g = torch.Generator().manual_seed(M + N)
-    x = torch.randn(M, K0, generator=g)
-    x2 = torch.randn(M, K1, generator=g) if K1 else None
-    w = torch.randn(N, K0 + K1, generator=g) * (K0 + K1) ** -0.5
-    b = torch.randn(N, generator=g) * 0.1
-    a64 = x.double() if x2 is None else torch.cat([x, x2], -1).double()
-    want = torch.nn.functional.linear(a64, w.double(), b.double())
-    if relu:
-        want = want.relu()
-    saved = ops.gemm_mode()
-    ops.set_gemm_mode(mode)
-    try:
-        res = {}
-        for dma in (True, False):
-            ops.set_gemm_dma(dma)
-            with torch.no_grad():
-                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, x2=x2.to(DEV) if K1 else None, groups=groups,
-                               out_dtype=out)
-            assert y is not None
-            res[dma] = y
-    finally:
-        ops.set_gemm_dma(None)
-        ops.set_gemm_mode(saved)
-    y = res[True].float().cpu()
-    if groups > 1:
-        y = torch.cat(list(y), -1)
-    scale = (a64.abs() @ w.double().abs().t()).clamp(min=1e-6)
-    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
-    assert (((y.double() - want).abs()) / scale.max()).max().item() < tol
-    assert ((y.double() - want).abs() / scale).max().item() < tol * 40
-    assert torch.equal(res[True], res[False])
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (4099, 192, 512), (130, 768, 256), (40000, 256, 256), (33, 64, 32)])
@@ -360,46 +306,6 @@ def test_linear_wgrad_kernel(M, N, K, mode):
     assert ((gw.cpu().double() - want_w).abs() / scale.clamp(min=1e-9)).max().item() < tol * 40
     assert ((gw.cpu().double() - want_w).abs().max() / scale.max()).item() < tol
     torch.testing.assert_close(gb.cpu().double(), want_b, rtol=1e-4, atol=1e-4 * M ** 0.5)
-
-
-@pytest.mark.parametrize("M,K,N,relu,groups,out", [
-    (70000, 256, 256, False, 1, torch.float32), (33001, 256, 512, True, 1, torch.float32),
-    (12345, 256, 1536, False, 6, torch.float32), (20011, 128, 896, False, 1, torch.float32),
-    (65570, 256, 256, False, 2, torch.bfloat16)])
-@pytest.mark.parametrize("mode", ["split", "bf16"])
-def test_linear_weight_stationary_kernel(M, K, N, relu, groups, out, mode):
-    """csrc/linear_ws.h (weight image of a column tile resident in LDS, activation rows loaded straight into
-    MFMA fragments with a permuted k order, 64- and 32-row tiles per wavefront) against the fp64 statement
-    of F.linear and against the first kernel: ragged row runs, N not a multiple of 128, grouped / bf16 output."""
-    g = torch.Generator().manual_seed(M + N)
-    x = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) * K ** -0.5
-    b = torch.randn(N, generator=g) * 0.1
-    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
-    if relu:
-        want = want.relu()
-    saved = ops.gemm_mode()
-    ops.set_gemm_mode(mode)
-    try:
-        res = {}
-        for kern in ("ws", "first"):
-            ops.set_gemm_kernel(kern)
-            with torch.no_grad():
-                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, groups=groups, out_dtype=out)
-            assert y is not None
-            res[kern] = y.float().cpu()
-    finally:
-        ops.set_gemm_kernel(None)
-        ops.set_gemm_mode(saved)
-    y = res["ws"]
-    if groups > 1:
-        y = torch.cat(list(y), -1)
-    scale = (x.double().abs() @ w.double().abs().t()).clamp(min=1e-6)
-    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
-    assert ((y.double() - want).abs() / scale).max().item() < tol
-    # same products, another summation order over k inside a 32-deep chunk
-    torch.testing.assert_close(res["ws"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
-                               atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)
 
 
 @pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
@@ -430,47 +336,6 @@ def test_linear_software_pipelined_kernel(M, K0, K1, N, relu, groups, out, mode)
         ops.set_gemm_kernel(None)
         ops.set_gemm_mode(saved)
     assert torch.equal(res["pipe"], res["first"])
-
-
-@pytest.mark.parametrize("M,N,relu,groups,out", [
-    (70000, 256, False, 1, torch.float32), (33001, 512, True, 1, torch.float32),
-    (12345, 1536, False, 6, torch.float32), (300, 128, False, 1, torch.float32),
-    (65570, 256, False, 2, torch.bfloat16)])
-@pytest.mark.parametrize("mode", ["split", "bf16"])
-def test_linear_activation_stationary_kernel(M, N, relu, groups, out, mode):
-    """csrc/linear_areg.h (a wavefront's 32 rows resident in registers as MFMA fragments for all of K = 256, the
-    packed weight image streamed through a 6-stage LDS ring five chunks ahead across column tiles, per-wavefront
-    wait counts) against the fp64 statement of F.linear and against the first kernel: ragged last workgroup,
-    wavefronts without rows, 1 - 12 column tiles, grouped / bf16 output."""
-    K = 256
-    g = torch.Generator().manual_seed(M + N)
-    x = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) * K ** -0.5
-    b = torch.randn(N, generator=g) * 0.1
-    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
-    if relu:
-        want = want.relu()
-    saved = ops.gemm_mode()
-    ops.set_gemm_mode(mode)
-    try:
-        res = {}
-        for kern in ("areg", "first"):
-            ops.set_gemm_kernel(kern)
-            with torch.no_grad():
-                y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, groups=groups, out_dtype=out)
-            assert y is not None
-            res[kern] = y.float().cpu()
-    finally:
-        ops.set_gemm_kernel(None)
-        ops.set_gemm_mode(saved)
-    y = res["areg"]
-    if groups > 1:
-        y = torch.cat(list(y), -1)
-    scale = (x.double().abs() @ w.double().abs().t()).clamp(min=1e-6)
-    tol = (2.5e-5 if mode == "split" else 8e-3) + (4e-3 if out == torch.bfloat16 else 0.0)
-    assert ((y.double() - want).abs() / scale).max().item() < tol
-    torch.testing.assert_close(res["areg"], res["first"], rtol=1e-2 if out == torch.bfloat16 else 1e-4,
-                               atol=2e-2 if (out == torch.bfloat16 or mode == "bf16") else 1e-5)
 
 
 @pytest.mark.parametrize("M,K0,K1,N,relu,groups,out", [
@@ -555,18 +420,12 @@ def test_linear_row_panel_layernorm_and_gather(gemm_mode, kernel):
     with torch.no_grad():
         norm.weight.copy_(_rand(256, seed=77) * 0.2 + 1.0)
         norm.bias.copy_(_rand(256, seed=78) * 0.1)
-    try:
-        ops.set_gemm_kernel(kernel)
-        ops.set_layernorm_fusion(True)
-        with torch.no_grad():
-            got = ops.linear_layernorm(rows, w, b, res, norm, gather=(idx, scale))
-            two = ops.linear_gather_mean(rows, idx, scale, w, b)
-            three = ops.linear(ops.gather_mean(rows, idx, scale), w, b)
-            got5 = ops.linear_layernorm(x5, w5, b, res, norm)
-            lin5 = ops.linear(x5, w5, b)
-    finally:
-        ops.set_layernorm_fusion(False)
-        ops.set_gemm_kernel(None)
+    with torch.no_grad(), ops.using(gemm_kernel=kernel, ln_fuse=True):
+        got = ops.linear_layernorm(rows, w, b, res, norm, gather=(idx, scale))
+        two = ops.linear_gather_mean(rows, idx, scale, w, b)
+        three = ops.linear(ops.gather_mean(rows, idx, scale), w, b)
+        got5 = ops.linear_layernorm(x5, w5, b, res, norm)
+        lin5 = ops.linear(x5, w5, b)
     assert got is not None and two is not None and got5 is not None
     assert torch.equal(two, three)                             # gather in the split pass == gather_mean + projection
     want = torch.nn.functional.layer_norm(two.double() + res.double(), (256,), norm.weight.double(), norm.bias.double(), norm.eps)

@@ -270,8 +270,8 @@ def test_fused_front_end_bf16_storage_kernels(kind, monkeypatch):
     ops.set_value_storage(torch.bfloat16)
     try:
         got16 = ops.msda_fused(*args, **kw)
-        monkeypatch.setenv("BEVMSDA_BF16_LANES8", "1")
-        got8 = ops.msda_fused(*args, **kw)
+        with ops.using(bf16_lanes8=True):
+            got8 = ops.msda_fused(*args, **kw)
     finally:
         ops.set_value_storage(torch.float32)
     assert got16 is not None and got16.dtype == torch.float32

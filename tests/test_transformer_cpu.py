@@ -208,3 +208,31 @@ def test_transformer_v2_frame_filling_matches_reference_file():
                 prev[i] = prev[i - 1].detach()
         want = ref.fusion([x.reshape(x.shape[0], h, w, x.shape[-1]).permute(0, 3, 1, 2).contiguous() for x in prev])
     torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_rotate_source_index_is_torch_grid_sample_nearest_on_the_torchvision_grid():
+    """The inside of the restated ``rotate``: torchvision's tensor path ends in
+    ``torch.nn.functional.grid_sample(img, grid, mode='nearest', padding_mode='zeros', align_corners=False)``
+    on the grid of ``_gen_affine_grid``.  torch IS installed: run its grid_sample kernel on an index image over the
+    same grid and require the oracle's index map (un-normalisation, rounding half to even, bounds) to be the one it
+    produces — random angles and centres at the base grid (200 x 200), odd sizes, quarter turns and half-pixel
+    centres (which put coordinates exactly on rounding ties)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    cases = [(200, 200, (100, 100), a) for a in (torch.rand(12, generator=g) * 20 - 10).tolist()]
+    cases += [(200, 200, (float(cx), float(cy)), a) for cx, cy, a in
+              zip((torch.rand(8, generator=g) * 200).tolist(), (torch.rand(8, generator=g) * 200).tolist(),
+                  (torch.rand(8, generator=g) * 360 - 180).tolist())]
+    cases += [(37, 53, (20, 11), 33.0), (50, 50, (25, 25), 90.0), (50, 50, (24.5, 24.5), 90.0), (12, 10, (5, 6), 180.0),
+              (150, 150, (75, 75), -0.37), (200, 200, (100, 100), 0.0), (16, 16, (7.5, 7.5), 45.0)]
+    ties = 0
+    for h, w, center, angle in cases:
+        grid = O.rotate_affine_grid(h, w, angle, list(center))
+        img = (torch.arange(h * w, dtype=torch.float32) + 1).view(1, 1, h, w)
+        out = F.grid_sample(img, grid.view(1, h, w, 2), mode="nearest", padding_mode="zeros", align_corners=False)
+        want = out.view(-1).long() - 1                                    # -1 = zero fill
+        got = O.rotate_source_index(h, w, angle, list(center))
+        assert torch.equal(got, want), (h, w, center, angle, int((got != want).sum()))
+        px = ((grid[:, 0] + 1) * w - 1) / 2
+        ties += int(((px - px.floor()) == 0.5).sum())
+    assert ties > 0            # the half-pixel-centre quarter turns do sit on ties: the rounding rule was exercised

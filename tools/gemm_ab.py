@@ -78,12 +78,10 @@ def main():
                 ops.set_gemm_kernel(k)
                 cols.append(med([timeit(lambda: ops.add_layernorm(ops.linear(x, w, b), res, norm.weight, norm.bias, norm.eps),
                                         args.iters)[0] * 1e6 for _ in range(args.rounds)]))
-            ops.set_layernorm_fusion(True)
             for k in ("panel64", "panel128"):
                 ops.set_gemm_kernel(k)
                 cols.append(med([timeit(lambda: ops.linear_layernorm(x, w, b, res, norm), args.iters)[0] * 1e6
                                  for _ in range(args.rounds)]))
-            ops.set_layernorm_fusion(False)
             ops.set_gemm_kernel(None)
         print(f"   {name:22s}" + "".join(f"{c:12.1f}" for c in cols))
 

@@ -15,7 +15,6 @@ for s in $steps; do
     bench_quick) timeout 600 python bench.py --no-cpu-baseline > "$out/bench_quick.json" 2> "$out/bench_quick.err"; echo "rc=$?" >> "$out/bench_quick.err"; tail -3 "$out/bench_quick.err"; python tools/bench_digest.py "$out/bench_quick.json";;
     bench_polar) timeout 600 python bench.py --no-cpu-baseline --no-variants --row-order polar > "$out/bench_polar.json" 2> "$out/bench_polar.err"; tail -2 "$out/bench_polar.err"; python tools/bench_digest.py "$out/bench_polar.json";;
     bench_main) timeout 600 python bench.py --no-cpu-baseline --no-variants > "$out/bench_main.json" 2> "$out/bench_main.err"; tail -2 "$out/bench_main.err"; python tools/bench_digest.py "$out/bench_main.json";;
-    bench_lds2) BEVMSDA_SCA_LDS2=1 timeout 600 python bench.py --no-cpu-baseline --no-variants > "$out/bench_lds2.json" 2> "$out/bench_lds2.err"; tail -2 "$out/bench_lds2.err"; python tools/bench_digest.py "$out/bench_lds2.json";;
     bench_static) timeout 600 python bench.py --no-cpu-baseline --no-variants --static-rig > "$out/bench_static.json" 2> "$out/bench_static.err"; tail -2 "$out/bench_static.err"; python tools/bench_digest.py "$out/bench_static.json";;
     bench_hostplans) timeout 600 python bench.py --no-cpu-baseline --no-variants --host-plans > "$out/bench_hostplans.json" 2> "$out/bench_hostplans.err"; tail -2 "$out/bench_hostplans.err"; python tools/bench_digest.py "$out/bench_hostplans.json";;
     bench_eager) timeout 600 python bench.py --no-cpu-baseline --graph off > "$out/bench_eager.json" 2> "$out/bench_eager.err"; tail -2 "$out/bench_eager.err"; python tools/bench_digest.py "$out/bench_eager.json";;
@@ -25,7 +24,6 @@ for s in $steps; do
     trace) PMC=0 timeout 400 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; head -40 "$out/prof_summary.txt" | cut -c1-170;;
     prof) PMC=1 timeout 1200 tools/prof.sh "$tag" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_summary.txt" 2>&1; tail -30 "$out/prof_summary.txt" | cut -c1-170;;
     prof_bwd) PMC=1 timeout 1200 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --backward --steps 2 --warmup 1 --windows 1 > "$out/prof_bwd_summary.txt" 2>&1; tail -30 "$out/prof_bwd_summary.txt" | cut -c1-170;;
-    prof_lds2) BEVMSDA_SCA_LDS2=1 TRACE=0 PMC=1 PMC_ONLY="1 3 4" timeout 900 tools/prof.sh "${tag}_lds2" python "$root/bench.py" --no-cpu-baseline --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_lds2_summary.txt" 2>&1; tail -30 "$out/prof_lds2_summary.txt" | cut -c1-170;;
     trace_sim) PMC=0 timeout 400 tools/prof.sh "${tag}_sim" python "$root/bench.py" --no-cpu-baseline --no-variants --simulate-rank 3,8 --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_sim_summary.txt" 2>&1; head -40 "$out/prof_sim_summary.txt" | cut -c1-170;;
     trace_bwd) PMC=0 timeout 400 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --backward --steps 2 --warmup 1 --windows 1 > "$out/prof_bwd_summary.txt" 2>&1; head -40 "$out/prof_bwd_summary.txt" | cut -c1-170;;
     kb*) timeout 600 python tools/kbench2.py > "$out/$s.log" 2>&1; tail -30 "$out/$s.log";;

@@ -18,7 +18,6 @@ for s in $steps; do
     bench) timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"; cat "$out/bench.json";;
     bench_vbf16) timeout 300 python bench.py --no-cpu-baseline --value-storage bf16 > "$out/bench_vbf16.json" 2> "$out/bench_vbf16.err"; cut -c1-300 "$out/bench_vbf16.json"; tail -2 "$out/bench_vbf16.err";;
     bench_allbf16) timeout 300 python bench.py --no-cpu-baseline --value-storage bf16 --gemm bf16 > "$out/bench_allbf16.json" 2> "$out/bench_allbf16.err"; cut -c1-300 "$out/bench_allbf16.json"; tail -2 "$out/bench_allbf16.err";;
-    bench_lds) timeout 300 python bench.py --no-cpu-baseline --sca-lds on > "$out/bench_lds.json" 2> "$out/bench_lds.err"; cut -c1-300 "$out/bench_lds.json"; tail -2 "$out/bench_lds.err";;
     bench_eager) timeout 300 python bench.py --no-cpu-baseline --graph off > "$out/bench_eager.json" 2> "$out/bench_eager.err"; cut -c1-300 "$out/bench_eager.json"; tail -2 "$out/bench_eager.err";;
     bench_image) timeout 300 python bench.py --no-cpu-baseline --row-order image > "$out/bench_image.json" 2> "$out/bench_image.err"; cat "$out/bench_image.json";;
     bench_raster) timeout 300 python bench.py --no-cpu-baseline --row-order raster > "$out/bench_raster.json" 2> "$out/bench_raster.err"; cat "$out/bench_raster.json";;

@@ -1,12 +1,13 @@
-"""Phase clocks of the grad_value sort kernel (BEVMSDA_GV_PROFILE hook of the library): where a workgroup's
+"""Phase clocks of the grad_value sort kernel (bevmsda_tuning.reserved[1..2] of the library): where a workgroup's
 time goes, summed over workgroups (lane 0 of each).  Runs on the GPU box."""
+import ctypes
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bevformer_amd import ext  # noqa: E402
+from bevformer_amd import _lib, ext  # noqa: E402
 from bevformer_amd.synthetic import make_sca_msda_case, make_tsa_msda_case  # noqa: E402
 
 DEV = "cuda:0"
@@ -34,10 +35,10 @@ for case, (v, sh, st, loc, attn, *_) in (("sca_raster", make_sca_msda_case("base
     gl = torch.empty_like(locd)
     ga = torch.empty_like(attnd)
     prof = torch.zeros(8, dtype=torch.int64, device=DEV)
-    os.environ["BEVMSDA_GV_PROFILE"] = hex(prof.data_ptr())
-    ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga)
+    tun = _lib.Tuning()
+    tun.reserved[1], tun.reserved[2] = ctypes.c_int32(prof.data_ptr() & 0xffffffff).value, ctypes.c_int32(prof.data_ptr() >> 32).value
+    ext.ms_deform_attn_backward(vd, shd, std, locd, attnd, g, gv, gl, ga, tuning=ctypes.byref(tun))
     torch.cuda.synchronize()
-    del os.environ["BEVMSDA_GV_PROFILE"]
     p = prof.cpu().tolist()
     tot = sum(p)
     print(case, "total clocks (sum over workgroups)", tot)
