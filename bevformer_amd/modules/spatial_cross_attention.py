@@ -300,7 +300,7 @@ class SpatialCrossAttention(BaseModule):
                                              spatial_shapes, level_start_index)
             qr = frame_plan.q_rows if frame_plan is not None and not frame_plan.dynamic else None
             if qr is not None and out_rows.is_cuda and out_rows.dtype == torch.float32 and qr.shape[0] == bs * Q \
-                    and ops._FUSED_TRAIN["enabled"] and C % 4 == 0 and out_rows.shape[0] > 0:
+                    and ops.modes().fused_train and C % 4 == 0 and out_rows.shape[0] > 0:
                 # camera sum + division by the camera count as one gather kernel (its backward is a gather too)
                 slots = ops.gather_mean_autograd(out_rows, qr, inv_count, row_query).view(bs, Q, C)
             else:

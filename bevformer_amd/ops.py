@@ -68,6 +68,11 @@ def value_storage():
     return _m().value_storage
 
 
+def modes():
+    """The modes of this call (read-only use; edit through ``using`` or the ``set_*`` functions)."""
+    return _m()
+
+
 def using(**overrides):
     """``with ops.using(gemm="bf16", value_storage=torch.bfloat16): ...`` — modes for the calling thread only
     (``bevformer_amd.modes.using``); the ``set_*`` functions below edit the process-wide defaults instead."""
@@ -303,7 +308,7 @@ class _FusedSampleFunction(Function):
         ctx.save_for_backward(vs, proj, shapes, start, ref.float().contiguous(),
                               row_batch if row_batch is not None else shapes.new_empty(0),
                               row_src if row_src is not None else shapes.new_empty(0))
-        ctx.n_off, ctx.meta = n_off, meta
+        ctx.n_off, ctx.meta, ctx.tag = n_off, meta, tag
         ctx.store = _m().value_storage     # the value storage the forward sampled (bf16: rounded copy of `value`)
         ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
         return out
@@ -346,16 +351,22 @@ class _FusedSampleFunction(Function):
             gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
             gl = torch.empty_like(loc)
             ga = torch.empty_like(attn)
-            if row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
-                # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
-                # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
-                _lib.check((lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
-                    _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
-                    _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
-            else:
-                _lib.check((lib.bevmsda_backward_ragged_bf16 if bf else lib.bevmsda_backward_ragged_f32)(
-                    _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
-                    RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
+            # algorithmic bytes of the operator's backward: value + locations + weights + grad_out read,
+            # grad_value + grad_loc + grad_attn written
+            cb = _TIMER["cb"]
+            alg = value.numel() * value.element_size() + RK * M * L * P * 12 + RK * M * D * g.element_size() \
+                + value.numel() * 4 + RK * M * L * P * 12
+            with (cb(ctx.tag.replace("_fwd", "") + "_bwd", alg) if cb is not None else _NoTimer()):
+                if row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
+                    # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
+                    # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
+                    _lib.check((lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
+                        _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
+                        _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
+                else:
+                    _lib.check((lib.bevmsda_backward_ragged_bf16 if bf else lib.bevmsda_backward_ragged_f32)(
+                        _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
+                        RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
             qr = ctx.q_rows
             rc = _lib.ERR_UNSUPPORTED
             if row_src is not None and qr is not None and K == 1 and qr.shape[0] == proj.shape[0]:

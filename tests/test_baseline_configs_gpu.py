@@ -183,8 +183,9 @@ def _gradient_case(name, storage, l2_tol, max_tol):
 
 # bounds = 3 x the worst per-tensor error measured on the GPU box (profiles/r3/r3c_gradient_errors.log); the float32 CPU
 # oracle is itself 2e-3 (d query) / 6e-3 (worst parameter) away from a float64 evaluation (profiles/r2/train_fwd_table.txt)
-GRAD_TOL = {("small4", torch.float32): (1e-2, 0.1), ("small4", torch.bfloat16): (5e-2, 0.3),
-            ("base1", torch.float32): (1e-2, 0.1), ("base1", torch.bfloat16): (5e-2, 0.3)}
+# measured (r3c): small4 fp32 5.1e-3 / 4.6e-2, small4 bf16 3.1e-2 / 9.0e-2, base1 fp32 2.0e-3 / 2.9e-2, base1 bf16 2.0e-2 / 5.0e-2
+GRAD_TOL = {("small4", torch.float32): (1e-2, 0.1), ("small4", torch.bfloat16): (5e-2, 0.27),
+            ("base1", torch.float32): (6e-3, 0.09), ("base1", torch.bfloat16): (5e-2, 0.15)}
 
 
 @pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])

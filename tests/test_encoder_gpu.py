@@ -109,17 +109,13 @@ def test_encoder_backward(temporal, fwd_mfma):
     queries; one flipped slope among 120 queries weighs more (measured here: 1.1e-2 on the
     sampling-offset weights of layer 1)."""
     from bevformer_amd import ops
-    saved = ops._GEMM["train_forward_mfma"]
-    ops._GEMM["train_forward_mfma"] = fwd_mfma
-    try:
+    with ops.using(train_forward_mfma=fwd_mfma):
         enc, sd = build_pair("micro4", device=DEV)
         q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
         qd, fd = q.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
         out = enc(qd, fd, fd, **_to_dev(kw))
         gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
-        out.backward(gout.to(DEV))
-    finally:
-        ops._GEMM["train_forward_mfma"] = saved
+        out.backward(gout.to(DEV))        # (the engine's thread sees the forward's modes: ops._forward_modes)
 
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     qc, fc = q.clone().requires_grad_(True), f.clone().requires_grad_(True)

@@ -68,6 +68,6 @@ saved = ops.gemm_mode()
 for label, mode, fwd in (("forward GEMMs library fp32", "split", False), ("forward GEMMs split-bf16 MFMA", "split", True),
                          ("forward GEMMs 1-product bf16 MFMA", "bf16", True), ("all GEMMs library fp32 (native)", "native", False)):
     ops.set_gemm_mode(mode)
-    ops._GEMM["train_forward_mfma"] = fwd
-    row(label, *package(), ref_out, ref_g)
+    with ops.using(train_forward_mfma=fwd):
+        row(label, *package(), ref_out, ref_g)
 ops.set_gemm_mode(saved)
