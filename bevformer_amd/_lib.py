@@ -49,6 +49,13 @@ class LayerNormDesc(ctypes.Structure):
                 ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("reserved", ctypes.c_int32 * 3)]
 
 
+class ChainDesc(ctypes.Structure):
+    """Mirror of ``struct bevmsda_chain_desc``."""
+    _fields_ = [("M", ctypes.c_int64), ("ld_rows", ctypes.c_int64), ("ld_res", ctypes.c_int64), ("ld_y", ctypes.c_int64),
+                ("C", ctypes.c_int32), ("F", ctypes.c_int32), ("precision", ctypes.c_int32), ("eps0", ctypes.c_float),
+                ("eps1", ctypes.c_float), ("reserved", ctypes.c_int32 * 5)]
+
+
 class PlanDesc(ctypes.Structure):
     """Mirror of ``struct bevmsda_plan_desc``."""
     _fields_ = [("B", ctypes.c_int32), ("Nc", ctypes.c_int32), ("Q", ctypes.c_int32),
@@ -110,6 +117,7 @@ SIGNATURES = {
                                              _c_int),
     "bevmsda_linear_panel_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
                                                   _c_void_p, _c_void_p], _c_int),
+    "bevmsda_proj_ffn_chain_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,
                                   _c_void_p, ctypes.c_int64, _c_void_p, _c_int, _c_void_p], _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),

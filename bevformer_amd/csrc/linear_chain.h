@@ -1,0 +1,346 @@
+// The row-local tail of an encoder layer as ONE kernel (K3c):
+//
+//     x = LayerNorm0( A W0^T + b0 + res )                 output projection of the attention + "+ identity" + norm
+//     y = LayerNorm1( x + relu(x W1^T + b1) W2^T + b2 )   FFN (256 -> 512 -> 256) + "+ identity" + norm
+//
+// i.e. SpatialCrossAttention's `output_proj` and residual (spatial_cross_attention.py:165-175, with the per-camera
+// scatter-add and camera-count division as a two-row gather in the A-load), `norms[1]`, the mmcv FFN and `norms[2]` of
+// BEVFormerLayer's operation order (encoder.py:376-404).  Every one of those ops is local to a BEV row, so a workgroup
+// that owns a panel of 64 complete rows can run the whole chain without the grid ever leaving the chip: as separate
+// launches the chain moves ~10 passes of the (Q, 256) grid through HBM (x written and read twice, the 512-wide hidden
+// layer written and read), here it reads the sampled rows and the residual and writes y — 3.15 passes.
+//
+// Built from the row-panel kernel's parts (linear_panel.h): the panel is fetched whole by LDS-DMA and split once into
+// [hi | lo] bf16 planes; weight fragments come straight from L2 in MFMA operand order; 8 wavefronts, each owning ONE
+// 32-column tile of every stage's output (N = 256 = 8 x 32 for all of them once the hidden layer is taken in two halves
+// of 256), so there is no column loop and the accumulators of a stage ARE the rows the next stage needs:
+//
+//   stage 0   planes(A) in buffer 0  ->  acc = A W0^T; + b0 + res; LayerNorm0 (row statistics exchanged through LDS)
+//             -> x kept in registers (fp32: the FFN's residual) and written as planes into buffer 1
+//   half h    acc = x W1[256h .. 256h+255]^T; + b1, relu -> planes into buffer 0      (the hidden layer never exists
+//             acc2 += h_half W2[:, 256h ..]^T                                          beyond one 64 x 256 half in LDS)
+//   final     acc2 + b2 + x -> LayerNorm1 -> y
+//
+// LDS: 2 x 64 KiB plane buffers + 2 KiB of row statistics: one workgroup (512 threads, 2 wavefronts per SIMD) per CU.
+// The accumulator -> plane write uses the same slot map the DMA + split pass produces, so the fragment reads of every
+// stage are the conflict-free ones of linear_panel.h (tests/test_linear_layout_model.py replays the arithmetic).
+#pragma once
+#include "linear_panel.h"
+
+namespace bevmsda {
+
+struct ChainArgs {
+  const float *rows;                // A source rows (ld_rows); with gidx: gathered (two rows per output row)
+  long ld_rows;
+  const int32_t *gidx;              // (M, 2) or nullptr: A[m] = rows[m]
+  const float *gscale;
+  const uint16_t *w0, *w1, *w2;     // fragment-order weight images: (256, 256), (512, 256), (256, 512)
+  const float *b0, *b1, *b2;
+  const float *res;                 // (M, ld_res) residual of stage 0, or nullptr
+  long ld_res;
+  const float *gamma0, *beta0, *gamma1, *beta1;
+  float eps0, eps1;
+  float *y;
+  long ld_y;
+  long M;
+};
+
+constexpr int kChainRows = 64;      // rows per workgroup
+constexpr int kChainWaves = 8;      // wavefronts = 32-column tiles per stage
+constexpr int kChainC = 256, kChainF = 512;
+
+template <int NPROD, int PRE>
+__global__ void __launch_bounds__(kChainWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+linear_chain_kernel(const ChainArgs a) {
+  static_assert(NPROD == 1 || NPROD == 3, "NPROD");
+  static_assert(PRE == 0 || PRE == 2, "PRE: 0 plain rows, 2 two-row gather");
+  constexpr bool LO = NPROD == 3;
+  constexpr int NPL = LO ? 2 : 1;
+  constexpr int MT = 2, NW = kChainWaves, BM = kChainRows;
+  constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: 64 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4];
+  unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
+  float *const stat = reinterpret_cast<float *>(lds + 2 * BUF);       // [wave][row]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long m0 = static_cast<long>(blockIdx.x) * BM;
+
+  // fragment read addresses (linear_panel.h)
+  const int f_r = lane & 31, f_h = lane >> 5;
+  const int f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1);
+  const int f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1);
+  const int f_x = f_r & 7;
+  unsigned f_addr[4];
+#pragma unroll
+  for (int sc = 0; sc < 4; ++sc)
+    f_addr[sc] = static_cast<unsigned>(f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * sc + f_h) ^ f_x))) * 16);
+  // accumulator -> plane write addresses: this lane's value (row i * 32 + f_r, column 32 w + 4 f_h + 8 g + e) is
+  // k = that column of the next stage: line w (pair w >> 1, slot half w & 1), 16-byte column c = f_h + 2 g
+  unsigned p_addr[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    p_addr[g] = static_cast<unsigned>((f_q0 * 4 + (wave >> 1)) * 2048 + (f_rl * 8 + ((f_h + 2 * g) ^ f_x)) * 16 + (wave & 1) * 8);
+
+  const int wlane = lane * 16;
+  lin_f32x16 acc[MT], xk[MT], acc2[MT];
+
+  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256)
+  auto gemm16 = [&](lin_f32x16 (&c)[MT], const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
+    lin_bf16x8 wf[3][NPL], af[2][MT][NPL];
+    auto wload = [&](int st, int sg) {
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        wf[st][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        wrsrc, wlane, ((T32 * nstep + sg) * 2 + pl) * 1024, 0));
+    };
+    auto aload = [&](int set, int s) {
+      const unsigned base = f_addr[s & 3] + (s >> 2) * 2048;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          af[set][i][pl] = *reinterpret_cast<const lin_bf16x8 *>(buf + base + i * (4 * 4 * 2048) + pl * 1024);
+    };
+    wload(0, sg0);
+    wload(1, sg0 + 1);
+    aload(0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 2 < 16) wload((s + 2) % 3, sg0 + s + 2);
+      if (s + 1 < 16) aload((s + 1) & 1, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (LO) {
+          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][0], af[s & 1][i][1], c[i], 0, 0, 0);
+          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][1], af[s & 1][i][0], c[i], 0, 0, 0);
+        }
+        c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][0], af[s & 1][i][0], c[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto zero = [&](lin_f32x16 (&c)[MT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+  };
+  // the tile as [hi | lo] planes of the next stage's activation panel
+  auto to_planes = [&](const lin_f32x16 (&c)[MT], unsigned char *buf) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = c[i][4 * g], v1 = c[i][4 * g + 1], v2 = c[i][4 * g + 2], v3 = c[i][4 * g + 3];
+        uint2 hi, lo;
+        hi.x = lin_pack2(v0, v1);
+        hi.y = lin_pack2(v2, v3);
+        unsigned char *dst = buf + p_addr[g] + i * (4 * 4 * 2048);
+        *reinterpret_cast<uint2 *>(dst) = hi;
+        if (LO) {
+          lo.x = lin_pack2(v0 - __uint_as_float(hi.x << 16), v1 - __uint_as_float(hi.x & 0xffff0000u));
+          lo.y = lin_pack2(v2 - __uint_as_float(hi.y << 16), v3 - __uint_as_float(hi.y & 0xffff0000u));
+          *reinterpret_cast<uint2 *>(dst + 1024) = lo;
+        }
+      }
+  };
+  // LayerNorm over the 256 columns of every row of the tile set (8 wavefronts x 32 columns), in place; two-pass
+  // statistics, exchanged through LDS (torch.nn.LayerNorm: biased variance, eps inside the square root)
+  auto layernorm = [&](lin_f32x16 (&c)[MT], const float *gamma, const float *beta, float eps) {
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += c[i][r];
+      sum += __shfl_xor(sum, 32, 64);
+      mean[i] = sum;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) stat[wave * BM + i * 32 + lane] = mean[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
+      mean[i] = t * (1.0f / kChainC);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = c[i][r] - mean[i];
+        ss = fmaf(d, d, ss);
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rstd[i] = ss;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) stat[wave * BM + i * 32 + lane] = rstd[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
+      rstd[i] = rsqrtf(t * (1.0f / kChainC) + eps);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = wave * 32 + 4 * (lane >> 5) + 8 * g;
+        const float4 ga = *reinterpret_cast<const float4 *>(gamma + n);
+        const float4 be = *reinterpret_cast<const float4 *>(beta + n);
+        c[i][4 * g] = (c[i][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
+        c[i][4 * g + 1] = (c[i][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
+        c[i][4 * g + 2] = (c[i][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
+        c[i][4 * g + 3] = (c[i][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
+      }
+    }
+    __syncthreads();                           // `stat` may be written again
+  };
+
+  // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
+  {
+    const int d_rl = lane >> 3, d_cc = lane & 7;
+    const int row = panel_row_of(wave, d_rl);  // 8 row blocks, one per wavefront; 4 line pairs each
+    const int cx = d_cc ^ (row & 7);
+    long gm = m0 + row;
+    if (gm >= a.M) gm = a.M - 1;               // clamped rows are computed and never stored
+    long srow = gm, arow = gm;
+    int g0 = 0, g1 = -1;
+    float gs = 1.f;
+    if (PRE == 2) {
+      g0 = a.gidx[gm * 2];
+      g1 = a.gidx[gm * 2 + 1];
+      gs = a.gscale[gm];
+      srow = g0 < 0 ? 0 : g0;
+      arow = g1 < 0 ? 0 : g1;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float *src = a.rows + srow * a.ld_rows + (2 * p) * 32 + cx * 4;
+      unsigned char *dst = buf0 + (wave * 4 + p) * 2048;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                       (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32),
+                                       (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+    }
+    float4 ad[PRE == 2 ? 4 : 1][2];
+    if (PRE == 2) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float *s1 = a.rows + arow * a.ld_rows + (2 * p) * 32 + cx * 4;
+        ad[PRE == 2 ? p : 0][0] = *reinterpret_cast<const float4 *>(s1);
+        ad[PRE == 2 ? p : 0][1] = *reinterpret_cast<const float4 *>(s1 + 32);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my own DMA slots have landed
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned char *slot = buf0 + (wave * 4 + p) * 2048 + lane * 16;
+      float4 va = *reinterpret_cast<const float4 *>(slot);
+      float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
+      if (PRE == 2) {
+        va = panel_gsum(va, g0 >= 0, ad[PRE == 2 ? p : 0][0], g1 >= 0, gs);
+        vb = panel_gsum(vb, g0 >= 0, ad[PRE == 2 ? p : 0][1], g1 >= 0, gs);
+      }
+      uint4 hi, lo;
+      lin_split8<LO>(va, vb, hi, lo);
+      *reinterpret_cast<uint4 *>(slot) = hi;
+      if (LO) *reinterpret_cast<uint4 *>(slot + 1024) = lo;
+    }
+  }
+  __syncthreads();
+
+  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = 16u * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
+  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w2), 0, static_cast<int>(w2b), 0x00020000);
+
+  // rows and columns of this lane's accumulator registers
+  const int ncol = wave * 32 + 4 * (lane >> 5);        // + 8 g + e
+  long mrow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) mrow[i] = m0 + i * 32 + (lane & 31);
+
+  // ------------------------------------------------------------------ stage 0: x = LN0(A W0^T + b0 + res)
+  zero(acc);
+  gemm16(acc, buf0, r0, wave, 16, 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const bool mok = mrow[i] < a.M;
+    const float *rrow = a.res ? a.res + (mok ? mrow[i] : 0) * a.ld_res : nullptr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol + 8 * g;
+      float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+      if (a.b0) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b0 + n));
+      if (rrow) v = lin_add4(v, *reinterpret_cast<const float4 *>(rrow + n));
+      acc[i][4 * g] = v.x; acc[i][4 * g + 1] = v.y; acc[i][4 * g + 2] = v.z; acc[i][4 * g + 3] = v.w;
+    }
+  }
+  layernorm(acc, a.gamma0, a.beta0, a.eps0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) xk[i] = acc[i];
+  to_planes(xk, buf1);
+  __syncthreads();                             // x planes complete (and every wavefront is done with buffer 0)
+
+  // ------------------------------------------------------------------ FFN, the hidden layer in two halves of 256
+  zero(acc2);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    zero(acc);
+    gemm16(acc, buf1, r1, half * 8 + wave, 16, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = half * 256 + ncol + 8 * g;
+        float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        if (a.b1) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b1 + n));
+        acc[i][4 * g] = v.x < 0.f ? 0.f : v.x;      // NaN stays NaN, as torch.relu
+        acc[i][4 * g + 1] = v.y < 0.f ? 0.f : v.y;
+        acc[i][4 * g + 2] = v.z < 0.f ? 0.f : v.z;
+        acc[i][4 * g + 3] = v.w < 0.f ? 0.f : v.w;
+      }
+    to_planes(acc, buf0);
+    __syncthreads();                           // this half of the hidden layer is complete
+    gemm16(acc2, buf0, r2, wave, 32, half * 16);
+    __syncthreads();                           // ... and consumed: buffer 0 may be rewritten
+  }
+
+  // ------------------------------------------------------------------ y = LN1(x + ffn(x))
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol + 8 * g;
+      float4 v = make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+      if (a.b2) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b2 + n));
+      acc2[i][4 * g] = v.x + xk[i][4 * g];
+      acc2[i][4 * g + 1] = v.y + xk[i][4 * g + 1];
+      acc2[i][4 * g + 2] = v.z + xk[i][4 * g + 2];
+      acc2[i][4 * g + 3] = v.w + xk[i][4 * g + 3];
+    }
+  layernorm(acc2, a.gamma1, a.beta1, a.eps1);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (mrow[i] >= a.M) continue;
+    float *yrow = a.y + mrow[i] * a.ld_y;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(yrow + ncol + 8 * g) =
+          make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+  }
+}
+
+}  // namespace bevmsda

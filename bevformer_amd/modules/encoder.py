@@ -292,8 +292,29 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             """The LayerNorm the step at ``i`` may fold into its last projection (inference fast path)."""
             return self.norms[norm_i] if (fuse_norm and _defer(i)) else None
 
+        def _chain(i):
+            """cross_attn at ``i`` followed by norm, ffn, norm (the reference's order): a callable that runs the rest
+            of the layer — output projection, "+ identity", norm, FFN, "+ identity", norm — in one kernel."""
+            if not fuse_norm or tuple(order[i + 1:i + 4]) != ("norm", "ffn", "norm") or ffn_i >= len(self.ffns):
+                return None
+            ffn, n0, n1 = self.ffns[ffn_i], self.norms[norm_i], self.norms[norm_i + 1]
+            if not isinstance(ffn, FFN) or ffn.num_fcs != 2 or not ffn.add_identity \
+                    or not isinstance(n0, torch.nn.LayerNorm) or not isinstance(n1, torch.nn.LayerNorm):
+                return None
+            fc1, fc2 = ffn.layers[0][0], ffn.layers[-2]
+            return lambda rows, w, b, res, post_norm, gather: ops.proj_ffn_chain(
+                rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain") if post_norm is n0 else None
+
         skip_norm = False                       # the previous step returned ops.Normed
+        skip_ops = 0                            # steps already applied by a chained kernel (ops.Chained)
         for i, op in enumerate(order):
+            if skip_ops:
+                skip_ops -= 1
+                if op == "norm":
+                    norm_i += 1
+                elif op == "ffn":
+                    ffn_i += 1
+                continue
             if op == "self_attn":
                 query = self.attentions[attn_i](
                     query, prev_bev, prev_bev, identity if self.pre_norm else None,
@@ -331,9 +352,12 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     reference_points_cam=reference_points_cam, mask=mask,
                     attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
                     spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                    frame_plan=frame_plan, defer_residual=_defer(i), post_norm=_post_norm(i), **kwargs)
+                    frame_plan=frame_plan, defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain(i), **kwargs)
                 attn_i += 1
-                if isinstance(query, ops.Normed):
+                if isinstance(query, ops.Chained):
+                    query, skip_ops = query.t, 3
+                    identity = query
+                elif isinstance(query, ops.Normed):
                     query, skip_norm = query.t, True
                 elif isinstance(query, tuple):
                     pending, query = query, None

@@ -217,7 +217,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
-                projected_value=None, defer_residual=False, post_norm=None, **kwargs):
+                projected_value=None, defer_residual=False, post_norm=None, chain=None, **kwargs):
         """query (bs, Q, C); key/value (Nc, S, bs, C); reference_points_cam
         (Nc, bs, Q, Dz, 2); bev_mask (Nc, bs, Q, Dz) -> (bs, Q, C).
 
@@ -266,6 +266,12 @@ class SpatialCrossAttention(BaseModule):
                     # slots seen by more than two cameras (rare; known to the device only): fold their
                     # third.. rows into the first so the two-row gather below sums all of them
                     ops.fold_extra_rows(out_rows, frame_plan.q_rows_all, frame_plan.n_extra_dev)
+                if post_norm is not None and chain is not None and not (self.training and self.dropout.p > 0):
+                    # ... and the FFN and its norm behind them: the whole row-local tail of the layer in one kernel
+                    done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
+                                 (frame_plan.q_rows, inv_count))
+                    if done is not None:
+                        return ops.Chained(done.view(bs, Q, C))
                 if post_norm is not None and not (self.training and self.dropout.p > 0):
                     # camera mean + output projection + "+ residual" + the layer's norm in one kernel
                     fused = ops.linear_layernorm(out_rows, self.output_proj.weight, self.output_proj.bias,

@@ -890,6 +890,87 @@ def linear_layernorm(x, weight, bias, res, norm, *, gather=None, tag="linear"):
     return None
 
 
+class Chained:
+    """Marks a module output to which the REST of the layer's row-local chain — "+ identity", norm, FFN,
+    "+ identity", norm — has already been applied (``proj_ffn_chain``): the layer skips those steps."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=None, tag="proj_ffn_chain"):
+    """``norm1(x + fc2(relu(fc1(x))))`` with ``x = norm0(linear(A, weight, bias) + res)`` in ONE kernel
+    (``bevmsda_proj_ffn_chain_f32``, csrc/linear_chain.h): the attention's output projection, "+ identity", the
+    layer's norm, the FFN, "+ identity" and the next norm — every op local to a BEV row.  A = ``rows`` or, with
+    ``gather = (idx (M, 2) int32, scale (M,))``, SpatialCrossAttention's camera mean over the rows.  ``fc1`` / ``fc2``:
+    the FFN's ``nn.Linear`` layers (256 -> 512 -> 256), ``norm0`` / ``norm1``: ``nn.LayerNorm(256)``.  Returns
+    ``None`` when not covered (the caller runs the steps one by one)."""
+    m = _m()
+    if not m.ln_fuse or m.gemm == "native" or not m.gemm_pack or m.gemm_variant is not None \
+            or m.gemm_kernel in ("first", "pipe") or not rows.is_cuda or rows.dtype != torch.float32:
+        return None
+    for norm in (norm0, norm1):
+        if not isinstance(norm, torch.nn.LayerNorm) or tuple(norm.normalized_shape) != (256,) or norm.weight is None \
+                or norm.bias is None:
+            return None
+    if not isinstance(fc1, torch.nn.Linear) or not isinstance(fc2, torch.nn.Linear) \
+            or tuple(weight.shape) != (256, 256) or tuple(fc1.weight.shape) != (512, 256) \
+            or tuple(fc2.weight.shape) != (256, 512) or fc1.bias is None or fc2.bias is None \
+            or not fused_wanted(rows, weight, bias, res, fc1.weight, fc2.weight, norm0.weight, norm1.weight):
+        return None
+    x0, ldx = _rows2d(rows, 256) if rows.shape[-1] == 256 else (None, 0)
+    if x0 is None:
+        return None
+    idx = scale = None
+    if gather is not None:
+        idx, scale = gather
+        if idx.dim() != 2 or idx.shape[1] != 2 or idx.dtype != torch.int32:
+            return None
+        idx = idx.contiguous()
+        scale = scale.reshape(-1).float().contiguous()
+        M = idx.shape[0]
+        if scale.numel() != M:
+            return None
+    else:
+        M = x0.shape[0]
+    r2, ldres = None, 0
+    if res is not None:
+        if res.dtype != torch.float32 or res.shape[-1] != 256 or res.numel() != M * 256:
+            return None
+        r2, ldres = _rows2d(res, 256)
+    lead = res.shape[:-1] if res is not None else (M,)
+    ws = []
+    for w in (weight, fc1.weight, fc2.weight):
+        w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
+        blob = panel_weight(w)
+        if blob is None:
+            return None
+        ws.append(blob)
+    y = torch.empty((M, 256), dtype=torch.float32, device=rows.device)
+    if M == 0:
+        return y.view(*lead, 256)
+    desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=512, precision=0 if m.gemm == "split" else 1,
+                          eps0=float(norm0.eps), eps1=float(norm1.eps))
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    flops = 2.0 * M * (256 * 256 + 2 * 256 * 512)
+    nbytes = 4.0 * ((min(x0.shape[0], 2 * M) if gather is not None else M) * 256 + M * 256 * (2 if res is not None else 1)
+                    + 256 * 256 + 2 * 256 * 512)
+    ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
+    p = lambda t: _ptr(t) if t is not None else None
+    bc = lambda t: t.contiguous() if t is not None else None
+    with torch.cuda.device(rows.device), ctx:
+        rc = lib.bevmsda_proj_ffn_chain_f32(
+            _ptr(x0), p(idx), p(scale), _ptr(ws[0]), p(bc(bias)), p(r2), _ptr(norm0.weight), _ptr(norm0.bias),
+            _ptr(ws[1]), p(bc(fc1.bias)), _ptr(ws[2]), p(bc(fc2.bias)), _ptr(norm1.weight), _ptr(norm1.bias),
+            ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "proj_ffn_chain")
+    return y.view(*lead, 256)
+
+
 def transposed_weight(weight):
     """Contiguous ``weight.t()`` cached on the tensor until it is written to: the operand of the
     input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""

@@ -397,6 +397,33 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
                              const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,
                              void *stream);
 
+/* The row-local tail of an encoder layer in one kernel (csrc/linear_chain.h):
+ *     x = LayerNorm0(A w0^T + b0 + res)                          attention output projection, "+ identity", norm
+ *     y = LayerNorm1(x + relu(x w1^T + b1) w2^T + b2)            FFN (C -> F -> C), "+ identity", norm
+ * = SpatialCrossAttention's `output_proj` + residual (spatial_cross_attention.py:165-175; with idx / scale the
+ * per-camera scatter-add and camera-count division as a two-row gather: A[m] = scale[m] * (rows[idx[m, 0]] +
+ * rows[idx[m, 1]]), -1 = absent), `norms[1]`, the FFN and `norms[2]` of BEVFormerLayer's operation order
+ * (encoder.py:376-404).  A workgroup owns 64 complete rows; x and the hidden layer never leave the chip.
+ * w0p / w1p / w2p: bevmsda_linear_panel_pack_weight_f32 images of (C, C), (F, C), (C, F).  Supported: C = 256,
+ * F = 512; row strides multiples of 4, every pointer 16-byte aligned; else BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and
+ * the caller runs the three launches (bevmsda_linear_panel_f32 x 2 with LayerNorm descriptors + the first Linear).
+ * Arithmetic as bevmsda_linear_panel_f32 (precision 0: three bf16 MFMAs per fp32 product; x and the hidden
+ * activations are re-split from their fp32 values exactly as a separate launch would split them: same results as the
+ * three-launch sequence to fp32 summation order). */
+typedef struct bevmsda_chain_desc {
+  int64_t M;                     /* rows of y */
+  int64_t ld_rows, ld_res, ld_y; /* row strides in floats */
+  int32_t C, F;                  /* embedding and hidden width */
+  int32_t precision;             /* as bevmsda_linear_desc */
+  float eps0, eps1;
+  int32_t reserved[5];
+} bevmsda_chain_desc;
+
+int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                               const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                               const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
+                               const bevmsda_chain_desc *desc, float *y, void *stream);
+
 /* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
  *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)
  * g (M, ldg) = gradient w.r.t. the layer's output (N columns), x (M, ldx) = the layer's input (K columns).

@@ -432,3 +432,49 @@ def test_linear_row_panel_layernorm_and_gather(gemm_mode, kernel):
     torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5)
     want5 = torch.nn.functional.layer_norm(lin5.double() + res.double(), (256,), norm.weight.double(), norm.bias.double(), norm.eps)
     torch.testing.assert_close(got5.double(), want5, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+@pytest.mark.parametrize("M,with_gather", [(641, True), (4099, False), (64, True), (1, False)])
+def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, with_gather):
+    """``bevmsda_proj_ffn_chain_f32`` (csrc/linear_chain.h): output projection (+ camera gather) + residual + LayerNorm
+    + FFN + residual + LayerNorm in one kernel against the same chain as three launches of the row-panel kernel (the
+    intermediate x and hidden activations are split from the same fp32 values: differences come from the order of the
+    LayerNorm statistics only) and against the fp64 statement."""
+    gemm_mode(mode)
+    g = torch.Generator().manual_seed(M)
+    R = max(M + 37, 100)
+    rows = _rand(R, 256, seed=81)
+    idx = scale = None
+    if with_gather:
+        idx = torch.randint(0, R, (M, 2), generator=g, dtype=torch.int32)
+        idx[torch.rand(M, generator=g) < 0.6, 1] = -1
+        idx[:3] = -1
+        scale = (1.0 / (idx >= 0).sum(1).clamp(min=1).float()).to(DEV)
+        idx = idx.to(DEV)
+    w0, b0, res = _rand(256, 256, seed=82) / 16, _rand(256, seed=83) * 0.1, _rand(M, 256, seed=84)
+    fc1, fc2 = torch.nn.Linear(256, 512).to(DEV), torch.nn.Linear(512, 256).to(DEV)
+    n0, n1 = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        for n, s in ((n0, 85), (n1, 87)):
+            n.weight.copy_(_rand(256, seed=s) * 0.2 + 1.0)
+            n.bias.copy_(_rand(256, seed=s + 1) * 0.1)
+        gather = (idx, scale) if with_gather else None
+        src = rows if with_gather else rows[:M]
+        with ops.using(ln_fuse=True, gemm_kernel="panel64"):
+            got = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather)
+            x = ops.linear_layernorm(src, w0, b0, res, n0, gather=gather)
+            h = ops.linear(x, fc1.weight, fc1.bias, relu=True)
+            want = ops.linear_layernorm(h, fc2.weight, fc2.bias, x, n1)
+        assert got is not None and x is not None and want is not None and got.shape == (M, 256)
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+        # fp64 statement
+        a = src.double() if not with_gather else sum(
+            torch.where((idx[:, j] >= 0)[:, None], rows.double()[idx[:, j].clamp(min=0).long()], torch.zeros(1, dtype=torch.float64, device=DEV))
+            for j in range(2)) * scale.double()[:, None]
+        ln = torch.nn.functional.layer_norm
+        x64 = ln(a @ w0.double().t() + b0.double() + res.double(), (256,), n0.weight.double(), n0.bias.double(), n0.eps)
+        y64 = ln(x64 + torch.relu(x64 @ fc1.weight.double().t() + fc1.bias.double()) @ fc2.weight.double().t() + fc2.bias.double(),
+                 (256,), n1.weight.double(), n1.bias.double(), n1.eps)
+    tol = 2e-4 if mode == "split" else 5e-2
+    torch.testing.assert_close(got.double(), y64, rtol=tol, atol=tol)

@@ -323,3 +323,52 @@ def test_panel_lds_image_is_conflict_free_for_b128_fragment_reads():
                 for d in range(4):
                     banks.add((byte // 4 + d) % 64)
             assert len(banks) == 64, (s, g)
+
+
+def test_chain_kernel_plane_writes_feed_the_next_stage():
+    """csrc/linear_chain.h: a stage's output tile set (8 wavefronts x 64 x 32 in MFMA accumulator layout: lane holds
+    row i * 32 + (lane & 31), columns 32 w + 4 (lane >> 5) + 8 g + e in register 4 g + e) is written straight into the
+    plane buffer (``p_addr``); the next stage's fragment reads (``f_addr``, as in the row-panel kernel) and the
+    fragment-order weight image must then reproduce x @ w.T — i.e. the register -> slot map is the one the DMA + split
+    pass of linear_panel.h produces."""
+    rng = np.random.default_rng(3)
+    BM, NW = 64, 8
+    x = rng.standard_normal((BM, 256))
+    w = rng.standard_normal((256, 256))
+    lds = np.full(32 * 2048 // 2, np.nan)                      # hi planes only, one entry per bf16 element (2 bytes)
+    for wave in range(NW):
+        for lane in range(64):
+            f_r, f_h = lane & 31, lane >> 5
+            f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1)
+            f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1)
+            f_x = f_r & 7
+            for i in range(2):
+                for g in range(4):
+                    byte = (f_q0 * 4 + (wave >> 1)) * 2048 + (f_rl * 8 + ((f_h + 2 * g) ^ f_x)) * 16 + (wave & 1) * 8 \
+                        + i * (4 * 4 * 2048)
+                    assert byte % 8 == 0 and (byte % 2048) < 1024       # hi half of the pair
+                    row, col = i * 32 + f_r, 32 * wave + 4 * f_h + 8 * g
+                    assert np.isnan(lds[byte // 2:byte // 2 + 4]).all()
+                    lds[byte // 2:byte // 2 + 4] = x[row, col:col + 4]
+    blob = _panel_pack_weight(w, 8)
+    got = np.zeros((BM, 256))
+    for wave in range(NW):
+        acc = np.zeros((2, 64, 16))
+        for s in range(16):
+            af = np.zeros((2, 64, 8))
+            for lane in range(64):
+                f_r, f_h = lane & 31, lane >> 5
+                f_q0 = ((f_r >> 2) & 1) | ((f_r >> 4) << 1)
+                f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1)
+                addr = f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * (s & 3)) + f_h) ^ (f_r & 7))) * 16 + (s >> 2) * 2048
+                for i in range(2):
+                    a = addr + i * (4 * 4 * 2048)
+                    af[i, lane] = lds[a // 2:a // 2 + 8]
+            assert not np.isnan(af).any()
+            for i in range(2):
+                acc[i] = _mfma_32x32x16(blob[wave, s], af[i], acc[i])
+        for lane in range(64):
+            for i in range(2):
+                for r in range(16):
+                    got[i * 32 + (lane & 31), 32 * wave + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3)] = acc[i, lane, r]
+    np.testing.assert_allclose(got, x @ w.T, rtol=1e-11, atol=1e-11)
