@@ -86,15 +86,23 @@ linear_chain_kernel(const ChainArgs a) {
   const int wlane = lane * 16;
   lin_f32x16 acc[MT], xk[MT], acc2[MT];
 
-  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256)
-  auto gemm16 = [&](lin_f32x16 (&c)[MT], const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
-    lin_bf16x8 wf[3][NPL], af[2][MT][NPL];
-    auto wload = [&](int st, int sg) {
+  lin_bf16x8 wf[3][NPL];                       // weight fragments: ring over k16 steps (two in flight)
+  auto wload = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int st, int sg) {
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
-        wf[st][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        wrsrc, wlane, ((T32 * nstep + sg) * 2 + pl) * 1024, 0));
-    };
+    for (int pl = 0; pl < NPL; ++pl)
+      wf[st][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      wrsrc, wlane, ((T32 * nstep + sg) * 2 + pl) * 1024, 0));
+  };
+  // the first two weight fragments of a stage, requested before the previous stage's epilogue / the barrier in front
+  // of it (an L2 round trip that would otherwise open every stage)
+  auto wprefetch = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
+    wload(wrsrc, T32, nstep, 0, sg0);
+    wload(wrsrc, T32, nstep, 1, sg0 + 1);
+  };
+  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256); ring stages 0, 1 hold
+  // steps sg0, sg0 + 1 already (wprefetch)
+  auto gemm16 = [&](lin_f32x16 (&c)[MT], const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
+    lin_bf16x8 af[2][MT][NPL];
     auto aload = [&](int set, int s) {
       const unsigned base = f_addr[s & 3] + (s >> 2) * 2048;
 #pragma unroll
@@ -103,12 +111,10 @@ linear_chain_kernel(const ChainArgs a) {
         for (int pl = 0; pl < NPL; ++pl)
           af[set][i][pl] = *reinterpret_cast<const lin_bf16x8 *>(buf + base + i * (4 * 4 * 2048) + pl * 1024);
     };
-    wload(0, sg0);
-    wload(1, sg0 + 1);
     aload(0, 0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      if (s + 2 < 16) wload((s + 2) % 3, sg0 + s + 2);
+      if (s + 2 < 16) wload(wrsrc, T32, nstep, (s + 2) % 3, sg0 + s + 2);
       if (s + 1 < 16) aload((s + 1) & 1, s + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -208,6 +214,27 @@ linear_chain_kernel(const ChainArgs a) {
     __syncthreads();                           // `stat` may be written again
   };
 
+  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = 16u * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
+  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w2), 0, static_cast<int>(w2b), 0x00020000);
+
+  // rows and columns of this lane's accumulator registers
+  const int ncol = wave * 32 + 4 * (lane >> 5);        // + 8 g + e
+  long mrow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) mrow[i] = m0 + i * 32 + (lane & 31);
+  // the residual rows of stage 0 and its first weight fragments travel under the panel fetch
+  float4 rs[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const float *rrow = a.res ? a.res + (mrow[i] < a.M ? mrow[i] : a.M - 1) * a.ld_res : nullptr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      rs[i][g] = rrow ? *reinterpret_cast<const float4 *>(rrow + ncol + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  wprefetch(r0, wave, 16, 0);
+
   // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
   {
     const int d_rl = lane >> 3, d_cc = lane & 7;
@@ -261,30 +288,18 @@ linear_chain_kernel(const ChainArgs a) {
   }
   __syncthreads();
 
-  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = 16u * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
-  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
-  __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
-  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w2), 0, static_cast<int>(w2b), 0x00020000);
-
-  // rows and columns of this lane's accumulator registers
-  const int ncol = wave * 32 + 4 * (lane >> 5);        // + 8 g + e
-  long mrow[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) mrow[i] = m0 + i * 32 + (lane & 31);
-
   // ------------------------------------------------------------------ stage 0: x = LN0(A W0^T + b0 + res)
   zero(acc);
   gemm16(acc, buf0, r0, wave, 16, 0);
+  wprefetch(r1, wave, 16, 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const bool mok = mrow[i] < a.M;
-    const float *rrow = a.res ? a.res + (mok ? mrow[i] : 0) * a.ld_res : nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = ncol + 8 * g;
       float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
       if (a.b0) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b0 + n));
-      if (rrow) v = lin_add4(v, *reinterpret_cast<const float4 *>(rrow + n));
+      v = lin_add4(v, rs[i][g]);
       acc[i][4 * g] = v.x; acc[i][4 * g + 1] = v.y; acc[i][4 * g + 2] = v.z; acc[i][4 * g + 3] = v.w;
     }
   }
@@ -300,6 +315,7 @@ linear_chain_kernel(const ChainArgs a) {
   for (int half = 0; half < 2; ++half) {
     zero(acc);
     gemm16(acc, buf1, r1, half * 8 + wave, 16, 0);
+    wprefetch(r2, wave, 32, half * 16);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -315,6 +331,7 @@ linear_chain_kernel(const ChainArgs a) {
     to_planes(acc, buf0);
     __syncthreads();                           // this half of the hidden layer is complete
     gemm16(acc2, buf0, r2, wave, 32, half * 16);
+    if (half == 0) wprefetch(r1, 8 + wave, 16, 0);
     __syncthreads();                           // ... and consumed: buffer 0 may be rewritten
   }
 

@@ -467,7 +467,9 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
             h = ops.linear(x, fc1.weight, fc1.bias, relu=True)
             want = ops.linear_layernorm(h, fc2.weight, fc2.bias, x, n1)
         assert got is not None and x is not None and want is not None and got.shape == (M, 256)
-        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+        # (bf16 operands: a last-bit difference of x flips its bf16 rounding for single elements)
+        t3 = 2e-5 if mode == "split" else 2e-2
+        torch.testing.assert_close(got, want, rtol=t3, atol=t3)
         # fp64 statement
         a = src.double() if not with_gather else sum(
             torch.where((idx[:, j] >= 0)[:, None], rows.double()[idx[:, j].clamp(min=0).long()], torch.zeros(1, dtype=torch.float64, device=DEV))
