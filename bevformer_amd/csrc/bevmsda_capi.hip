@@ -370,9 +370,11 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
     const dim3 hgrid(static_cast<unsigned>(((hnb + 7) / 8) * 8));
     const long rest = ((nb - hnb + 7) / 8) * 8;
     const dim3 tgrid(static_cast<unsigned>(rest < 8 ? 8 : (rest < kDynGridBlocks ? rest : kDynGridBlocks)));
+    if (d->reserved[4] < 0 || d->reserved[4] > 64) return BEVMSDA_ERR_BAD_OPTION;
+    const size_t dpad = static_cast<size_t>(d->reserved[4]) * 1024;     // occupancy cap of the head launch (see below)
 #define BEVMSDA_DYN(HEAD_, TAIL_)                                                                          \
   do {                                                                                                     \
-    if (hint > 0) hipLaunchKernelGGL(HEAD_, hgrid, dim3(256), 0, st, f);                                   \
+    if (hint > 0) hipLaunchKernelGGL(HEAD_, hgrid, dim3(256), dpad, st, f);                                \
     if (hint < d->R) hipLaunchKernelGGL(TAIL_, tgrid, dim3(256), 0, st, f);                                \
   } while (0)
     if constexpr (sizeof(T) == 2) {
@@ -417,8 +419,12 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
     }
   }
   const bool wide = d->reserved[0] ? d->reserved[0] == 4 : d->L > 1;     // 4 waves / SIMD: more taps in flight
+  // desc->reserved[4] = KiB of (unused) dynamic LDS requested per workgroup: an occupancy cap for co-scheduling
+  // experiments (tools/overlap_probe.py): 54 -> at most two workgroups of this kernel per CU, 80 -> one
+  if (d->reserved[4] < 0 || d->reserved[4] > 64) return BEVMSDA_ERR_BAD_OPTION;
+  const size_t pad = static_cast<size_t>(d->reserved[4]) * 1024;
   if (d->P == 8) {
-    if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), 0, st, f);
+    if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), pad, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 8>), grid, dim3(256), 0, st, f);
   } else if (d->K == 2) {
     if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4>), grid, dim3(256), 0, st, f);

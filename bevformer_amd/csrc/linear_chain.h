@@ -43,7 +43,22 @@ struct ChainArgs {
   float *y;
   long ld_y;
   long M;
+#ifdef BEVMSDA_CHAIN_PROF
+  unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
+#endif
 };
+#ifdef BEVMSDA_CHAIN_PROF
+#define CHAIN_STAMP(k)                                                           \
+  do {                                                                           \
+    if (tid == 0) {                                                              \
+      const unsigned long long now_ = __builtin_readcyclecounter();             \
+      atomicAdd(a.prof + (k), now_ - t_prev_);                                   \
+      t_prev_ = now_;                                                            \
+    }                                                                            \
+  } while (0)
+#else
+#define CHAIN_STAMP(k) do {} while (0)
+#endif
 
 constexpr int kChainRows = 64;      // rows per workgroup
 constexpr int kChainWaves = 8;      // wavefronts = 32-column tiles per stage
@@ -66,6 +81,9 @@ linear_chain_kernel(const ChainArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long m0 = static_cast<long>(blockIdx.x) * BM;
+#ifdef BEVMSDA_CHAIN_PROF
+  unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
 
   // fragment read addresses (linear_panel.h)
   const int f_r = lane & 31, f_h = lane >> 5;
@@ -86,21 +104,22 @@ linear_chain_kernel(const ChainArgs a) {
   const int wlane = lane * 16;
   lin_f32x16 acc[MT], xk[MT], acc2[MT];
 
-  lin_bf16x8 wf[3][NPL];                       // weight fragments: ring over k16 steps (two in flight)
+  constexpr int WD = 2;                        // weight fragments in flight (k16 steps ahead): 4 measured no faster: 122 vs 115-118 us
+  lin_bf16x8 wf[WD + 1][NPL];                  // ring over k16 steps
   auto wload = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int st, int sg) {
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
       wf[st][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                                       wrsrc, wlane, ((T32 * nstep + sg) * 2 + pl) * 1024, 0));
   };
-  // the first two weight fragments of a stage, requested before the previous stage's epilogue / the barrier in front
+  // the first WD weight fragments of a stage, requested before the previous stage's epilogue / the barrier in front
   // of it (an L2 round trip that would otherwise open every stage)
   auto wprefetch = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
-    wload(wrsrc, T32, nstep, 0, sg0);
-    wload(wrsrc, T32, nstep, 1, sg0 + 1);
+#pragma unroll
+    for (int k = 0; k < WD; ++k) wload(wrsrc, T32, nstep, k, sg0 + k);
   };
-  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256); ring stages 0, 1 hold
-  // steps sg0, sg0 + 1 already (wprefetch)
+  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256); ring stages 0 .. WD - 1 hold
+  // steps sg0 .. sg0 + WD - 1 already (wprefetch)
   auto gemm16 = [&](lin_f32x16 (&c)[MT], const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
     lin_bf16x8 af[2][MT][NPL];
     auto aload = [&](int set, int s) {
@@ -114,16 +133,16 @@ linear_chain_kernel(const ChainArgs a) {
     aload(0, 0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      if (s + 2 < 16) wload(wrsrc, T32, nstep, (s + 2) % 3, sg0 + s + 2);
+      if (s + WD < 16) wload(wrsrc, T32, nstep, (s + WD) % (WD + 1), sg0 + s + WD);
       if (s + 1 < 16) aload((s + 1) & 1, s + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if (LO) {
-          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][0], af[s & 1][i][1], c[i], 0, 0, 0);
-          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][1], af[s & 1][i][0], c[i], 0, 0, 0);
+          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][0], af[s & 1][i][1], c[i], 0, 0, 0);
+          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][1], af[s & 1][i][0], c[i], 0, 0, 0);
         }
-        c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][0], af[s & 1][i][0], c[i], 0, 0, 0);
+        c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][0], af[s & 1][i][0], c[i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -287,10 +306,12 @@ linear_chain_kernel(const ChainArgs a) {
     }
   }
   __syncthreads();
+  CHAIN_STAMP(0);                              // panel fetch + split
 
   // ------------------------------------------------------------------ stage 0: x = LN0(A W0^T + b0 + res)
   zero(acc);
   gemm16(acc, buf0, r0, wave, 16, 0);
+  CHAIN_STAMP(1);                              // GEMM 0
   wprefetch(r1, wave, 16, 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -308,6 +329,7 @@ linear_chain_kernel(const ChainArgs a) {
   for (int i = 0; i < MT; ++i) xk[i] = acc[i];
   to_planes(xk, buf1);
   __syncthreads();                             // x planes complete (and every wavefront is done with buffer 0)
+  CHAIN_STAMP(2);                              // bias + residual + LayerNorm 0 + plane write
 
   // ------------------------------------------------------------------ FFN, the hidden layer in two halves of 256
   zero(acc2);
@@ -315,6 +337,7 @@ linear_chain_kernel(const ChainArgs a) {
   for (int half = 0; half < 2; ++half) {
     zero(acc);
     gemm16(acc, buf1, r1, half * 8 + wave, 16, 0);
+    CHAIN_STAMP(3 + 3 * half);                 // GEMM 1 (half)
     wprefetch(r2, wave, 32, half * 16);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -330,9 +353,11 @@ linear_chain_kernel(const ChainArgs a) {
       }
     to_planes(acc, buf0);
     __syncthreads();                           // this half of the hidden layer is complete
+    CHAIN_STAMP(4 + 3 * half);                 // bias + ReLU + plane write
     gemm16(acc2, buf0, r2, wave, 32, half * 16);
     if (half == 0) wprefetch(r1, 8 + wave, 16, 0);
     __syncthreads();                           // ... and consumed: buffer 0 may be rewritten
+    CHAIN_STAMP(5 + 3 * half);                 // GEMM 2 (half)
   }
 
   // ------------------------------------------------------------------ y = LN1(x + ffn(x))
@@ -349,6 +374,7 @@ linear_chain_kernel(const ChainArgs a) {
       acc2[i][4 * g + 3] = v.w + xk[i][4 * g + 3];
     }
   layernorm(acc2, a.gamma1, a.beta1, a.eps1);
+  CHAIN_STAMP(9);                              // bias + residual + LayerNorm 1
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (mrow[i] >= a.M) continue;
@@ -358,6 +384,7 @@ linear_chain_kernel(const ChainArgs a) {
       *reinterpret_cast<float4 *>(yrow + ncol + 8 * g) =
           make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
   }
+  CHAIN_STAMP(10);                             // stores issued
 }
 
 }  // namespace bevmsda

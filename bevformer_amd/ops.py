@@ -236,6 +236,8 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                           lg_k=lg_k, vmul=vmul, vadd=vadd)
     if _m().fused_wpe and nrows is None:   # benchmark sweeps: register budget of the kernel
         desc.reserved[0] = _m().fused_wpe
+    if _m().fused_lds_pad_kb and L > 1:    # occupancy cap of the multi-level (SCA) launch
+        desc.reserved[4] = _m().fused_lds_pad_kb
     lib = _lib.load()
     if store == torch.bfloat16 and not _m().bf16_lanes8:
         desc.reserved[2] = 1            # 16-byte-lane kernel writes fp32 rows for the fp32 output projection

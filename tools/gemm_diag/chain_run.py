@@ -1,0 +1,58 @@
+"""Where does a workgroup of the row-chain kernel spend its time?  Phase clocks (lane 0 of wavefront 0, summed over
+workgroups) of csrc/linear_chain.h at the base shape (40,000 rows, two-row gather).  GPU box: python tools/gemm_diag/chain_run.py"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bevformer_amd import ops  # noqa: E402
+
+so, src = os.path.join(HERE, "libchaindiag.so"), os.path.join(HERE, "chain_diag.hip")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", src, "-o", so], check=True)
+lib = ctypes.CDLL(so)
+lib.diag_chain.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 13 + [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+DEV = torch.device("cuda:0")
+M, R = 40000, 45960
+g = torch.Generator().manual_seed(0)
+rows = torch.randn(R, 256, generator=g).to(DEV)
+idx = torch.full((M, 2), -1, dtype=torch.int32)
+idx[:, 0] = torch.arange(M, dtype=torch.int32)
+idx[:R - M, 1] = torch.arange(M, R, dtype=torch.int32)
+idx = idx.to(DEV)
+scale = (1.0 / (idx >= 0).sum(1).clamp(min=1).float()).contiguous()
+w0, w1, w2 = (torch.randn(256, 256, generator=g) / 16).to(DEV), (torch.randn(512, 256, generator=g) / 16).to(DEV), (torch.randn(256, 512, generator=g) / 22).to(DEV)
+b0, b1, b2 = torch.randn(256, device=DEV) * 0.1, torch.randn(512, device=DEV) * 0.1, torch.randn(256, device=DEV) * 0.1
+res = torch.randn(M, 256, generator=g).to(DEV)
+ga, be = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+p0, p1, p2 = ops.panel_weight(w0), ops.panel_weight(w1), ops.panel_weight(w2)
+y = torch.empty(M, 256, device=DEV)
+prof = torch.zeros(12, dtype=torch.int64, device=DEV)
+st = torch.cuda.current_stream().cuda_stream
+call = lambda: lib.diag_chain(rows.data_ptr(), 256, idx.data_ptr(), scale.data_ptr(), p0.data_ptr(), b0.data_ptr(), res.data_ptr(),
+                              ga.data_ptr(), be.data_ptr(), p1.data_ptr(), b1.data_ptr(), p2.data_ptr(), b2.data_ptr(), ga.data_ptr(),
+                              be.data_ptr(), M, y.data_ptr(), prof.data_ptr(), st)
+for _ in range(3):
+    call()
+torch.cuda.synchronize()
+prof.zero_()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+N = 10
+for _ in range(N):
+    call()
+b.record()
+torch.cuda.synchronize()
+names = ["panel fetch + split", "GEMM 0 (out_proj)", "bias + res + LayerNorm 0 + planes", "GEMM 1 half 0", "bias + ReLU + planes",
+         "GEMM 2 half 0", "GEMM 1 half 1", "bias + ReLU + planes", "GEMM 2 half 1", "bias + res + LayerNorm 1", "stores"]
+p = prof.cpu().tolist()
+nb = (M + 63) // 64
+print(f"launch {a.elapsed_time(b) / N * 1e3:.1f} us (with the clock stamps); {nb} workgroups; cycles per workgroup and phase (mean):")
+tot = sum(p[:11])
+for n, c in zip(names, p):
+    print(f"   {n:36s} {c / N / nb:9.0f} clk  {100.0 * c / tot:5.1f} %")
+print(f"   {'sum':36s} {tot / N / nb:9.0f} clk  (MFMA floor of a workgroup: 5 x 16 steps x 6 MFMA x 32 clk x 2 waves / SIMD = 30,720 clk)")
