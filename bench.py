@@ -812,6 +812,34 @@ def main():
                             note="one untiled frame per GPU per step, no collective")
         except Exception as e:          # noqa: BLE001 — never lose the main line to the extra one
             replicas = dict(error=f"{type(e).__name__}: {str(e)[:160]}")
+    # the exchange step alone (N > 1): one all-gather of the (Q / N, 256) fp32 shards, HIP events around 20 calls
+    collective = None
+    if world > 1:
+        try:
+            from bevformer_amd import bev_tiling as _bt2
+            blocks = _bt2.row_blocks(w["bev_h"], world)
+            h0, h1 = blocks[rank]
+            shard = torch.randn(1, (h1 - h0) * w["bev_w"], 256, device=dev)
+            for _ in range(3):
+                _bt2.all_gather_rows(shard, blocks, w["bev_w"])
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                _bt2.all_gather_rows(shard, blocks, w["bev_w"])
+            e1.record()
+            fence()
+            t_ag = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
+            collective = dict(backend="nccl (RCCL)", ranks=dist.get_world_size(), op="all_gather_into_tensor",
+                              shard_bytes=int(shard.numel() * 4), us_per_call_max_over_ranks=float(t_ag.item()),
+                              calls_per_step=1 if not args.first_frame else w["layers"])
+        except Exception as e:          # noqa: BLE001
+            collective = dict(error=f"{type(e).__name__}: {str(e)[:160]}")
+    if line is not None:
+        line["ranks"] = world
+        if collective is not None:
+            line["collective"] = collective
     if line is not None and replicas is not None:
         line["frames_in_parallel"] = replicas
     if world > 1 or args.force_tiling:

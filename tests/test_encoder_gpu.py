@@ -205,3 +205,38 @@ def test_pre_norm_operation_order_inference_path_equals_autograd_path():
     with torch.enable_grad():
         slow = enc(q.clone().requires_grad_(True), f, f, **kw).detach()
     torch.testing.assert_close(fast, slow, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("temporal", [False, True])
+def test_train_mode_with_active_dropout_on_the_gpu(temporal, monkeypatch):
+    """``train()`` mode with dropout ACTIVE (p = 0.1 in TSA, SCA and the FFN, as in the reference's training step,
+    spatial_cross_attention.py:175 / temporal_self_attention.py:272): the GPU path (autograd Functions on the HIP
+    kernels) against the same modules evaluated on the CPU through the oracle's operators, both with
+    ``torch.nn.functional.dropout`` replaced by one deterministic mask (random streams cannot be shared between CPU and
+    GPU).  tests/test_oracle_vs_reference.py pins the CPU side of this against the reference's own files."""
+    from helpers import oracle_ops
+    calls = {"n": 0}
+
+    def det_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        calls["n"] += 1
+        idx = torch.arange(x.numel(), dtype=torch.int64, device=x.device).view(x.shape)
+        keep = ((idx * 2654435761 + calls["n"] * 40503) % 1000) >= int(round(p * 1000))
+        return x * keep.to(x.dtype) / (1.0 - p)
+
+    monkeypatch.setattr(torch.nn.functional, "dropout", det_dropout)
+    enc, sd = build_pair("micro4")
+    q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
+    enc.train()
+    with torch.no_grad(), oracle_ops():
+        want = enc(q, f, f, **kw)
+    n_cpu, calls["n"] = calls["n"], 0
+    enc = enc.to(DEV)
+    qd = q.to(DEV).requires_grad_(True)
+    got = enc(qd, f.to(DEV), f.to(DEV), **_to_dev(kw))
+    assert calls["n"] == n_cpu == 8
+    assert got.grad_fn is not None
+    torch.testing.assert_close(got.detach().cpu(), want, **TOL)
+    got.sum().backward()
+    assert torch.isfinite(qd.grad).all()

@@ -165,3 +165,44 @@ def test_history_queue_restatement_against_the_reference_detector_code():
     want = fns["obtain_history_bev"](det, imgs_queue, copy_metas(metas_list))
     got = O.obtain_history_bev(bev_fn, feats_queue, copy_metas(metas_list))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("temporal", [False, True])
+def test_train_mode_with_active_dropout_matches_the_reference(temporal, monkeypatch):
+    """The reference's training step runs with dropout ACTIVE in TemporalSelfAttention (:272),
+    SpatialCrossAttention (:175) and both FFN dropouts (p = 0.1 in the BEVFormer configs); every other parity test is
+    ``eval()``.  CPU and GPU random streams cannot be shared, so ``torch.nn.functional.dropout`` is replaced — for the
+    reference's own files under the stub AND for the product modules — by a deterministic mask that depends on the
+    call's position in the forward pass and on the element index: equal outputs in ``train()`` mode then mean the
+    product applies dropout at the same places, to the same tensors, in the same order, with the same scaling."""
+    calls = {"n": 0, "shapes": []}
+
+    def det_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        calls["n"] += 1
+        calls["shapes"].append(tuple(x.shape))
+        idx = torch.arange(x.numel(), dtype=torch.int64).view(x.shape)
+        keep = ((idx * 2654435761 + calls["n"] * 40503) % 1000) >= int(round(p * 1000))
+        return x * keep.to(x.dtype) / (1.0 - p)
+
+    monkeypatch.setattr(torch.nn.functional, "dropout", det_dropout)
+    ref = mmcv_stub.build_reference_encoder(S.encoder_cfg("micro4"))
+    ref.load_state_dict(S.trained_like_({k: v.clone() for k, v in ref.state_dict().items()}, seed=5))
+    enc, _ = build_pair("micro4")
+    enc.load_state_dict(ref.state_dict())
+    q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
+    ref.train()
+    enc.train()
+    with torch.no_grad():
+        want = ref(q, f, f, **kw)
+        ref_calls = dict(calls)
+        calls["n"], calls["shapes"] = 0, []
+        with oracle_ops():
+            got = enc(q, f, f, **kw)
+        ref.eval()
+        plain = ref(q, f, f, **kw)
+    assert ref_calls["n"] == calls["n"] == 2 * 4, (ref_calls["n"], calls["n"])     # 2 layers x (TSA, SCA, 2 x FFN)
+    assert ref_calls["shapes"] == calls["shapes"]
+    assert (want - plain).abs().max() > 1e-2                                        # dropout really was active
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
