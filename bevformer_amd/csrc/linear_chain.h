@@ -73,9 +73,14 @@ linear_chain_kernel(const ChainArgs a) {
   constexpr int NPL = LO ? 2 : 1;
   constexpr int MT = 2, NW = kChainWaves, BM = kChainRows;
   constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: 64 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4];
+  constexpr int NCST = 4 * kChainC + kChainF + 3 * kChainC;           // gamma0, beta0, gamma1, beta1 | b1 | b0, b2, (pad)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4 + NCST * 4];
   unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
   float *const stat = reinterpret_cast<float *>(lds + 2 * BUF);       // [wave][row]
+  // the per-column constants of every epilogue, copied once: read from LDS instead of as an L2 round trip per stage
+  float *const cst = stat + NW * BM;
+  float *const c_g0 = cst, *const c_be0 = cst + 256, *const c_g1 = cst + 512, *const c_be1 = cst + 768;
+  float *const c_b1 = cst + 1024, *const c_b0 = cst + 1536, *const c_b2 = cst + 1792;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,6 +89,15 @@ linear_chain_kernel(const ChainArgs a) {
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
+
+  {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t4 = tid * 4;                    // 512 threads x 4 floats = 2048 = the constant block
+    const float *src = t4 < 256 ? a.gamma0 + t4 : t4 < 512 ? a.beta0 + (t4 - 256) : t4 < 768 ? a.gamma1 + (t4 - 512)
+                       : t4 < 1024 ? a.beta1 + (t4 - 768) : t4 < 1536 ? (a.b1 ? a.b1 + (t4 - 1024) : nullptr)
+                       : t4 < 1792 ? (a.b0 ? a.b0 + (t4 - 1536) : nullptr) : (a.b2 ? a.b2 + (t4 - 1792) : nullptr);
+    *reinterpret_cast<float4 *>(cst + t4) = src ? *reinterpret_cast<const float4 *>(src) : z4;
+  }                                            // (visible after the barrier that closes the panel fetch)
 
   // fragment read addresses (linear_panel.h)
   const int f_r = lane & 31, f_h = lane >> 5;
@@ -319,12 +333,12 @@ linear_chain_kernel(const ChainArgs a) {
     for (int g = 0; g < 4; ++g) {
       const int n = ncol + 8 * g;
       float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-      if (a.b0) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b0 + n));
+      v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b0 + n));
       v = lin_add4(v, rs[i][g]);
       acc[i][4 * g] = v.x; acc[i][4 * g + 1] = v.y; acc[i][4 * g + 2] = v.z; acc[i][4 * g + 3] = v.w;
     }
   }
-  layernorm(acc, a.gamma0, a.beta0, a.eps0);
+  layernorm(acc, c_g0, c_be0, a.eps0);
 #pragma unroll
   for (int i = 0; i < MT; ++i) xk[i] = acc[i];
   to_planes(xk, buf1);
@@ -345,7 +359,7 @@ linear_chain_kernel(const ChainArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int n = half * 256 + ncol + 8 * g;
         float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-        if (a.b1) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b1 + n));
+        v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b1 + n));
         acc[i][4 * g] = v.x < 0.f ? 0.f : v.x;      // NaN stays NaN, as torch.relu
         acc[i][4 * g + 1] = v.y < 0.f ? 0.f : v.y;
         acc[i][4 * g + 2] = v.z < 0.f ? 0.f : v.z;
@@ -367,13 +381,13 @@ linear_chain_kernel(const ChainArgs a) {
     for (int g = 0; g < 4; ++g) {
       const int n = ncol + 8 * g;
       float4 v = make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
-      if (a.b2) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.b2 + n));
+      v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b2 + n));
       acc2[i][4 * g] = v.x + xk[i][4 * g];
       acc2[i][4 * g + 1] = v.y + xk[i][4 * g + 1];
       acc2[i][4 * g + 2] = v.z + xk[i][4 * g + 2];
       acc2[i][4 * g + 3] = v.w + xk[i][4 * g + 3];
     }
-  layernorm(acc2, a.gamma1, a.beta1, a.eps1);
+  layernorm(acc2, c_g1, c_be1, a.eps1);
   CHAIN_STAMP(9);                              // bias + residual + LayerNorm 1
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
