@@ -286,7 +286,7 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
     return BEVMSDA_ERR_MISALIGNED;
   const long long nb = (d->M + bevmsda::kChainRows - 1) / bevmsda::kChainRows;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  bevmsda::ChainArgs a;
+  bevmsda::ChainArgs a{};
   a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale;
   a.w0 = w0p; a.w1 = w1p; a.w2 = w2p; a.b0 = b0; a.b1 = b1; a.b2 = b2;
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = gamma1; a.beta1 = beta1;
@@ -299,6 +299,41 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
   } else {
     if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0>), grid, block, 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                   const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                   const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  const long ld_y2 = d->reserved[0];
+  if (d->C != bevmsda::kChainC || d->F <= 0 || d->F % 32 != 0 || d->F > bevmsda::kChainMaxN2) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->M == 0) return BEVMSDA_OK;
+  if (!rows || !w0p || !w1p || !gamma0 || !beta0 || !x_out || !proj_out) return BEVMSDA_ERR_NULL_POINTER;
+  if ((idx == nullptr) != (scale == nullptr)) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->ld_rows % 4 != 0 || d->ld_y % 4 != 0 || ld_y2 % 4 != 0 || (res && d->ld_res % 4 != 0)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->ld_rows < d->C || d->ld_y < d->C || ld_y2 < d->F || (res && d->ld_res < d->C)) return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(rows) || misaligned(w0p) || misaligned(w1p) || misaligned(x_out) || misaligned(proj_out) || (res && misaligned(res)) ||
+      (b0 && misaligned(b0)) || (b1 && misaligned(b1)) || misaligned(gamma0) || misaligned(beta0))
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = (d->M + bevmsda::kChainRows - 1) / bevmsda::kChainRows;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::ChainArgs a{};
+  a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale;
+  a.w0 = w0p; a.w1 = w1p; a.w2 = nullptr; a.b0 = b0; a.b1 = b1; a.b2 = nullptr;
+  a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = a.beta1 = nullptr;
+  a.eps0 = d->eps0; a.eps1 = 0.f; a.y = x_out; a.ld_y = d->ld_y; a.M = d->M; a.y2 = proj_out; a.ld_y2 = ld_y2; a.N2 = d->F;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(nb)), block(bevmsda::kChainWaves * 64);
+  if (d->precision == 0) {
+    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 1>), grid, block, 0, st, a);
+  } else {
+    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 2, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0, 1>), grid, block, 0, st, a);
   }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }

@@ -21,6 +21,13 @@
 //             acc2 += h_half W2[:, 256h ..]^T                                          beyond one 64 x 256 half in LDS)
 //   final     acc2 + b2 + x -> LayerNorm1 -> y
 //
+// MODE 1 — the attention-to-attention seam of the layer, same machinery:
+//     x = LayerNorm0( A W0^T + b0 + res )    TemporalSelfAttention's output projection + "+ identity" + norms[0]
+//     p = x W1^T + b1                         SpatialCrossAttention's merged [sampling_offsets | attention_weights]
+//                                             projection of the same rows (N2 = 768 columns at base)
+// x is stored (it is SpatialCrossAttention's residual) AND kept as planes, so the second projection never re-reads it;
+// a wavefront walks the 32-column tiles t = wave, wave + 8, ... of p.
+//
 // LDS: 2 x 64 KiB plane buffers + 2 KiB of row statistics: one workgroup (512 threads, 2 wavefronts per SIMD) per CU.
 // The accumulator -> plane write uses the same slot map the DMA + split pass produces, so the fragment reads of every
 // stage are the conflict-free ones of linear_panel.h (tests/test_linear_layout_model.py replays the arithmetic).
@@ -43,6 +50,9 @@ struct ChainArgs {
   float *y;
   long ld_y;
   long M;
+  float *y2;                        // MODE 1: the second projection's output (M, ld_y2), N2 columns
+  long ld_y2;
+  int N2;
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -64,7 +74,10 @@ constexpr int kChainRows = 64;      // rows per workgroup
 constexpr int kChainWaves = 8;      // wavefronts = 32-column tiles per stage
 constexpr int kChainC = 256, kChainF = 512;
 
-template <int NPROD, int PRE>
+constexpr int kChainMaxN2 = 768;   // MODE 1: columns of the second projection (its bias is staged in LDS)
+
+// MODE 0: projection + norm + FFN + norm; MODE 1: projection + norm (stored) + a second projection of N2 columns
+template <int NPROD, int PRE, int MODE = 0>
 __global__ void __launch_bounds__(kChainWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -73,14 +86,15 @@ linear_chain_kernel(const ChainArgs a) {
   constexpr int NPL = LO ? 2 : 1;
   constexpr int MT = 2, NW = kChainWaves, BM = kChainRows;
   constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: 64 KiB
-  constexpr int NCST = 4 * kChainC + kChainF + 3 * kChainC;           // gamma0, beta0, gamma1, beta1 | b1 | b0, b2, (pad)
+  constexpr int NCST = 4 * kChainC + kChainMaxN2 + 2 * kChainC;       // gamma0, beta0, gamma1, beta1 | b1 | b0, b2
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4 + NCST * 4];
   unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
   float *const stat = reinterpret_cast<float *>(lds + 2 * BUF);       // [wave][row]
   // the per-column constants of every epilogue, copied once: read from LDS instead of as an L2 round trip per stage
   float *const cst = stat + NW * BM;
   float *const c_g0 = cst, *const c_be0 = cst + 256, *const c_g1 = cst + 512, *const c_be1 = cst + 768;
-  float *const c_b1 = cst + 1024, *const c_b0 = cst + 1536, *const c_b2 = cst + 1792;
+  float *const c_b1 = cst + 1024, *const c_b0 = cst + 1024 + kChainMaxN2, *const c_b2 = c_b0 + 256;
+  const int nb1 = MODE == 1 ? a.N2 : kChainF;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,11 +106,17 @@ linear_chain_kernel(const ChainArgs a) {
 
   {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int t4 = tid * 4;                    // 512 threads x 4 floats = 2048 = the constant block
-    const float *src = t4 < 256 ? a.gamma0 + t4 : t4 < 512 ? a.beta0 + (t4 - 256) : t4 < 768 ? a.gamma1 + (t4 - 512)
-                       : t4 < 1024 ? a.beta1 + (t4 - 768) : t4 < 1536 ? (a.b1 ? a.b1 + (t4 - 1024) : nullptr)
-                       : t4 < 1792 ? (a.b0 ? a.b0 + (t4 - 1536) : nullptr) : (a.b2 ? a.b2 + (t4 - 1792) : nullptr);
-    *reinterpret_cast<float4 *>(cst + t4) = src ? *reinterpret_cast<const float4 *>(src) : z4;
+    for (int t4 = tid * 4; t4 < NCST; t4 += kChainWaves * 64 * 4) {
+      const float *src = nullptr;
+      if (t4 < 256) src = a.gamma0 + t4;
+      else if (t4 < 512) src = a.beta0 + (t4 - 256);
+      else if (t4 < 768) src = MODE == 0 ? a.gamma1 + (t4 - 512) : nullptr;
+      else if (t4 < 1024) src = MODE == 0 ? a.beta1 + (t4 - 768) : nullptr;
+      else if (t4 < 1024 + kChainMaxN2) src = (a.b1 && t4 - 1024 < nb1) ? a.b1 + (t4 - 1024) : nullptr;
+      else if (t4 < 1024 + kChainMaxN2 + 256) src = a.b0 ? a.b0 + (t4 - 1024 - kChainMaxN2) : nullptr;
+      else src = (MODE == 0 && a.b2) ? a.b2 + (t4 - 1024 - kChainMaxN2 - 256) : nullptr;
+      *reinterpret_cast<float4 *>(cst + t4) = src ? *reinterpret_cast<const float4 *>(src) : z4;
+    }
   }                                            // (visible after the barrier that closes the panel fetch)
 
   // fragment read addresses (linear_panel.h)
@@ -247,10 +267,10 @@ linear_chain_kernel(const ChainArgs a) {
     __syncthreads();                           // `stat` may be written again
   };
 
-  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = 16u * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
+  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = static_cast<unsigned>((nb1 + 63) / 64 * 2) * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
   __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
-  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w2), 0, static_cast<int>(w2b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(MODE == 0 ? a.w2 : a.w0), 0, static_cast<int>(MODE == 0 ? w2b : w0b), 0x00020000);
 
   // rows and columns of this lane's accumulator registers
   const int ncol = wave * 32 + 4 * (lane >> 5);        // + 8 g + e
@@ -344,6 +364,39 @@ linear_chain_kernel(const ChainArgs a) {
   to_planes(xk, buf1);
   __syncthreads();                             // x planes complete (and every wavefront is done with buffer 0)
   CHAIN_STAMP(2);                              // bias + residual + LayerNorm 0 + plane write
+
+  if constexpr (MODE == 1) {
+    // x is the next attention's residual: store it, then project it (from its planes) tile by tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mrow[i] >= a.M) continue;
+      float *yrow = a.y + mrow[i] * a.ld_y;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(yrow + ncol + 8 * g) =
+            make_float4(xk[i][4 * g], xk[i][4 * g + 1], xk[i][4 * g + 2], xk[i][4 * g + 3]);
+    }
+    const int ntile = a.N2 / 32;
+#pragma unroll 1
+    for (int t = wave; t < ntile; t += NW) {
+      zero(acc);
+      gemm16(acc, buf1, r1, t, 16, 0);
+      if (t + NW < ntile) wprefetch(r1, t + NW, 16, 0);
+      const int nc = t * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (mrow[i] >= a.M) continue;
+        float *prow = a.y2 + mrow[i] * a.ld_y2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+          v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b1 + nc + 8 * g));
+          *reinterpret_cast<float4 *>(prow + nc + 8 * g) = v;
+        }
+      }
+    }
+    return;
+  }
 
   // ------------------------------------------------------------------ FFN, the hidden layer in two halves of 256
   zero(acc2);

@@ -305,8 +305,27 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             return lambda rows, w, b, res, post_norm, gather: ops.proj_ffn_chain(
                 rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain") if post_norm is n0 else None
 
+        def _chain_t(i):
+            """self_attn at ``i`` followed by norm, cross_attn: a callable that runs the output projection,
+            "+ identity", the norm AND the cross-attention's merged offset / weight projection in one kernel."""
+            if not fuse_norm or tuple(order[i + 1:i + 3]) != ("norm", "cross_attn") or query_pos is not None \
+                    or attn_i + 1 >= len(self.attentions):
+                return None
+            da = getattr(self.attentions[attn_i + 1], "deformable_attention", None)
+            n0 = self.norms[norm_i]
+            if da is None or not hasattr(da, "sampling_offsets") or not isinstance(n0, torch.nn.LayerNorm):
+                return None
+
+            def run(rows, w, b, res, post_norm):
+                if post_norm is not n0:
+                    return None
+                wm, bm = ops.merged_linear_params(da, da.sampling_offsets, da.attention_weights)
+                return ops.proj_ln_proj_chain(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain")
+            return run
+
         skip_norm = False                       # the previous step returned ops.Normed
         skip_ops = 0                            # steps already applied by a chained kernel (ops.Chained)
+        next_proj = None                        # the cross-attention's query projection, when a chained kernel made it
         for i, op in enumerate(order):
             if skip_ops:
                 skip_ops -= 1
@@ -321,9 +340,11 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_i],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                     spatial_shapes=bev_shapes, level_start_index=bev_start,
-                    defer_residual=_defer(i), post_norm=_post_norm(i), **kwargs)
+                    defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain_t(i), **kwargs)
                 attn_i += 1
-                if isinstance(query, ops.Normed):
+                if isinstance(query, ops.NormedWithProj):
+                    query, next_proj, skip_norm = query.t, query.proj, True
+                elif isinstance(query, ops.Normed):
                     query, skip_norm = query.t, True
                 elif isinstance(query, tuple):
                     pending, query = query, None
@@ -352,7 +373,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     reference_points_cam=reference_points_cam, mask=mask,
                     attn_mask=attn_masks[attn_i], key_padding_mask=key_padding_mask,
                     spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                    frame_plan=frame_plan, defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain(i), **kwargs)
+                    frame_plan=frame_plan, defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain(i),
+                    query_proj=next_proj, **kwargs)
+                next_proj = None
                 attn_i += 1
                 if isinstance(query, ops.Chained):
                     query, skip_ops = query.t, 3

@@ -136,7 +136,7 @@ class MSDeformableAttention3D(BaseModule):
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
                                        spatial_shapes, level_start_index, frame_plan=None, autograd=False,
-                                       q_rows=None):
+                                       q_rows=None, proj=None):
         """queries (Q, C) projected once; row r samples with the projection row
         ``row_src[r]`` and its own anchors ``row_ref[r]`` -> (R, C), or None when
         the fused kernel does not cover the shape.  ``autograd``: through
@@ -146,8 +146,9 @@ class MSDeformableAttention3D(BaseModule):
         if P % Dz != 0 or row_ref.shape[-1] != 2:
             return None
         n_off = self.sampling_offsets.out_features
-        w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
-        proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
+        if proj is None:            # (else: the merged projection of these rows came out of the previous step's kernel)
+            w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
+            proj = ops.linear_or_torch(queries, w, b, tag="sca_offs_attn")
         if autograd:
             if value.shape[-1] != 32 or L > 4 or P not in (4, 8) or value.dtype != torch.float32:   # (storage may be bf16)
                 return None
@@ -217,7 +218,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
-                projected_value=None, defer_residual=False, post_norm=None, chain=None, **kwargs):
+                projected_value=None, defer_residual=False, post_norm=None, chain=None, query_proj=None, **kwargs):
         """query (bs, Q, C); key/value (Nc, S, bs, C); reference_points_cam
         (Nc, bs, Q, Dz, 2); bev_mask (Nc, bs, Q, Dz) -> (bs, Q, C).
 
@@ -260,7 +261,8 @@ class SpatialCrossAttention(BaseModule):
             # reads its query's projection row through row_src; the camera mean is a gather
             out_rows = da.forward_rows_shared_projection(
                 query.reshape(bs * Q, C), projected_value, row_ref, row_batch,
-                frame_plan.row_query32, spatial_shapes, level_start_index, frame_plan=frame_plan)
+                frame_plan.row_query32, spatial_shapes, level_start_index, frame_plan=frame_plan,
+                proj=query_proj if query_pos is None else None)
             if out_rows is not None:
                 if frame_plan.dynamic:
                     # slots seen by more than two cameras (rare; known to the device only): fold their

@@ -136,7 +136,7 @@ class TemporalSelfAttention(BaseModule):
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, flag="decoder", bev_slice=None, defer_residual=False,
-                tsa_projected_value=None, post_norm=None, **kwargs):
+                tsa_projected_value=None, post_norm=None, chain=None, **kwargs):
         """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
         b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C).
 
@@ -214,6 +214,11 @@ class TemporalSelfAttention(BaseModule):
         if out is None:
             out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,
                                        level_start_index, shared_value, bs, Q, C)
+        if post_norm is not None and chain is not None and self.batch_first and not (self.training and self.dropout.p > 0):
+            # ... and the next attention's projection of the normed rows behind them, in the same kernel
+            done = chain(out, self.output_proj.weight, self.output_proj.bias, identity, post_norm)
+            if done is not None:
+                return ops.NormedWithProj(done[0], done[1])
         if post_norm is not None and self.batch_first and not (self.training and self.dropout.p > 0):
             # output_proj, "+ identity" and the layer's norm in one kernel
             fused = ops.linear_layernorm(out, self.output_proj.weight, self.output_proj.bias, identity, post_norm,

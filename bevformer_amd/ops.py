@@ -973,6 +973,65 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
     return y.view(*lead, 256)
 
 
+class NormedWithProj:
+    """A module output to which "+ identity" and the layer's norm have been applied (``t``) together with the NEXT
+    attention's projection of those rows (``proj``), both from one kernel (``proj_ln_proj_chain``)."""
+    __slots__ = ("t", "proj")
+
+    def __init__(self, t, proj):
+        self.t, self.proj = t, proj
+
+
+def proj_ln_proj_chain(rows, weight, bias, res, norm0, w1, b1, *, tag="proj_ln_proj_chain"):
+    """``x = norm0(linear(rows, weight, bias) + res)`` and ``p = linear(x, w1, b1)`` in ONE kernel
+    (``bevmsda_proj_ln_proj_chain_f32``, csrc/linear_chain.h MODE 1): TemporalSelfAttention's output projection,
+    "+ identity", the layer's norm and SpatialCrossAttention's merged offset / weight projection of the result.
+    Returns ``(x, p)`` or ``None`` when not covered."""
+    m = _m()
+    if not m.ln_fuse or m.gemm == "native" or not m.gemm_pack or m.gemm_variant is not None \
+            or m.gemm_kernel in ("first", "pipe") or not rows.is_cuda or rows.dtype != torch.float32 \
+            or not isinstance(norm0, torch.nn.LayerNorm) or tuple(norm0.normalized_shape) != (256,) \
+            or norm0.weight is None or norm0.bias is None or tuple(weight.shape) != (256, 256) or w1.dim() != 2 \
+            or w1.shape[1] != 256 or w1.shape[0] % 32 or w1.shape[0] > 768 or rows.shape[-1] != 256 \
+            or res is None or res.dtype != torch.float32 or res.shape[-1] != 256 \
+            or not fused_wanted(rows, weight, bias, res, norm0.weight, w1, b1):
+        return None
+    x0, ldx = _rows2d(rows, 256)
+    M = x0.shape[0]
+    if res.numel() != M * 256:
+        return None
+    r2, ldres = _rows2d(res, 256)
+    N2 = w1.shape[0]
+    blobs = []
+    for w in (weight, w1):
+        w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
+        blob = panel_weight(w)
+        if blob is None:
+            return None
+        blobs.append(blob)
+    x = torch.empty((M, 256), dtype=torch.float32, device=rows.device)
+    pr = torch.empty((M, N2), dtype=torch.float32, device=rows.device)
+    lead = res.shape[:-1]
+    if M == 0:
+        return x.view(*lead, 256), pr
+    desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=N2, precision=0 if m.gemm == "split" else 1,
+                          eps0=float(norm0.eps), eps1=0.0)
+    desc.reserved[0] = N2
+    lib = _lib.load()
+    cb = _GEMM_TIMER["cb"]
+    ctx = cb(tag, 2.0 * M * 256 * (256 + N2), 4.0 * (M * 256 * 3 + M * N2 + 256 * 256 + N2 * 256)) if cb is not None else _NoTimer()
+    p = lambda t: _ptr(t) if t is not None else None
+    bc = lambda t: t.contiguous() if t is not None else None
+    with torch.cuda.device(rows.device), ctx:
+        rc = lib.bevmsda_proj_ln_proj_chain_f32(_ptr(x0), None, None, _ptr(blobs[0]), p(bc(bias)), _ptr(r2), _ptr(norm0.weight),
+                                                _ptr(norm0.bias), _ptr(blobs[1]), p(bc(b1)), ctypes.byref(desc), _ptr(x), _ptr(pr),
+                                                torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "proj_ln_proj_chain")
+    return x.view(*lead, 256), pr
+
+
 def transposed_weight(weight):
     """Contiguous ``weight.t()`` cached on the tensor until it is written to: the operand of the
     input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""

@@ -416,13 +416,24 @@ typedef struct bevmsda_chain_desc {
   int32_t C, F;                  /* embedding and hidden width */
   int32_t precision;             /* as bevmsda_linear_desc */
   float eps0, eps1;
-  int32_t reserved[5];
+  int32_t reserved[5];           /* [0]: bevmsda_proj_ln_proj_chain_f32: row stride of proj_out in floats */
 } bevmsda_chain_desc;
 
 int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                                const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
                                const bevmsda_chain_desc *desc, float *y, void *stream);
+
+/* The attention-to-attention seam of a layer with the same machinery:
+ *     x = LayerNorm0(A w0^T + b0 + res)        TemporalSelfAttention's output projection, "+ identity", norms[0]
+ *     p = x w1^T + b1                           the next attention's projection of the same rows — SpatialCrossAttention's
+ *                                               merged [sampling_offsets ; attention_weights] Linear (desc->F columns)
+ * (temporal_self_attention.py:267-272, encoder.py:376-378, spatial_cross_attention.py:338-348).  x_out (M, ld_y) is stored
+ * (it is the next attention's residual), p goes to proj_out (M, desc->reserved[0]); x is projected from its on-chip copy.
+ * desc->F: a multiple of 32, at most 768; w1p: the panel image of (F, C).  Other requirements as above. */
+int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                   const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                   const bevmsda_chain_desc *desc, float *x_out, float *proj_out, void *stream);
 
 /* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
  *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)

@@ -480,3 +480,36 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
                  (256,), n1.weight.double(), n1.bias.double(), n1.eps)
     tol = 2e-4 if mode == "split" else 5e-2
     torch.testing.assert_close(got.double(), y64, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+@pytest.mark.parametrize("M,N2", [(641, 768), (4099, 192), (64, 96), (5000, 768)])
+def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M, N2):
+    """``bevmsda_proj_ln_proj_chain_f32`` (csrc/linear_chain.h, MODE 1): output projection + residual + LayerNorm (stored)
+    + the next attention's projection of the normed rows, against the LayerNorm-fused projection followed by a plain
+    projection, and against the fp64 statement."""
+    gemm_mode(mode)
+    rows, res = _rand(M, 256, seed=91), _rand(M, 256, seed=92)
+    w0, b0 = _rand(256, 256, seed=93) / 16, _rand(256, seed=94) * 0.1
+    w1, b1 = _rand(N2, 256, seed=95) / 16, _rand(N2, seed=96) * 0.1
+    n0 = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        n0.weight.copy_(_rand(256, seed=97) * 0.2 + 1.0)
+        n0.bias.copy_(_rand(256, seed=98) * 0.1)
+        with ops.using(ln_fuse=True):
+            got = ops.proj_ln_proj_chain(rows, w0, b0, res, n0, w1, b1)
+            x = ops.linear_layernorm(rows, w0, b0, res, n0)
+        with ops.using(gemm_kernel="first"):
+            p = ops.linear(x, w1, b1)
+        assert got is not None and x is not None
+        gx, gp = got
+        assert gx.shape == (M, 256) and gp.shape == (M, N2)
+        t2 = 2e-5 if mode == "split" else 2e-2
+        torch.testing.assert_close(gx, x, rtol=t2, atol=t2)
+        torch.testing.assert_close(gp, p, rtol=max(t2, 5e-5), atol=max(t2, 5e-5))
+        ln = torch.nn.functional.layer_norm
+        x64 = ln(rows.double() @ w0.double().t() + b0.double() + res.double(), (256,), n0.weight.double(), n0.bias.double(), n0.eps)
+        p64 = x64 @ w1.double().t() + b1.double()
+    tol = 2e-4 if mode == "split" else 5e-2
+    torch.testing.assert_close(gx.double(), x64, rtol=tol, atol=tol)
+    torch.testing.assert_close(gp.double(), p64, rtol=tol, atol=tol)
