@@ -236,7 +236,8 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
       return BEVMSDA_ERR_MISALIGNED;
     a.res = ln->res; a.ldres = ln->ldres; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
   }
-  // workgroup shape (desc->reserved[2]): 1 = 64-row panels, 4 wavefronts of 64 x 64 tiles, two workgroups per CU;
+  // workgroup shape (desc->reserved[2]): 1 = 64-row panels, 4 wavefronts of 64 x 64 tiles, two workgroups per CU, weight
+  // fragments 2 k16 steps ahead (desc->reserved[3] = 6: six, a benchmark knob — no gain, tools/gemm_ab.py);
   // 2 = 128-row panels, 8 wavefronts of 128 x 32 tiles, one workgroup per CU (half the weight traffic per MFMA);
   // 0 = by shape.  Two panel passes (K = 512) and the LayerNorm epilogue need one column tile per wavefront: N <= 256
   int shape = d->reserved[2];
@@ -248,9 +249,14 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
+  // desc->reserved[3]: weight fragments in flight for shape 1 (0 = default, 2 or 6 k16 steps ahead)
+  if (d->reserved[3] != 0 && d->reserved[3] != 2 && d->reserved[3] != 6) return BEVMSDA_ERR_BAD_OPTION;
+  const bool deep = d->reserved[3] == 6;       // (measured in one process: 616 vs 612 us, 272 vs 274 us — no default)
 #define BEVMSDA_PANEL2(NP_, LN_, PRE_)                                                                                   \
   do {                                                                                                                   \
-    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, LN_, PRE_>), grid, dim3(256), 0, st, a); \
+    if (shape == 1 && deep && (PRE_) == 0)                                                                               \
+      hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, LN_, PRE_, 0, 0, false, 6>), grid, dim3(256), 0, st, a); \
+    else if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, LN_, PRE_>), grid, dim3(256), 0, st, a); \
     else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, LN_, PRE_>), grid, dim3(512), 0, st, a);           \
   } while (0)
 #define BEVMSDA_PANEL(NP_, LN_)                              \

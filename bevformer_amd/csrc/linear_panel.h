@@ -114,7 +114,8 @@ __device__ __forceinline__ void panel_store(uint16_t *p, const uint2 &v) {
 // every wavefront re-reads (tools/gemm_diag/panel_run.py).
 // DRIP: a finished column tile's accumulators move to a second register set and are stored ONE 16-byte piece per k16 step
 // of the next tile instead of as a burst of 16 stores at the tile's end.
-template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false>
+// WD: weight fragments in flight, in k16 steps ahead of the MFMAs that consume them (ring of WD + 1 stages).
+template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false, int WD = 2>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_panel_kernel(const PanelArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -156,7 +157,8 @@ linear_panel_kernel(const PanelArgs a) {
   const int wlane = lane * 16;
 
   lin_f32x16 acc[MT][NT];
-  lin_bf16x8 wf[3][NT][NPL];                   // weight fragments: ring over k16 steps (two in flight)
+  constexpr int RS = WD + 1;
+  lin_bf16x8 wf[RS][NT][NPL];                  // weight fragments: ring over k16 steps (WD in flight)
 
   // weight fragments of (column tile ct, global step sg) -> ring stage st
   auto wload = [&](int st, int ct, int sg) {
@@ -276,8 +278,8 @@ linear_panel_kernel(const PanelArgs a) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
     if (ct < nct) {
-      wload(0, ct, half * 16 + 0);
-      wload(1, ct, half * 16 + 1);
+#pragma unroll
+      for (int k = 0; k < WD; ++k) wload(k, ct, half * 16 + k);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my own DMA slots have landed (no other lane reads them yet)
 #pragma unroll
@@ -319,11 +321,11 @@ linear_panel_kernel(const PanelArgs a) {
       aload(0, 0);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        // weight fragments two steps ahead (ring stage (s + 2) % 3); past the tile's end: the next tile's first two
-        if (s + 2 < 16) {
-          wload((s + 2) % 3, ct, half * 16 + s + 2);
+        // weight fragments WD steps ahead (ring stage (s + WD) % RS); past the tile's end: the next tile's first WD
+        if (s + WD < 16) {
+          wload((s + WD) % RS, ct, half * 16 + s + WD);
         } else if (ct_next < nct) {
-          wload((s + 2) % 3, ct_next, half * 16 + s + 2 - 16);
+          wload((s + WD) % RS, ct_next, half * 16 + s + WD - 16);
         }
         if (s + 1 < 16) aload((s + 1) & 1, s + 1);
         if constexpr (DRIP && !LN) {
@@ -336,28 +338,34 @@ linear_panel_kernel(const PanelArgs a) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             if (PANEL_DIAG(a, 0) && s > 0) {   // operands stay live, the matrix pipe idles
-              asm volatile("" ::"v"(wf[s % 3][j][0]), "v"(af[s & 1][i][0]));
-              if (LO) asm volatile("" ::"v"(wf[s % 3][j][1]), "v"(af[s & 1][i][1]));
+              asm volatile("" ::"v"(wf[s % RS][j][0]), "v"(af[s & 1][i][0]));
+              if (LO) asm volatile("" ::"v"(wf[s % RS][j][1]), "v"(af[s & 1][i][1]));
               continue;
             }
             // D[n][m]: the W fragment is the MFMA's A operand (4 consecutive output columns per lane -> float4 stores)
             if (LO) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][0], af[s & 1][i][1], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][1], af[s & 1][i][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % RS][j][0], af[s & 1][i][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % RS][j][1], af[s & 1][i][0], acc[i][j], 0, 0, 0);
             }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % 3][j][0], af[s & 1][i][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % RS][j][0], af[s & 1][i][0], acc[i][j], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);     // ... and hoists every fragment read of the tile to its top
       }
-      // 16 % 3 == 1: the next tile's steps 0, 1 sit in ring stages 1, 2 -> rotate them to 0, 1
-      if (ct_next < nct) {
+      // the next tile's steps 0 .. WD - 1 sit in ring stages (16 + k) % RS: rotate them to stages 0 .. WD - 1
+      if (ct_next < nct && (16 % RS) != 0) {
+        lin_bf16x8 tmp[WD][NT][NPL];
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn)
+        for (int k = 0; k < WD; ++k)
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) {
-            wf[0][jn][pl] = wf[1][jn][pl];
-            wf[1][jn][pl] = wf[2][jn][pl];
-          }
+          for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) tmp[k][jn][pl] = wf[(16 + k) % RS][jn][pl];
+#pragma unroll
+        for (int k = 0; k < WD; ++k)
+#pragma unroll
+          for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) wf[k][jn][pl] = tmp[k][jn][pl];
       }
       if (!last_half) continue;                // (two passes: one column tile per wavefront, checked by the launcher)
       if constexpr (!LN) {

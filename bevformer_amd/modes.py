@@ -14,7 +14,7 @@ import threading
 import torch
 
 GEMM_MODES = ("split", "bf16", "native")
-GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128")
+GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w2", "panel64w6")
 
 
 class Modes:

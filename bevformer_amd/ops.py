@@ -645,7 +645,9 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     if blob is None:
         return False
     # panel shape: 128-row panels (half the weight traffic per MFMA, one workgroup per CU) pay from ~128 k rows on
-    desc.reserved[2] = {"panel64": 1, "panel128": 2}.get(_m().gemm_kernel) or (2 if desc.M >= (1 << 17) and ln is None else 1)
+    desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(_m().gemm_kernel) \
+        or (2 if desc.M >= (1 << 17) and ln is None else 1)
+    desc.reserved[3] = {"panel64w2": 2, "panel64w6": 6}.get(_m().gemm_kernel, 0)      # benchmark knob: weight prefetch depth
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()

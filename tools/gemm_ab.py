@@ -17,7 +17,7 @@ from bevformer_amd import ops  # noqa: E402
 from kbench import timeit  # noqa: E402
 
 DEV = "cuda:0"
-KERNELS = ("first", "panel64", "panel128")
+KERNELS = ("first", "panel64w2", "panel64w6", "panel128")
 SHAPES = [("sca_value_proj", 184950, 256, 0, 1536, 6, False), ("tsa_value_proj", 80000, 256, 0, 1536, 6, False),
           ("tsa_offs_attn", 40000, 256, 256, 192, 1, False), ("tsa_output_proj", 40000, 256, 0, 256, 1, False),
           ("sca_offs_attn", 40000, 256, 0, 768, 1, False), ("ffn_fc1", 40000, 256, 0, 512, 1, True),

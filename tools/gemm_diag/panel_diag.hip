@@ -3,6 +3,17 @@
 #include "../../include/bevmsda.h"
 #include "../../bevformer_amd/csrc/linear_panel.h"
 
+template <int WD>
+static void launch_wd(const bevmsda::PanelArgs &a, int nprod, int shape, dim3 grid, hipStream_t st) {
+  if (nprod == 3) {
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 2, 2, 4, false, 0, 0, 0, false, WD>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 4, 1, 8, false, 0, 0, 0, false, WD>), grid, dim3(512), 0, st, a);
+  } else {
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 2, 2, 4, false, 0, 0, 0, false, WD>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 4, 1, 8, false, 0, 0, 0, false, WD>), grid, dim3(512), 0, st, a);
+  }
+}
+
 template <int ST, int LD, bool DRIP = false>
 static void launch(const bevmsda::PanelArgs &a, int nprod, int shape, dim3 grid, hipStream_t st) {
   if (shape == 3) {
@@ -36,6 +47,9 @@ extern "C" int diag_panel_policy(const float *x, long ldx, const uint16_t *wp, u
     case 200: launch<0, 2>(a, nprod, shape, grid, st); break;
     case 216: launch<16, 2>(a, nprod, shape, grid, st); break;
     case 202: launch<2, 2>(a, nprod, shape, grid, st); break;
+    case 3003: launch_wd<3>(a, nprod, shape, grid, st); break;
+    case 3004: launch_wd<4>(a, nprod, shape, grid, st); break;
+    case 3006: launch_wd<6>(a, nprod, shape, grid, st); break;
     case 1000: launch<0, 0, true>(a, nprod, shape, grid, st); break;
     case 1200: launch<0, 2, true>(a, nprod, shape, grid, st); break;
     default: return -2;

@@ -22,8 +22,10 @@ lib.diag_panel.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctyp
 lib.diag_panel_policy.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_long, ctypes.c_long] + [ctypes.c_int] * 7 + [ctypes.c_void_p]
 DEV = torch.device("cuda:0")
-POLICIES = [(0, "burst stores, default fetch"), (200, "burst stores, nt fetch"), (1000, "paced stores, default fetch"),
-            (1200, "paced stores, nt fetch")]
+POLICIES = [(0, "weights 2 steps ahead (default)"), (3003, "weights 3 steps ahead"), (3004, "weights 4 steps ahead"),
+            (3006, "weights 6 steps ahead")]
+if "--paced" in sys.argv:
+    POLICIES += [(200, "burst stores, nt fetch"), (1000, "paced stores, default fetch"), (1200, "paced stores, nt fetch")]
 if "--policies" in sys.argv:
     POLICIES += [(2, "nt stores"), (16, "sc1 stores"), (18, "sc1 nt stores"), (216, "sc1 stores, nt fetch"), (202, "nt stores, nt fetch")]
 MASKS = [(0, "full kernel"), (1, "no MFMA after step 0"), (2, "no stores"), (4, "weight fragments: steps 0-1 only"),
@@ -58,7 +60,7 @@ for name, M, N, K, groups in (("sca_value_proj", 184950, 1536, 256, 6), ("output
     print(f"{name}: M {M} N {N} K {K}  (fp32 in {M * K * 4 / 1e6:.0f} MB, out {M * N * 4 / 1e6:.0f} MB)")
     want = torch.nn.functional.linear(x[:4096], w).view(4096, groups, N // groups).transpose(0, 1)
     for nprod in (3, 1):
-        for shape in (1, 2, 3):
+        for shape in (1, 2):
             for pol, label in POLICIES:
                 call = lambda: lib.diag_panel_policy(x.data_ptr(), K, blob.data_ptr(), blob.numel() * 2, None, y.data_ptr(), N // groups,
                                                      M, N, K, N // groups if groups > 1 else 0, nprod, shape, 0, pol, st)
