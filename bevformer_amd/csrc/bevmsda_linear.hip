@@ -10,6 +10,10 @@
 namespace {
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
 constexpr long long kLinearPipeMaxRows = 8192;   // ... and always for M <= this
+// linear_chain.h workgroup shape by measurement (tools/chain_small_m.py, profiles/r3): 32-row panels up to this many
+// rows (a rank's tile of a BEV-tiled frame: 5,000 rows 20 vs 28 us), 64-row panels above (40,000 rows: 103 vs 103-110 us,
+// half the weight traffic from L2)
+constexpr long long kChainSmallRows = 8192;
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 }  // namespace
 
@@ -290,7 +294,13 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
       (b0 && misaligned(b0)) || (b1 && misaligned(b1)) || (b2 && misaligned(b2)) || misaligned(gamma0) || misaligned(beta0) ||
       misaligned(gamma1) || misaligned(beta1))
     return BEVMSDA_ERR_MISALIGNED;
-  const long long nb = (d->M + bevmsda::kChainRows - 1) / bevmsda::kChainRows;
+  // workgroup shape (desc->reserved[1]): 1 = 64-row panels (8 wavefronts, one workgroup per CU), 2 = 32-row panels
+  // (4 wavefronts, two workgroups per CU); 0 = default
+  int shape = d->reserved[1];
+  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
+  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
+  const int bm = shape == 1 ? 64 : 32;
+  const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::ChainArgs a{};
   a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale;
@@ -298,14 +308,15 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = gamma1; a.beta1 = beta1;
   a.eps0 = d->eps0; a.eps1 = d->eps1; a.y = y; a.ld_y = d->ld_y; a.M = d->M;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(nb)), block(bevmsda::kChainWaves * 64);
-  if (d->precision == 0) {
-    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0>), grid, block, 0, st, a);
-  } else {
-    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0>), grid, block, 0, st, a);
-  }
+  const dim3 grid(static_cast<unsigned>(nb));
+#define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
+  do {                                                                                                                  \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
+  } while (0)
+  if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }
+  else { if (idx) BEVMSDA_CHAIN(1, 2); else BEVMSDA_CHAIN(1, 0); }
+#undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
@@ -325,7 +336,12 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
   if (misaligned(rows) || misaligned(w0p) || misaligned(w1p) || misaligned(x_out) || misaligned(proj_out) || (res && misaligned(res)) ||
       (b0 && misaligned(b0)) || (b1 && misaligned(b1)) || misaligned(gamma0) || misaligned(beta0))
     return BEVMSDA_ERR_MISALIGNED;
-  const long long nb = (d->M + bevmsda::kChainRows - 1) / bevmsda::kChainRows;
+  int shape = d->reserved[1];
+  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
+  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
+  if (d->F % 64 != 0) shape = 1;               // the 32-row shape walks 64-column tiles
+  const int bm = shape == 1 ? 64 : 32;
+  const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::ChainArgs a{};
   a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale;
@@ -333,14 +349,15 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = a.beta1 = nullptr;
   a.eps0 = d->eps0; a.eps1 = 0.f; a.y = x_out; a.ld_y = d->ld_y; a.M = d->M; a.y2 = proj_out; a.ld_y2 = ld_y2; a.N2 = d->F;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(nb)), block(bevmsda::kChainWaves * 64);
-  if (d->precision == 0) {
-    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 1>), grid, block, 0, st, a);
-  } else {
-    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 2, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0, 1>), grid, block, 0, st, a);
-  }
+  const dim3 grid(static_cast<unsigned>(nb));
+#define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
+  do {                                                                                                                  \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
+  } while (0)
+  if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }
+  else { if (idx) BEVMSDA_CHAIN(1, 2); else BEVMSDA_CHAIN(1, 0); }
+#undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

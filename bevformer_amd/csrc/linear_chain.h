@@ -70,22 +70,29 @@ struct ChainArgs {
 #define CHAIN_STAMP(k) do {} while (0)
 #endif
 
-constexpr int kChainRows = 64;      // rows per workgroup
-constexpr int kChainWaves = 8;      // wavefronts = 32-column tiles per stage
 constexpr int kChainC = 256, kChainF = 512;
-
 constexpr int kChainMaxN2 = 768;   // MODE 1: columns of the second projection (its bias is staged in LDS)
 
-// MODE 0: projection + norm + FFN + norm; MODE 1: projection + norm (stored) + a second projection of N2 columns
-template <int NPROD, int PRE, int MODE = 0>
-__global__ void __launch_bounds__(kChainWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// MODE 0: projection + norm + FFN + norm; MODE 1: projection + norm (stored) + a second projection of N2 columns.
+// Workgroup shape: MT x NT MFMA tiles of 32 x 32 per wavefront, NW wavefronts with NW * NT = 8 (the 256 columns of
+// every stage), BM = 32 MT rows:
+//   <2, 1, 8>  64 rows, 512 threads, 133 KiB of LDS: one workgroup per CU, every weight fragment feeds two row tiles;
+//   <1, 2, 4>  32 rows, 256 threads,  69 KiB of LDS: TWO workgroups per CU — one's fetch / LayerNorm / plane-write
+//              phases (58 % of a workgroup's cycles in the first shape: tools/gemm_diag/chain_run.py) run under the
+//              other's MFMAs, and 1,250 half-size workgroups quantise better over 256 CUs than 625 — at twice the
+//              weight traffic from L2 per row.
+template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
   static_assert(PRE == 0 || PRE == 2, "PRE: 0 plain rows, 2 two-row gather");
+  static_assert(NW * NT == 8 && (MT == 1 || MT == 2) && (NT == 1 || NT == 2), "workgroup shape");
   constexpr bool LO = NPROD == 3;
   constexpr int NPL = LO ? 2 : 1;
-  constexpr int MT = 2, NW = kChainWaves, BM = kChainRows;
-  constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: 64 KiB
+  constexpr int BM = MT * 32;
+  constexpr int NTHREADS = NW * 64;
+  constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: BM KiB
+  constexpr int PPW = (BM / 8) * 4 / NW;       // (row block, line pair) DMA pairs per wavefront
   constexpr int NCST = 4 * kChainC + kChainMaxN2 + 2 * kChainC;       // gamma0, beta0, gamma1, beta1 | b1 | b0, b2
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4 + NCST * 4];
   unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
@@ -106,7 +113,7 @@ linear_chain_kernel(const ChainArgs a) {
 
   {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t4 = tid * 4; t4 < NCST; t4 += kChainWaves * 64 * 4) {
+    for (int t4 = tid * 4; t4 < NCST; t4 += NTHREADS * 4) {
       const float *src = nullptr;
       if (t4 < 256) src = a.gamma0 + t4;
       else if (t4 < 512) src = a.beta0 + (t4 - 256);
@@ -128,33 +135,40 @@ linear_chain_kernel(const ChainArgs a) {
 #pragma unroll
   for (int sc = 0; sc < 4; ++sc)
     f_addr[sc] = static_cast<unsigned>(f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * sc + f_h) ^ f_x))) * 16);
-  // accumulator -> plane write addresses: this lane's value (row i * 32 + f_r, column 32 w + 4 f_h + 8 g + e) is
-  // k = that column of the next stage: line w (pair w >> 1, slot half w & 1), 16-byte column c = f_h + 2 g
-  unsigned p_addr[4];
+  // accumulator -> plane write addresses: this lane's value (row i * 32 + f_r, column 32 (NT w + j) + 4 f_h + 8 g + e)
+  // is k = that column of the next stage: line NT w + j (pair line >> 1, slot half line & 1), 16-byte column f_h + 2 g
+  unsigned p_addr[NT][4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    p_addr[g] = static_cast<unsigned>((f_q0 * 4 + (wave >> 1)) * 2048 + (f_rl * 8 + ((f_h + 2 * g) ^ f_x)) * 16 + (wave & 1) * 8);
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int line = NT * wave + j;
+      p_addr[j][g] = static_cast<unsigned>((f_q0 * 4 + (line >> 1)) * 2048 + (f_rl * 8 + ((f_h + 2 * g) ^ f_x)) * 16 + (line & 1) * 8);
+    }
 
   const int wlane = lane * 16;
-  lin_f32x16 acc[MT], xk[MT], acc2[MT];
+  lin_f32x16 acc[MT][NT], xk[MT][NT], acc2[MODE == 0 ? MT : 1][MODE == 0 ? NT : 1];
 
-  constexpr int WD = 2;                        // weight fragments in flight (k16 steps ahead): 4 measured no faster: 122 vs 115-118 us
-  lin_bf16x8 wf[WD + 1][NPL];                  // ring over k16 steps
-  auto wload = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int st, int sg) {
+  constexpr int WD = 2;                        // weight fragments in flight (k16 steps ahead); 4 measured no faster
+  lin_bf16x8 wf[WD + 1][NT][NPL];              // ring over k16 steps
+  // column tile `tile` (32 NT columns) of a weight image with `nstep` k16 steps per 32-row tile
+  auto wload = [&](__amdgpu_buffer_rsrc_t wrsrc, int tile, int nstep, int st, int sg) {
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
-      wf[st][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      wrsrc, wlane, ((T32 * nstep + sg) * 2 + pl) * 1024, 0));
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        wf[st][j][pl] = __builtin_bit_cast(lin_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wrsrc, wlane, (((tile * NT + j) * nstep + sg) * 2 + pl) * 1024, 0));
   };
   // the first WD weight fragments of a stage, requested before the previous stage's epilogue / the barrier in front
   // of it (an L2 round trip that would otherwise open every stage)
-  auto wprefetch = [&](__amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
+  auto wprefetch = [&](__amdgpu_buffer_rsrc_t wrsrc, int tile, int nstep, int sg0) {
 #pragma unroll
-    for (int k = 0; k < WD; ++k) wload(wrsrc, T32, nstep, k, sg0 + k);
+    for (int k = 0; k < WD; ++k) wload(wrsrc, tile, nstep, k, sg0 + k);
   };
-  // acc = planes(buf) x W[tile T32, k16 steps sg0 .. sg0 + 15]^T   (one 64 x 32 tile, K = 256); ring stages 0 .. WD - 1 hold
-  // steps sg0 .. sg0 + WD - 1 already (wprefetch)
-  auto gemm16 = [&](lin_f32x16 (&c)[MT], const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int T32, int nstep, int sg0) {
+  // c += planes(buf) x W[column tile, k16 steps sg0 .. sg0 + 15]^T   (K = 256); ring stages 0 .. WD - 1 hold steps
+  // sg0 .. sg0 + WD - 1 already (wprefetch)
+  auto gemm16 = [&](auto &c, const unsigned char *buf, __amdgpu_buffer_rsrc_t wrsrc, int tile, int nstep, int sg0) {
     lin_bf16x8 af[2][MT][NPL];
     auto aload = [&](int set, int s) {
       const unsigned base = f_addr[s & 3] + (s >> 2) * 2048;
@@ -167,54 +181,64 @@ linear_chain_kernel(const ChainArgs a) {
     aload(0, 0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      if (s + WD < 16) wload(wrsrc, T32, nstep, (s + WD) % (WD + 1), sg0 + s + WD);
+      if (s + WD < 16) wload(wrsrc, tile, nstep, (s + WD) % (WD + 1), sg0 + s + WD);
       if (s + 1 < 16) aload((s + 1) & 1, s + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if (LO) {
-          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][0], af[s & 1][i][1], c[i], 0, 0, 0);
-          c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][1], af[s & 1][i][0], c[i], 0, 0, 0);
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (LO) {
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][0], af[s & 1][i][1], c[i][j], 0, 0, 0);
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][1], af[s & 1][i][0], c[i][j], 0, 0, 0);
+          }
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][0], af[s & 1][i][0], c[i][j], 0, 0, 0);
         }
-        c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][0], af[s & 1][i][0], c[i], 0, 0, 0);
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto zero = [&](lin_f32x16 (&c)[MT]) {
+  auto zero = [&](auto &c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
   };
   // the tile as [hi | lo] planes of the next stage's activation panel
-  auto to_planes = [&](const lin_f32x16 (&c)[MT], unsigned char *buf) {
+  auto to_planes = [&](const auto &c, unsigned char *buf) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v0 = c[i][4 * g], v1 = c[i][4 * g + 1], v2 = c[i][4 * g + 2], v3 = c[i][4 * g + 3];
-        uint2 hi, lo;
-        hi.x = lin_pack2(v0, v1);
-        hi.y = lin_pack2(v2, v3);
-        unsigned char *dst = buf + p_addr[g] + i * (4 * 4 * 2048);
-        *reinterpret_cast<uint2 *>(dst) = hi;
-        if (LO) {
-          lo.x = lin_pack2(v0 - __uint_as_float(hi.x << 16), v1 - __uint_as_float(hi.x & 0xffff0000u));
-          lo.y = lin_pack2(v2 - __uint_as_float(hi.y << 16), v3 - __uint_as_float(hi.y & 0xffff0000u));
-          *reinterpret_cast<uint2 *>(dst + 1024) = lo;
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v0 = c[i][j][4 * g], v1 = c[i][j][4 * g + 1], v2 = c[i][j][4 * g + 2], v3 = c[i][j][4 * g + 3];
+          uint2 hi, lo;
+          hi.x = lin_pack2(v0, v1);
+          hi.y = lin_pack2(v2, v3);
+          unsigned char *dst = buf + p_addr[j][g] + i * (4 * 4 * 2048);
+          *reinterpret_cast<uint2 *>(dst) = hi;
+          if (LO) {
+            lo.x = lin_pack2(v0 - __uint_as_float(hi.x << 16), v1 - __uint_as_float(hi.x & 0xffff0000u));
+            lo.y = lin_pack2(v2 - __uint_as_float(hi.y << 16), v3 - __uint_as_float(hi.y & 0xffff0000u));
+            *reinterpret_cast<uint2 *>(dst + 1024) = lo;
+          }
         }
-      }
   };
-  // LayerNorm over the 256 columns of every row of the tile set (8 wavefronts x 32 columns), in place; two-pass
+  // columns of this lane's accumulator registers: ncol(j) + 8 g + e
+  auto ncol = [&](int j) { return (NT * wave + j) * 32 + 4 * (lane >> 5); };
+  // LayerNorm over the 256 columns of every row of the tile set (NW wavefronts x 32 NT columns), in place; two-pass
   // statistics, exchanged through LDS (torch.nn.LayerNorm: biased variance, eps inside the square root)
-  auto layernorm = [&](lin_f32x16 (&c)[MT], const float *gamma, const float *beta, float eps) {
+  auto layernorm = [&](auto &c, const float *gamma, const float *beta, float eps) {
     float mean[MT], rstd[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum += c[i][r];
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += c[i][j][r];
       sum += __shfl_xor(sum, 32, 64);
       mean[i] = sum;
     }
@@ -235,10 +259,12 @@ linear_chain_kernel(const ChainArgs a) {
     for (int i = 0; i < MT; ++i) {
       float ss = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d = c[i][r] - mean[i];
-        ss = fmaf(d, d, ss);
-      }
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = c[i][j][r] - mean[i];
+          ss = fmaf(d, d, ss);
+        }
       ss += __shfl_xor(ss, 32, 64);
       rstd[i] = ss;
     }
@@ -254,44 +280,58 @@ linear_chain_kernel(const ChainArgs a) {
       for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
       rstd[i] = rsqrtf(t * (1.0f / kChainC) + eps);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = wave * 32 + 4 * (lane >> 5) + 8 * g;
-        const float4 ga = *reinterpret_cast<const float4 *>(gamma + n);
-        const float4 be = *reinterpret_cast<const float4 *>(beta + n);
-        c[i][4 * g] = (c[i][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
-        c[i][4 * g + 1] = (c[i][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
-        c[i][4 * g + 2] = (c[i][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
-        c[i][4 * g + 3] = (c[i][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
-      }
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = ncol(j) + 8 * g;
+          const float4 ga = *reinterpret_cast<const float4 *>(gamma + n);
+          const float4 be = *reinterpret_cast<const float4 *>(beta + n);
+          c[i][j][4 * g] = (c[i][j][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
+          c[i][j][4 * g + 1] = (c[i][j][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;
+          c[i][j][4 * g + 2] = (c[i][j][4 * g + 2] - mean[i]) * rstd[i] * ga.z + be.z;
+          c[i][j][4 * g + 3] = (c[i][j][4 * g + 3] - mean[i]) * rstd[i] * ga.w + be.w;
+        }
     }
     __syncthreads();                           // `stat` may be written again
+  };
+  // c[i][j][4g .. 4g+3] += vec[ncol(j) + 8 g ..] (a per-column constant from LDS)
+  auto add_cols = [&](auto &c, const float *vec, int col0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4 *>(vec + col0 + ncol(j) + 8 * g);
+          c[i][j][4 * g] += v.x; c[i][j][4 * g + 1] += v.y; c[i][j][4 * g + 2] += v.z; c[i][j][4 * g + 3] += v.w;
+        }
   };
 
   const unsigned w0b = 8u * 16 * 2 * 1024, w1b = static_cast<unsigned>((nb1 + 63) / 64 * 2) * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
   __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
   __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(MODE == 0 ? a.w2 : a.w0), 0, static_cast<int>(MODE == 0 ? w2b : w0b), 0x00020000);
-
-  // rows and columns of this lane's accumulator registers
-  const int ncol = wave * 32 + 4 * (lane >> 5);        // + 8 g + e
   long mrow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) mrow[i] = m0 + i * 32 + (lane & 31);
   // the residual rows of stage 0 and its first weight fragments travel under the panel fetch
-  float4 rs[MT][4];
+  float4 rs[MT][NT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const float *rrow = a.res ? a.res + (mrow[i] < a.M ? mrow[i] : a.M - 1) * a.ld_res : nullptr;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      rs[i][g] = rrow ? *reinterpret_cast<const float4 *>(rrow + ncol + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        rs[i][j][g] = rrow ? *reinterpret_cast<const float4 *>(rrow + ncol(j) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   wprefetch(r0, wave, 16, 0);
 
   // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
   {
     const int d_rl = lane >> 3, d_cc = lane & 7;
-    const int row = panel_row_of(wave, d_rl);  // 8 row blocks, one per wavefront; 4 line pairs each
+    const int row = panel_row_of(wave * PPW / 4, d_rl);   // PPW / 4 row blocks per wavefront (here: one)
+    static_assert(PPW == 4, "one row block (4 line pairs) per wavefront");
     const int cx = d_cc ^ (row & 7);
     long gm = m0 + row;
     if (gm >= a.M) gm = a.M - 1;               // clamped rows are computed and never stored
@@ -347,111 +387,91 @@ linear_chain_kernel(const ChainArgs a) {
   gemm16(acc, buf0, r0, wave, 16, 0);
   CHAIN_STAMP(1);                              // GEMM 0
   wprefetch(r1, wave, 16, 0);
+  add_cols(acc, c_b0, 0);
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = ncol + 8 * g;
-      float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-      v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b0 + n));
-      v = lin_add4(v, rs[i][g]);
-      acc[i][4 * g] = v.x; acc[i][4 * g + 1] = v.y; acc[i][4 * g + 2] = v.z; acc[i][4 * g + 3] = v.w;
-    }
-  }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc[i][j][4 * g] += rs[i][j][g].x; acc[i][j][4 * g + 1] += rs[i][j][g].y;
+        acc[i][j][4 * g + 2] += rs[i][j][g].z; acc[i][j][4 * g + 3] += rs[i][j][g].w;
+      }
   layernorm(acc, c_g0, c_be0, a.eps0);
 #pragma unroll
-  for (int i = 0; i < MT; ++i) xk[i] = acc[i];
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xk[i][j] = acc[i][j];
   to_planes(xk, buf1);
   __syncthreads();                             // x planes complete (and every wavefront is done with buffer 0)
   CHAIN_STAMP(2);                              // bias + residual + LayerNorm 0 + plane write
 
-  if constexpr (MODE == 1) {
-    // x is the next attention's residual: store it, then project it (from its planes) tile by tile
+  auto store_tile = [&](const auto &c, float *out, long ld, int col0) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if (mrow[i] >= a.M) continue;
-      float *yrow = a.y + mrow[i] * a.ld_y;
+      float *yrow = out + mrow[i] * ld + col0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4 *>(yrow + ncol + 8 * g) =
-            make_float4(xk[i][4 * g], xk[i][4 * g + 1], xk[i][4 * g + 2], xk[i][4 * g + 3]);
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(yrow + j * 32 + 4 * (lane >> 5) + 8 * g) =
+              make_float4(c[i][j][4 * g], c[i][j][4 * g + 1], c[i][j][4 * g + 2], c[i][j][4 * g + 3]);
     }
-    const int ntile = a.N2 / 32;
+  };
+
+  if constexpr (MODE == 1) {
+    // x is the next attention's residual: store it, then project it (from its planes) tile by tile
+    store_tile(xk, a.y, a.ld_y, NT * wave * 32);
+    const int ntile = a.N2 / (32 * NT);        // (N2 a multiple of 32 NT: checked by the launcher)
 #pragma unroll 1
     for (int t = wave; t < ntile; t += NW) {
       zero(acc);
       gemm16(acc, buf1, r1, t, 16, 0);
       if (t + NW < ntile) wprefetch(r1, t + NW, 16, 0);
-      const int nc = t * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if (mrow[i] >= a.M) continue;
-        float *prow = a.y2 + mrow[i] * a.ld_y2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-          v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b1 + nc + 8 * g));
-          *reinterpret_cast<float4 *>(prow + nc + 8 * g) = v;
-        }
-      }
+      // (bias of tile t: columns 32 NT t ..; add_cols indexes by this wavefront's own tile, so shift)
+      add_cols(acc, c_b1, (t - wave) * 32 * NT);
+      store_tile(acc, a.y2, a.ld_y2, t * 32 * NT);
     }
     return;
-  }
-
-  // ------------------------------------------------------------------ FFN, the hidden layer in two halves of 256
-  zero(acc2);
+  } else {
+    // ---------------------------------------------------------------- FFN, the hidden layer in two halves of 256
+    zero(acc2);
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    zero(acc);
-    gemm16(acc, buf1, r1, half * 8 + wave, 16, 0);
-    CHAIN_STAMP(3 + 3 * half);                 // GEMM 1 (half)
-    wprefetch(r2, wave, 32, half * 16);
+    for (int half = 0; half < 2; ++half) {
+      zero(acc);
+      gemm16(acc, buf1, r1, half * NW + wave, 16, 0);
+      CHAIN_STAMP(3 + 3 * half);               // GEMM 1 (half)
+      wprefetch(r2, wave, 32, half * 16);
+      add_cols(acc, c_b1, half * 256);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] < 0.f ? 0.f : acc[i][j][r];     // NaN stays NaN, as torch.relu
+      to_planes(acc, buf0);
+      __syncthreads();                         // this half of the hidden layer is complete
+      CHAIN_STAMP(4 + 3 * half);               // bias + ReLU + plane write
+      gemm16(acc2, buf0, r2, wave, 32, half * 16);
+      if (half == 0) wprefetch(r1, NW + wave, 16, 0);
+      __syncthreads();                         // ... and consumed: buffer 0 may be rewritten
+      CHAIN_STAMP(5 + 3 * half);               // GEMM 2 (half)
+    }
+
+    // ---------------------------------------------------------------- y = LN1(x + ffn(x))
+    add_cols(acc2, c_b2, 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = half * 256 + ncol + 8 * g;
-        float4 v = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-        v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b1 + n));
-        acc[i][4 * g] = v.x < 0.f ? 0.f : v.x;      // NaN stays NaN, as torch.relu
-        acc[i][4 * g + 1] = v.y < 0.f ? 0.f : v.y;
-        acc[i][4 * g + 2] = v.z < 0.f ? 0.f : v.z;
-        acc[i][4 * g + 3] = v.w < 0.f ? 0.f : v.w;
-      }
-    to_planes(acc, buf0);
-    __syncthreads();                           // this half of the hidden layer is complete
-    CHAIN_STAMP(4 + 3 * half);                 // bias + ReLU + plane write
-    gemm16(acc2, buf0, r2, wave, 32, half * 16);
-    if (half == 0) wprefetch(r1, 8 + wave, 16, 0);
-    __syncthreads();                           // ... and consumed: buffer 0 may be rewritten
-    CHAIN_STAMP(5 + 3 * half);                 // GEMM 2 (half)
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] += xk[i][j][r];
+    layernorm(acc2, c_g1, c_be1, a.eps1);
+    CHAIN_STAMP(9);                            // bias + residual + LayerNorm 1
+    store_tile(acc2, a.y, a.ld_y, NT * wave * 32);
+    CHAIN_STAMP(10);                           // stores issued
   }
-
-  // ------------------------------------------------------------------ y = LN1(x + ffn(x))
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = ncol + 8 * g;
-      float4 v = make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
-      v = lin_add4(v, *reinterpret_cast<const float4 *>(c_b2 + n));
-      acc2[i][4 * g] = v.x + xk[i][4 * g];
-      acc2[i][4 * g + 1] = v.y + xk[i][4 * g + 1];
-      acc2[i][4 * g + 2] = v.z + xk[i][4 * g + 2];
-      acc2[i][4 * g + 3] = v.w + xk[i][4 * g + 3];
-    }
-  layernorm(acc2, c_g1, c_be1, a.eps1);
-  CHAIN_STAMP(9);                              // bias + residual + LayerNorm 1
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    if (mrow[i] >= a.M) continue;
-    float *yrow = a.y + mrow[i] * a.ld_y;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4 *>(yrow + ncol + 8 * g) =
-          make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
-  }
-  CHAIN_STAMP(10);                             // stores issued
 }
 
 }  // namespace bevmsda

@@ -956,6 +956,7 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
         return y.view(*lead, 256)
     desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=512, precision=0 if m.gemm == "split" else 1,
                           eps0=float(norm0.eps), eps1=float(norm1.eps))
+    desc.reserved[1] = m.chain_shape
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     flops = 2.0 * M * (256 * 256 + 2 * 256 * 512)
@@ -1019,6 +1020,7 @@ def proj_ln_proj_chain(rows, weight, bias, res, norm0, w1, b1, *, tag="proj_ln_p
     desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=N2, precision=0 if m.gemm == "split" else 1,
                           eps0=float(norm0.eps), eps1=0.0)
     desc.reserved[0] = N2
+    desc.reserved[1] = m.chain_shape
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, 2.0 * M * 256 * (256 + N2), 4.0 * (M * 256 * 3 + M * N2 + 256 * 256 + N2 * 256)) if cb is not None else _NoTimer()

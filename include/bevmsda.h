@@ -416,7 +416,8 @@ typedef struct bevmsda_chain_desc {
   int32_t C, F;                  /* embedding and hidden width */
   int32_t precision;             /* as bevmsda_linear_desc */
   float eps0, eps1;
-  int32_t reserved[5];           /* [0]: bevmsda_proj_ln_proj_chain_f32: row stride of proj_out in floats */
+  int32_t reserved[5];           /* [0]: bevmsda_proj_ln_proj_chain_f32: row stride of proj_out in floats; [1]: workgroup
+                                    shape, 0 = default, 1 = 64-row panels (one workgroup per CU), 2 = 32-row panels (two) */
 } bevmsda_chain_desc;
 
 int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,

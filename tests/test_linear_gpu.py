@@ -434,9 +434,10 @@ def test_linear_row_panel_layernorm_and_gather(gemm_mode, kernel):
     torch.testing.assert_close(got5.double(), want5, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [1, 2])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
 @pytest.mark.parametrize("M,with_gather", [(641, True), (4099, False), (64, True), (1, False)])
-def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, with_gather):
+def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, with_gather, shape):
     """``bevmsda_proj_ffn_chain_f32`` (csrc/linear_chain.h): output projection (+ camera gather) + residual + LayerNorm
     + FFN + residual + LayerNorm in one kernel against the same chain as three launches of the row-panel kernel (the
     intermediate x and hidden activations are split from the same fp32 values: differences come from the order of the
@@ -461,7 +462,7 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
             n.bias.copy_(_rand(256, seed=s + 1) * 0.1)
         gather = (idx, scale) if with_gather else None
         src = rows if with_gather else rows[:M]
-        with ops.using(ln_fuse=True, gemm_kernel="panel64"):
+        with ops.using(ln_fuse=True, gemm_kernel="panel64", chain_shape=shape):
             got = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather)
             x = ops.linear_layernorm(src, w0, b0, res, n0, gather=gather)
             h = ops.linear(x, fc1.weight, fc1.bias, relu=True)
@@ -482,9 +483,10 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
     torch.testing.assert_close(got.double(), y64, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("shape", [1, 2])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
 @pytest.mark.parametrize("M,N2", [(641, 768), (4099, 192), (64, 96), (5000, 768)])
-def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M, N2):
+def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M, N2, shape):
     """``bevmsda_proj_ln_proj_chain_f32`` (csrc/linear_chain.h, MODE 1): output projection + residual + LayerNorm (stored)
     + the next attention's projection of the normed rows, against the LayerNorm-fused projection followed by a plain
     projection, and against the fp64 statement."""
@@ -496,7 +498,7 @@ def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M
     with torch.no_grad():
         n0.weight.copy_(_rand(256, seed=97) * 0.2 + 1.0)
         n0.bias.copy_(_rand(256, seed=98) * 0.1)
-        with ops.using(ln_fuse=True):
+        with ops.using(ln_fuse=True, chain_shape=shape):
             got = ops.proj_ln_proj_chain(rows, w0, b0, res, n0, w1, b1)
             x = ops.linear_layernorm(rows, w0, b0, res, n0)
         with ops.using(gemm_kernel="first"):

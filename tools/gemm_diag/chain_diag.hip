@@ -5,13 +5,20 @@
 
 extern "C" int diag_chain(const float *rows, long ld_rows, const int32_t *idx, const float *scale, const uint16_t *w0, const float *b0,
                           const float *res, const float *g0, const float *be0, const uint16_t *w1, const float *b1, const uint16_t *w2,
-                          const float *b2, const float *g1, const float *be1, long M, float *y, unsigned long long *prof, void *stream) {
+                          const float *b2, const float *g1, const float *be1, long M, float *y, unsigned long long *prof, int shape, void *stream) {
   bevmsda::ChainArgs a{};
   a.rows = rows; a.ld_rows = ld_rows; a.gidx = idx; a.gscale = scale; a.w0 = w0; a.w1 = w1; a.w2 = w2; a.b0 = b0; a.b1 = b1; a.b2 = b2;
   a.res = res; a.ld_res = 256; a.gamma0 = g0; a.beta0 = be0; a.gamma1 = g1; a.beta1 = be1; a.eps0 = a.eps1 = 1e-5f;
   a.y = y; a.ld_y = 256; a.M = M; a.prof = prof;
-  const dim3 grid(static_cast<unsigned>((M + 63) / 64)), block(512);
-  if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2>), grid, block, 0, static_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0>), grid, block, 0, static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (shape == 1) {
+    const dim3 grid(static_cast<unsigned>((M + 63) / 64)), block(512);
+    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2, 0, 2, 1, 8>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 0, 2, 1, 8>), grid, block, 0, st, a);
+  } else {
+    const dim3 grid(static_cast<unsigned>((M + 31) / 32)), block(256);
+    if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2, 0, 1, 2, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 0, 1, 2, 4>), grid, block, 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

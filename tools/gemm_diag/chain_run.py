@@ -15,7 +15,7 @@ so, src = os.path.join(HERE, "libchaindiag.so"), os.path.join(HERE, "chain_diag.
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", src, "-o", so], check=True)
 lib = ctypes.CDLL(so)
-lib.diag_chain.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 13 + [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.diag_chain.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 13 + [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 DEV = torch.device("cuda:0")
 M, R = 40000, 45960
 g = torch.Generator().manual_seed(0)
@@ -33,9 +33,10 @@ p0, p1, p2 = ops.panel_weight(w0), ops.panel_weight(w1), ops.panel_weight(w2)
 y = torch.empty(M, 256, device=DEV)
 prof = torch.zeros(12, dtype=torch.int64, device=DEV)
 st = torch.cuda.current_stream().cuda_stream
+SHAPE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 call = lambda: lib.diag_chain(rows.data_ptr(), 256, idx.data_ptr(), scale.data_ptr(), p0.data_ptr(), b0.data_ptr(), res.data_ptr(),
                               ga.data_ptr(), be.data_ptr(), p1.data_ptr(), b1.data_ptr(), p2.data_ptr(), b2.data_ptr(), ga.data_ptr(),
-                              be.data_ptr(), M, y.data_ptr(), prof.data_ptr(), st)
+                              be.data_ptr(), M, y.data_ptr(), prof.data_ptr(), SHAPE, st)
 for _ in range(3):
     call()
 torch.cuda.synchronize()
@@ -50,8 +51,8 @@ torch.cuda.synchronize()
 names = ["panel fetch + split", "GEMM 0 (out_proj)", "bias + res + LayerNorm 0 + planes", "GEMM 1 half 0", "bias + ReLU + planes",
          "GEMM 2 half 0", "GEMM 1 half 1", "bias + ReLU + planes", "GEMM 2 half 1", "bias + res + LayerNorm 1", "stores"]
 p = prof.cpu().tolist()
-nb = (M + 63) // 64
-print(f"launch {a.elapsed_time(b) / N * 1e3:.1f} us (with the clock stamps); {nb} workgroups; cycles per workgroup and phase (mean):")
+nb = (M + 63) // 64 if SHAPE == 1 else (M + 31) // 32
+print(f"shape {SHAPE}: launch {a.elapsed_time(b) / N * 1e3:.1f} us (with the clock stamps); {nb} workgroups; cycles per workgroup and phase (mean):")
 tot = sum(p[:11])
 for n, c in zip(names, p):
     print(f"   {n:36s} {c / N / nb:9.0f} clk  {100.0 * c / tot:5.1f} %")
