@@ -519,7 +519,7 @@ def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 
            "t1_ms": t1_ms, "replicated_value_projections_us": replicated_us,
            "status": "per-rank times measured on one GPU; collective modelled; unmeasured on multi-GPU hardware"}
     for G in worlds:
-        per_rank = []
+        per_rank, cams = [], []
         for r in range(G):
             bev_tiling.enable_bev_tiling(cfg.enc, simulate=(r, G))
             for _ in range(2):
@@ -534,11 +534,14 @@ def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 
                     torch.cuda.synchronize()
             ts = timed_windows(cfg, cfg.encoder_step, fence, 10, 3, graph)
             per_rank.append(statistics.median(ts) / 10 * 1e3)
+            seg = getattr(cfg.enc, "_last_segments", None)
+            cams.append(int(((seg[0][1:] - seg[0][:-1]) > 0).sum()) if seg is not None else None)
             del graph
         shard = cfg.Q / G * 256 * 4
         ag_us = LAT_US + shard * (G - 1) / (min(G - 1, 7) * LINK_GBS * 1e9) * 1e6
         T = max(per_rank) + ag_us * 1e-3
-        out[str(G)] = dict(per_rank_ms=[round(p, 4) for p in per_rank], all_gather_model_us=ag_us, step_ms=T,
+        out[str(G)] = dict(per_rank_ms=[round(p, 4) for p in per_rank], cameras_projected_per_rank=cams,
+                           all_gather_model_us=ag_us, step_ms=T,
                            queries_per_s=cfg.Q / (T * 1e-3), efficiency=t1_ms / (G * T),
                            amdahl_bound_efficiency=t1_ms / (G * (replicated_us * 1e-3 + (t1_ms - replicated_us * 1e-3) / G))
                            if replicated_us else None)

@@ -166,7 +166,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     x = full_query[:, q0:q1].contiguous()
     inter = []
     # replicated, layer-invariant value projections: one grouped GEMM each (encoder.py docstring)
-    sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value)
+    # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
+    sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value, plan=tile if world > 1 else None)
     for li, layer in enumerate(encoder.layers):
         hoisted = {}
         if sca_vals is not None:

@@ -203,9 +203,10 @@ int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
-int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
-                             const float *scale, const uint16_t *wpanel, const float *bias,
-                             const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream) {
+static int panel_launch(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
+                        const float *scale, const uint16_t *wpanel, const float *bias,
+                        const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream,
+                        const int32_t *seg_start, int64_t seg_len) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0 || d->group_cols < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -233,6 +234,8 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
   a.bias = bias; a.y = y; a.ldy = d->ldy; a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1;
   a.relu = d->relu ? 1 : 0; a.group_cols = gcols; a.out_bf16 = d->out_bf16 ? 1 : 0;
   a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
+  a.seg_start = seg_start; a.seg_len = seg_len;
+  if (seg_start && seg_len <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (ln) {
     if (d->N != 256 || gcols != 0 || d->relu || d->out_bf16) return BEVMSDA_ERR_UNSUPPORTED;
     if (!ln->gamma || !ln->beta) return BEVMSDA_ERR_NULL_POINTER;
@@ -274,6 +277,18 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
 #undef BEVMSDA_PANEL2
 #undef BEVMSDA_PANEL
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
+                             const float *scale, const uint16_t *wpanel, const float *bias,
+                             const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream) {
+  return panel_launch(x0, a0, x1, a1, idx, scale, wpanel, bias, d, ln, y, stream, nullptr, 0);
+}
+
+int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, const float *bias, const bevmsda_linear_desc *d,
+                                      const int32_t *seg_start, int64_t seg_len, float *y, void *stream) {
+  if (!seg_start) return BEVMSDA_ERR_NULL_POINTER;
+  return panel_launch(x0, nullptr, nullptr, nullptr, nullptr, nullptr, wpanel, bias, d, nullptr, y, stream, seg_start, seg_len);
 }
 
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)

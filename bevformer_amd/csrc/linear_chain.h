@@ -188,7 +188,7 @@ linear_chain_kernel(const ChainArgs a) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          if (LO) {
+          if constexpr (LO) {
             c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][0], af[s & 1][i][1], c[i][j], 0, 0, 0);
             c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][1], af[s & 1][i][0], c[i][j], 0, 0, 0);
           }

@@ -58,6 +58,10 @@ struct PanelArgs {
   long ldres;
   const float *gamma, *beta;
   float eps;
+  // row segments (e.g. one per camera): a workgroup whose rows all lie in segments with no entry — seg_start[s + 1] ==
+  // seg_start[s], read from DEVICE memory when the kernel runs — computes and stores nothing
+  const int32_t *seg_start;         // (ceil(M / seg_len) + 1) or nullptr
+  long seg_len;
 #ifdef BEVMSDA_PANEL_DIAG
   int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
                                     //   3 activation fragments of step 0 only, 4 no panel fetch / split
@@ -134,6 +138,13 @@ linear_panel_kernel(const PanelArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA bases and buffer soffsets are scalar operands
   const long m0 = static_cast<long>(blockIdx.x) * BM;
+  if (a.seg_start != nullptr) {                // unused row segments: nobody will read their outputs
+    const long last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+    const int s_lo = static_cast<int>(m0 / a.seg_len), s_hi = static_cast<int>(last / a.seg_len);
+    int used = 0;
+    for (int sg = s_lo; sg <= s_hi; ++sg) used |= a.seg_start[sg + 1] - a.seg_start[sg];
+    if (used == 0) return;                     // (uniform over the workgroup)
+  }
   const int K = a.K0 + a.K1;
   const int nhalf = K / kPanelK;
   const int nstep = K / 16;                    // k16 steps of the whole K axis (weight image stride)

@@ -124,7 +124,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._plan_cache[key] = plan
         return plan
 
-    def hoisted_value_projections(self, value, tsa_value):
+    def hoisted_value_projections(self, value, tsa_value, plan=None):
         """The layer-invariant projections, issued once for all layers.
 
         The inputs of ``MSDeformableAttention3D.value_proj`` (camera features,
@@ -134,6 +134,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         layer; only the weights do.  The reference streams the 189 MB of camera features six
         times; here one grouped GEMM reads each input once and writes every layer's
         projected value (``ops.linear(groups=num_layers)``).  Inference path only.
+        ``plan``: a TILE's device-side frame plan (BEV tiling over GPUs): cameras none of whose pixels the tile's
+        queries can sample (no ragged row: a device-side count) are skipped by the camera-value projection.
         Returns (per-layer SCA values or None, per-layer TSA values or None)."""
         from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
         from .temporal_self_attention import TemporalSelfAttention
@@ -156,6 +158,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
         w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
         store = ops.value_storage()          # bf16 storage: the GEMM rounds its fp32 result on the way out
         self._sca_ready = None
+        seg = None
+        if plan is not None and getattr(plan, "dynamic", False) and plan.cam_start is not None \
+                and plan.cam_start.numel() == bs * Nc + 1:
+            seg = (plan.cam_start, S)        # rows of (batch entry, camera) = one segment of S feature rows
+        self._last_segments = seg            # (bench.py reports how many cameras a rank projects)
         if self.overlap_value_proj and ops._GEMM_TIMER["cb"] is None:
             cur = torch.cuda.current_stream(value.device)
             if self._side_stream is None or self._side_stream.device != value.device:
@@ -164,12 +171,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
             ops.packed_weight(w)                       # (weight image built on the main stream, once)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj")
+                y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj", segments=seg)
                 if y is not None:
                     self._sca_ready = side.record_event()
                     y.record_stream(cur)
         else:
-            y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj")
+            y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj", segments=seg)
         if y is not None:
             M = scas[0].num_heads
             sca_vals = [y[i].view(bs * Nc, S, M, -1) for i in range(L)]

@@ -541,6 +541,9 @@ def gather_mean_autograd(rows, idx, scale, row_slot):
 # ---------------------------------------------------------------------------
 GEMM_MODES = _modes.GEMM_MODES
 _GEMM_TIMER = {"cb": None}
+# test hook: outputs of launches that may leave row segments unwritten are pre-filled with NaN, so a consumer that
+# reads a skipped row cannot go unnoticed (tests/test_frame_plan_gpu.py)
+_SEGMENT_POISON = {"on": False, "launches": 0}
 
 
 def set_gemm_mode(mode):
@@ -639,8 +642,10 @@ def _panel_covers(N, K0, K1, groups, ln):
     return groups == 1 or (N // groups) % 64 == 0
 
 
-def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbytes):
-    """One launch of the row-panel kernel; returns False when the library declines the call."""
+def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbytes, segments=None):
+    """One launch of the row-panel kernel; returns False when the library declines the call.  ``segments =
+    (seg_start int32 device tensor, seg_len)``: only row segments with entries are computed
+    (``bevmsda_linear_panel_segments_f32``)."""
     blob = panel_weight(w)
     if blob is None:
         return False
@@ -653,9 +658,13 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
     p = lambda t: _ptr(t) if t is not None else None
     with torch.cuda.device(x0.device), ctx:
-        rc = lib.bevmsda_linear_panel_f32(p(x0), p(a0), p(x1), p(a1), p(idx), p(scale), _ptr(blob), p(b),
-                                          ctypes.byref(desc), ctypes.byref(ln) if ln is not None else None, _ptr(y),
-                                          torch.cuda.current_stream().cuda_stream)
+        if segments is not None and a0 is None and x1 is None and idx is None and ln is None:
+            rc = lib.bevmsda_linear_panel_segments_f32(p(x0), _ptr(blob), p(b), ctypes.byref(desc), _ptr(segments[0]),
+                                                       int(segments[1]), _ptr(y), torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = lib.bevmsda_linear_panel_f32(p(x0), p(a0), p(x1), p(a1), p(idx), p(scale), _ptr(blob), p(b),
+                                              ctypes.byref(desc), ctypes.byref(ln) if ln is not None else None, _ptr(y),
+                                              torch.cuda.current_stream().cuda_stream)
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return False
     _lib.check(rc, "linear_panel")
@@ -688,14 +697,18 @@ def _rows2d(t, K):
 
 
 def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, groups=1,
-           out_dtype=torch.float32, tag="linear", _inside_autograd=False):
+           out_dtype=torch.float32, tag="linear", _inside_autograd=False, segments=None):
     """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
     ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
     covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
     32) and the caller then runs the torch ops.
 
     ``groups = G > 1``: ``weight`` is the row-wise concatenation of G Linear layers that share
-    the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x."""
+    the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x.
+
+    ``segments = (seg_start, seg_len)``: the rows of x are segments of ``seg_len`` rows of which only those with
+    ``seg_start[s + 1] > seg_start[s]`` (int32 DEVICE tensor, read by the kernel) will be read by anyone: the others'
+    output rows may be left unwritten (row-panel kernel only; other kernels compute everything)."""
     mode = _m().gemm
     if mode == "native" or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
             or not (_inside_autograd or fused_wanted(x, weight, bias, x_add, x2, x2_add)):
@@ -735,6 +748,9 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     if out_dtype not in (torch.float32, torch.bfloat16) or (out_dtype == torch.bfloat16 and N % 4):
         return None
     y = torch.empty((groups, M, ncol), dtype=out_dtype, device=x.device)
+    if segments is not None and _SEGMENT_POISON["on"]:
+        y.fill_(float("nan"))
+        _SEGMENT_POISON["launches"] += 1
     if M == 0 or N == 0:
         return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     desc = _lib.LinearDesc(M=M, ldx0=ldx0, lda0=lda0, ldx1=ldx1, lda1=lda1, ldw=w.stride(0),
@@ -744,7 +760,8 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
                            out_bf16=int(out_dtype == torch.bfloat16))
     if _m().gemm_pack and _panel_covers(N, K0, K1, groups, False):
         nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
-        if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes):
+        if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes,
+                       segments=segments):
             return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     variant = _m().gemm_variant
     blob = packed_weight(w) if _m().gemm_pack and (variant is None or variant >= 4) else None

@@ -397,6 +397,16 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
                              const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,
                              void *stream);
 
+/* bevmsda_linear_panel_f32 over ROW SEGMENTS of which only some are needed (BEV tiling over GPUs, SURVEY.md §8e: the
+ * camera-feature value projection is a replicated input, but a rank's queries see only some of the cameras): the rows
+ * form ceil(M / seg_len) segments of seg_len rows (one per (batch entry, camera)); seg_start (segments + 1, int32, DEVICE
+ * memory — the camera starts of bevmsda_frame_plan_f32's counters, read when the kernel runs) tells how many ragged
+ * rows sample each segment; a workgroup whose rows all lie in segments with none returns at once and its output rows
+ * stay unwritten (nothing samples them).  No host synchronisation, graph-capturable.  Single source, no addend. */
+int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, const float *bias,
+                                      const bevmsda_linear_desc *desc, const int32_t *seg_start, int64_t seg_len,
+                                      float *y, void *stream);
+
 /* The row-local tail of an encoder layer in one kernel (csrc/linear_chain.h):
  *     x = LayerNorm0(A w0^T + b0 + res)                          attention output projection, "+ identity", norm
  *     y = LayerNorm1(x + relu(x w1^T + b1) w2^T + b2)            FFN (C -> F -> C), "+ identity", norm

@@ -275,3 +275,43 @@ def test_simulated_rank_on_the_gpu_equals_its_rows_of_the_untiled_encoder(name, 
             h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
             q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
             torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,world", [("tiny", 5), ("micro4", 3)])
+def test_tiled_rank_skips_the_value_projection_of_cameras_it_cannot_see(name, world):
+    """BEV tiling over GPUs: the camera-feature value projection is replicated work, but a rank's tile only samples
+    cameras that some of its queries project into — the tile plan's device-side camera starts gate the projection's
+    workgroups (``ops.linear(segments=...)``).  With the projection's output pre-filled with NaN, every rank's rows
+    must still be the untiled encoder's rows (nobody reads a skipped camera), and across the ranks some camera must
+    actually have been skipped (else this test shows nothing)."""
+    from bevformer_amd import bev_tiling, ops
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=True, device=DEV)
+    w = S.WORKLOADS[name]
+    seen, real = [], ops.linear
+
+    def spy(*a, **k):
+        if k.get("segments") is not None:
+            st = k["segments"][0]
+            seen.append(int(((st[1:] - st[:-1]) == 0).sum()))
+        return real(*a, **k)
+
+    ops._SEGMENT_POISON.update(on=True, launches=0)
+    ops.linear = spy
+    try:
+        with torch.no_grad(), ops.using(gemm_kernel="panel64"):
+            want = enc(q, f, f, **kw)
+            assert not seen                         # the untiled encoder projects every camera
+            for rank in range(world):
+                bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+                got = enc(q, f, f, **kw)
+                bev_tiling.disable_bev_tiling(enc)
+                h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+                q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
+                assert torch.isfinite(got[:, q0:q1]).all()
+                torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-4, atol=1e-4)
+    finally:
+        ops.linear = real
+        ops._SEGMENT_POISON["on"] = False
+    assert len(seen) == world and ops._SEGMENT_POISON["launches"] == world
+    assert sum(seen) > 0, f"no rank of {world} could skip a camera on workload {name}: {seen}"

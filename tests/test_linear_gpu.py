@@ -383,6 +383,45 @@ def test_linear_row_panel_kernel(gemm_mode, mode, kernel, M, K0, K1, N, relu, gr
         assert d < (2e-6 if mode == "split" else 1e-6), f"{kernel} vs the first kernel: {d:.3e}"
 
 
+@pytest.mark.parametrize("seg_len,nseg,empty", [(375, 12, (0, 3, 4, 11)), (64, 9, (1, 2, 3)), (50, 7, ()), (1000, 3, (0, 1, 2)),
+                                                (37, 40, tuple(range(5, 31)))])
+@pytest.mark.parametrize("kernel", ["panel64", "panel128"])
+def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, nseg, empty):
+    """``bevmsda_linear_panel_segments_f32``: rows of segments WITH entries (device-side starts) are exactly those of
+    the full launch; a workgroup returns early only when all of its rows lie in empty segments, so rows of empty
+    segments are either untouched (the NaN prefill) or equal to the full result — never anything else."""
+    gemm_mode("split")
+    M, K, N, L = seg_len * nseg, 256, 768, 3
+    x, w, b = _rand(M, K, seed=71), _rand(N, K, seed=72) * 0.05, _rand(N, seed=73)
+    counts = torch.tensor([0 if i in empty else 1 + (i * 7) % 5 for i in range(nseg)])
+    start = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).to(torch.int32).to(DEV)
+    ops._SEGMENT_POISON["on"] = True
+    try:
+        with torch.no_grad(), ops.using(gemm_kernel=kernel):
+            full = ops.linear(x, w, b, groups=L)
+            part = ops.linear(x, w, b, groups=L, segments=(start, seg_len))
+    finally:
+        ops._SEGMENT_POISON["on"] = False
+    assert torch.isfinite(full).all()
+    full, part = full.view(L, nseg, seg_len, -1), part.view(L, nseg, seg_len, -1)
+    untouched = 0
+    for i in range(nseg):
+        if i in empty:
+            row_nan = torch.isnan(part[:, i]).all(-1).all(0)             # (seg_len,) rows left alone in every group
+            row_same = (part[:, i] == full[:, i]).all(-1).all(0)
+            assert (row_nan | row_same).all()
+            untouched += int(row_nan.sum())
+        else:
+            assert torch.equal(part[:, i], full[:, i])
+    bm = 64 if kernel == "panel64" else 128
+    # every aligned run of bm rows that lies wholly in empty segments must have been skipped
+    rows_empty = torch.zeros(M, dtype=torch.bool)
+    for i in empty:
+        rows_empty[i * seg_len:(i + 1) * seg_len] = True
+    want = sum(int(min(m0 + bm, M) - m0) for m0 in range(0, M, bm) if rows_empty[m0:m0 + bm].all())
+    assert untouched == want
+
+
 @pytest.mark.parametrize("kernel", ["panel64", "panel128"])
 def test_linear_row_panel_identity_with_asymmetric_weight(gemm_mode, kernel):
     """A = I picks single weights: catches a permuted k order between the activation image and the weight image,
