@@ -167,7 +167,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     inter = []
     # replicated, layer-invariant value projections: one grouped GEMM each (encoder.py docstring)
     # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
-    sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value, plan=tile if world > 1 else None)
+    sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value, plan=tile if world > 1 else None,
+                                                            spatial_shapes=spatial_shapes)
     for li, layer in enumerate(encoder.layers):
         hoisted = {}
         if sca_vals is not None:

@@ -206,7 +206,7 @@ int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int
 static int panel_launch(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                         const float *scale, const uint16_t *wpanel, const float *bias,
                         const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream,
-                        const int32_t *seg_start, int64_t seg_len) {
+                        const int32_t *seg_start, int64_t seg_len, const int64_t *level_shapes, int num_levels) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0 || d->group_cols < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -234,8 +234,8 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   a.bias = bias; a.y = y; a.ldy = d->ldy; a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1;
   a.relu = d->relu ? 1 : 0; a.group_cols = gcols; a.out_bf16 = d->out_bf16 ? 1 : 0;
   a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
-  a.seg_start = seg_start; a.seg_len = seg_len;
-  if (seg_start && seg_len <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  a.seg_start = seg_start; a.seg_len = seg_len; a.level_shapes = level_shapes; a.num_levels = level_shapes ? num_levels : 0;
+  if (seg_start && (seg_len <= 0 || num_levels < 0)) return BEVMSDA_ERR_BAD_SHAPE;
   if (ln) {
     if (d->N != 256 || gcols != 0 || d->relu || d->out_bf16) return BEVMSDA_ERR_UNSUPPORTED;
     if (!ln->gamma || !ln->beta) return BEVMSDA_ERR_NULL_POINTER;
@@ -282,13 +282,15 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
 int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                              const float *scale, const uint16_t *wpanel, const float *bias,
                              const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream) {
-  return panel_launch(x0, a0, x1, a1, idx, scale, wpanel, bias, d, ln, y, stream, nullptr, 0);
+  return panel_launch(x0, a0, x1, a1, idx, scale, wpanel, bias, d, ln, y, stream, nullptr, 0, nullptr, 0);
 }
 
 int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, const float *bias, const bevmsda_linear_desc *d,
-                                      const int32_t *seg_start, int64_t seg_len, float *y, void *stream) {
+                                      const int32_t *seg_start, int64_t seg_len, const int64_t *level_shapes,
+                                      int num_levels, float *y, void *stream) {
   if (!seg_start) return BEVMSDA_ERR_NULL_POINTER;
-  return panel_launch(x0, nullptr, nullptr, nullptr, nullptr, nullptr, wpanel, bias, d, nullptr, y, stream, seg_start, seg_len);
+  return panel_launch(x0, nullptr, nullptr, nullptr, nullptr, nullptr, wpanel, bias, d, nullptr, y, stream, seg_start, seg_len,
+                      level_shapes, num_levels);
 }
 
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)

@@ -60,8 +60,12 @@ struct PanelArgs {
   float eps;
   // row segments (e.g. one per camera): a workgroup whose rows all lie in segments with no entry — seg_start[s + 1] ==
   // seg_start[s], read from DEVICE memory when the kernel runs — computes and stores nothing
+  // The consumer (msda_d32.h) issues its zero-coefficient taps too: up to one image row + 1 pixel outside a level, so
+  // rows within max_l W_l + 1 of a used segment are computed as well (level_shapes: (levels, 2) int64 [H, W], DEVICE).
   const int32_t *seg_start;         // (ceil(M / seg_len) + 1) or nullptr
   long seg_len;
+  const int64_t *level_shapes;
+  int num_levels;
 #ifdef BEVMSDA_PANEL_DIAG
   int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
                                     //   3 activation fragments of step 0 only, 4 no panel fetch / split
@@ -139,8 +143,12 @@ linear_panel_kernel(const PanelArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA bases and buffer soffsets are scalar operands
   const long m0 = static_cast<long>(blockIdx.x) * BM;
   if (a.seg_start != nullptr) {                // unused row segments: nobody will read their outputs
-    const long last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
-    const int s_lo = static_cast<int>(m0 / a.seg_len), s_hi = static_cast<int>(last / a.seg_len);
+    long halo = 0;
+    for (int l = 0; l < a.num_levels; ++l) halo = a.level_shapes[2 * l + 1] > halo ? a.level_shapes[2 * l + 1] : halo;
+    halo += a.num_levels > 0 ? 1 : 0;
+    const long first = m0 - halo > 0 ? m0 - halo : 0;
+    const long last = (m0 + BM + halo < a.M ? m0 + BM + halo : a.M) - 1;
+    const int s_lo = static_cast<int>(first / a.seg_len), s_hi = static_cast<int>(last / a.seg_len);
     int used = 0;
     for (int sg = s_lo; sg <= s_hi; ++sg) used |= a.seg_start[sg + 1] - a.seg_start[sg];
     if (used == 0) return;                     // (uniform over the workgroup)

@@ -124,7 +124,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._plan_cache[key] = plan
         return plan
 
-    def hoisted_value_projections(self, value, tsa_value, plan=None):
+    def hoisted_value_projections(self, value, tsa_value, plan=None, spatial_shapes=None):
         """The layer-invariant projections, issued once for all layers.
 
         The inputs of ``MSDeformableAttention3D.value_proj`` (camera features,
@@ -160,8 +160,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
         self._sca_ready = None
         seg = None
         if plan is not None and getattr(plan, "dynamic", False) and plan.cam_start is not None \
-                and plan.cam_start.numel() == bs * Nc + 1:
-            seg = (plan.cam_start, S)        # rows of (batch entry, camera) = one segment of S feature rows
+                and plan.cam_start.numel() == bs * Nc + 1 \
+                and spatial_shapes is not None and spatial_shapes.dtype == torch.long and spatial_shapes.is_cuda:
+            # rows of (batch entry, camera) = one segment of S feature rows (+ the sampling kernel's zero-weight taps,
+            # which reach one image row + 1 pixel into the neighbouring cameras' rows: ops.linear docstring)
+            seg = (plan.cam_start, S, spatial_shapes.contiguous())
         self._last_segments = seg            # (bench.py reports how many cameras a rank projects)
         if self.overlap_value_proj and ops._GEMM_TIMER["cb"] is None:
             cur = torch.cuda.current_stream(value.device)

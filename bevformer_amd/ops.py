@@ -645,7 +645,8 @@ def _panel_covers(N, K0, K1, groups, ln):
 def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbytes, segments=None):
     """One launch of the row-panel kernel; returns False when the library declines the call.  ``segments =
     (seg_start int32 device tensor, seg_len)``: only row segments with entries are computed
-    (``bevmsda_linear_panel_segments_f32``)."""
+    (``bevmsda_linear_panel_segments_f32``); a third entry = the (levels, 2) int64 spatial_shapes of the sampling
+    operator that will read the result (its zero-weight taps reach max W + 1 rows into neighbouring segments)."""
     blob = panel_weight(w)
     if blob is None:
         return False
@@ -659,8 +660,12 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     p = lambda t: _ptr(t) if t is not None else None
     with torch.cuda.device(x0.device), ctx:
         if segments is not None and a0 is None and x1 is None and idx is None and ln is None:
+            shapes = segments[2] if len(segments) > 2 else None
+            if shapes is not None and (shapes.dtype != torch.long or not shapes.is_contiguous() or shapes.dim() != 2):
+                raise ValueError("segments[2] must be the contiguous (levels, 2) int64 spatial_shapes tensor")
             rc = lib.bevmsda_linear_panel_segments_f32(p(x0), _ptr(blob), p(b), ctypes.byref(desc), _ptr(segments[0]),
-                                                       int(segments[1]), _ptr(y), torch.cuda.current_stream().cuda_stream)
+                                                       int(segments[1]), p(shapes), 0 if shapes is None else shapes.shape[0],
+                                                       _ptr(y), torch.cuda.current_stream().cuda_stream)
         else:
             rc = lib.bevmsda_linear_panel_f32(p(x0), p(a0), p(x1), p(a1), p(idx), p(scale), _ptr(blob), p(b),
                                               ctypes.byref(desc), ctypes.byref(ln) if ln is not None else None, _ptr(y),
@@ -706,7 +711,7 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     ``groups = G > 1``: ``weight`` is the row-wise concatenation of G Linear layers that share
     the input; the result is ``(G, ..., N / G)`` — G contiguous outputs from one pass over x.
 
-    ``segments = (seg_start, seg_len)``: the rows of x are segments of ``seg_len`` rows of which only those with
+    ``segments = (seg_start, seg_len[, spatial_shapes])``: the rows of x are segments of ``seg_len`` rows of which only those with
     ``seg_start[s + 1] > seg_start[s]`` (int32 DEVICE tensor, read by the kernel) will be read by anyone: the others'
     output rows may be left unwritten (row-panel kernel only; other kernels compute everything)."""
     mode = _m().gemm

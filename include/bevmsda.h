@@ -401,11 +401,15 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
  * camera-feature value projection is a replicated input, but a rank's queries see only some of the cameras): the rows
  * form ceil(M / seg_len) segments of seg_len rows (one per (batch entry, camera)); seg_start (segments + 1, int32, DEVICE
  * memory — the camera starts of bevmsda_frame_plan_f32's counters, read when the kernel runs) tells how many ragged
- * rows sample each segment; a workgroup whose rows all lie in segments with none returns at once and its output rows
- * stay unwritten (nothing samples them).  No host synchronisation, graph-capturable.  Single source, no addend. */
+ * rows sample each segment.  The sampling kernels also ISSUE the taps whose bilinear coefficient is 0 (up to one image
+ * row + 1 pixel before / after a level: rows of the neighbouring segment), and 0 x NaN is NaN, so the rows within
+ * halo = max_l W_l + 1 of a used segment are computed too (level_shapes: (num_levels, 2) int64 [H, W], DEVICE memory,
+ * the operator's spatial_shapes; NULL / 0 levels = no halo).  A workgroup all of whose rows (+- halo) lie in unused
+ * segments returns at once and its output rows stay unwritten: nothing reads them.  No host synchronisation,
+ * graph-capturable.  Single source, no addend. */
 int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, const float *bias,
                                       const bevmsda_linear_desc *desc, const int32_t *seg_start, int64_t seg_len,
-                                      float *y, void *stream);
+                                      const int64_t *level_shapes, int num_levels, float *y, void *stream);
 
 /* The row-local tail of an encoder layer in one kernel (csrc/linear_chain.h):
  *     x = LayerNorm0(A w0^T + b0 + res)                          attention output projection, "+ identity", norm

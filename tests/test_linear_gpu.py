@@ -385,11 +385,13 @@ def test_linear_row_panel_kernel(gemm_mode, mode, kernel, M, K0, K1, N, relu, gr
 
 @pytest.mark.parametrize("seg_len,nseg,empty", [(375, 12, (0, 3, 4, 11)), (64, 9, (1, 2, 3)), (50, 7, ()), (1000, 3, (0, 1, 2)),
                                                 (37, 40, tuple(range(5, 31)))])
+@pytest.mark.parametrize("halo_w", [None, 0, 29])
 @pytest.mark.parametrize("kernel", ["panel64", "panel128"])
-def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, nseg, empty):
+def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, nseg, empty, halo_w):
     """``bevmsda_linear_panel_segments_f32``: rows of segments WITH entries (device-side starts) are exactly those of
     the full launch; a workgroup returns early only when all of its rows lie in empty segments, so rows of empty
-    segments are either untouched (the NaN prefill) or equal to the full result — never anything else."""
+    segments are either untouched (the NaN prefill) or equal to the full result — never anything else.  With level
+    shapes the rows within max W + 1 of a used segment count as used (the sampling kernels' zero-weight taps)."""
     gemm_mode("split")
     M, K, N, L = seg_len * nseg, 256, 768, 3
     x, w, b = _rand(M, K, seed=71), _rand(N, K, seed=72) * 0.05, _rand(N, seed=73)
@@ -399,7 +401,8 @@ def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, 
     try:
         with torch.no_grad(), ops.using(gemm_kernel=kernel):
             full = ops.linear(x, w, b, groups=L)
-            part = ops.linear(x, w, b, groups=L, segments=(start, seg_len))
+            shapes = None if halo_w is None else torch.tensor([[3, halo_w], [2, halo_w // 2]], device=DEV)
+            part = ops.linear(x, w, b, groups=L, segments=(start, seg_len) + ((shapes,) if shapes is not None else ()))
     finally:
         ops._SEGMENT_POISON["on"] = False
     assert torch.isfinite(full).all()
@@ -415,9 +418,11 @@ def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, 
             assert torch.equal(part[:, i], full[:, i])
     bm = 64 if kernel == "panel64" else 128
     # every aligned run of bm rows that lies wholly in empty segments must have been skipped
-    rows_empty = torch.zeros(M, dtype=torch.bool)
-    for i in empty:
-        rows_empty[i * seg_len:(i + 1) * seg_len] = True
+    rows_empty = torch.ones(M, dtype=torch.bool)
+    halo = 0 if halo_w is None else halo_w + 1
+    for i in range(nseg):
+        if i not in empty:
+            rows_empty[max(0, i * seg_len - halo):(i + 1) * seg_len + halo] = False
     want = sum(int(min(m0 + bm, M) - m0) for m0 in range(0, M, bm) if rows_empty[m0:m0 + bm].all())
     assert untouched == want
 
