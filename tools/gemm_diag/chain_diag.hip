@@ -2,6 +2,7 @@
 #define BEVMSDA_CHAIN_PROF 1
 #include "../../include/bevmsda.h"
 #include "../../bevformer_amd/csrc/linear_chain.h"
+#include "../../bevformer_amd/csrc/linear_rowreg.h"
 
 extern "C" int diag_chain(const float *rows, long ld_rows, const int32_t *idx, const float *scale, const uint16_t *w0, const float *b0,
                           const float *res, const float *g0, const float *be0, const uint16_t *w1, const float *b1, const uint16_t *w2,
@@ -11,7 +12,12 @@ extern "C" int diag_chain(const float *rows, long ld_rows, const int32_t *idx, c
   a.res = res; a.ld_res = 256; a.gamma0 = g0; a.beta0 = be0; a.gamma1 = g1; a.beta1 = be1; a.eps0 = a.eps1 = 1e-5f;
   a.y = y; a.ld_y = 256; a.M = M; a.prof = prof;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (shape == 1) {
+  if (shape >= 30) {                // rows resident in registers (weights: the rowreg images); shape = 30 + stop phase
+    a.ld_y2 = shape - 30;
+    const dim3 grid(static_cast<unsigned>((M + 127) / 128)), block(256);
+    if (idx) hipLaunchKernelGGL((bevmsda::linear_rowreg_chain_kernel<3, 2, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_rowreg_chain_kernel<3, 0, 0>), grid, block, 0, st, a);
+  } else if (shape == 1) {
     const dim3 grid(static_cast<unsigned>((M + 63) / 64)), block(512);
     if (idx) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 2, 0, 2, 1, 8>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 0, 2, 1, 8>), grid, block, 0, st, a);
