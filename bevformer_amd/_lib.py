@@ -119,8 +119,6 @@ SIGNATURES = {
                                                   _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_panel_segments_f32": ([_c_void_p] * 3 + [ctypes.POINTER(LinearDesc), _c_void_p, ctypes.c_int64, _c_void_p,
                                            _c_int, _c_void_p, _c_void_p], _c_int),
-    "bevmsda_linear_rowreg_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
-    "bevmsda_linear_rowreg_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_int, _c_void_p, _c_void_p], _c_int),
     "bevmsda_proj_ffn_chain_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_proj_ln_proj_chain_f32": ([_c_void_p] * 10 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,

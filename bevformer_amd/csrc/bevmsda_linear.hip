@@ -5,7 +5,6 @@
 #include "linear_pipe.h"
 #include "linear_panel.h"
 #include "linear_chain.h"
-#include "linear_rowreg.h"
 #include "wgrad_mfma.h"
 
 namespace {
@@ -294,23 +293,6 @@ int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, c
                       level_shapes, num_levels);
 }
 
-int64_t bevmsda_linear_rowreg_packed_bytes(int N, int K) {
-  if (N <= 0 || K <= 0 || N % 32 != 0 || K % 32 != 0) return 0;
-  return static_cast<int64_t>(N) * K * 4;
-}
-
-int bevmsda_linear_rowreg_pack_weight_f32(const float *w, int64_t ldw, int N, int K, int kmajor, uint16_t *out, void *stream) {
-  if (!w || !out) return BEVMSDA_ERR_NULL_POINTER;
-  if (N <= 0 || K <= 0 || N % 32 != 0 || K % 32 != 0 || ldw < K || ldw % 4 != 0) return BEVMSDA_ERR_BAD_SHAPE;
-  // 16 consecutive fragment units must be one chunk of the kernel's walk
-  if (kmajor ? N != bevmsda::kChainC : K != bevmsda::kChainC) return BEVMSDA_ERR_UNSUPPORTED;
-  if (misaligned(w) || misaligned(out)) return BEVMSDA_ERR_MISALIGNED;
-  const long total = static_cast<long>(N / 32) * (K / 16) * 64;
-  hipLaunchKernelGGL(bevmsda::lin_rowreg_pack_weight_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, kmajor ? 1 : 0, out);
-  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
-}
-
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)
 int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                                const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
@@ -330,12 +312,11 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
       misaligned(gamma1) || misaligned(beta1))
     return BEVMSDA_ERR_MISALIGNED;
   // workgroup shape (desc->reserved[1]): 1 = 64-row panels (8 wavefronts, one workgroup per CU), 2 = 32-row panels
-  // (4 wavefronts, two workgroups per CU), 3 = rows resident in registers (linear_rowreg.h: 128 rows per workgroup; the
-  // weight images are then those of bevmsda_linear_rowreg_pack_weight_f32); 0 = default (1 or 2 by row count)
+  // (4 wavefronts, two workgroups per CU); 0 = default
   int shape = d->reserved[1];
-  if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
   if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
-  const int bm = shape == 3 ? bevmsda::kRowRegRows : shape == 1 ? 64 : 32;
+  const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::ChainArgs a{};
@@ -347,8 +328,7 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
   const dim3 grid(static_cast<unsigned>(nb));
 #define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
   do {                                                                                                                  \
-    if (shape == 3) hipLaunchKernelGGL((bevmsda::linear_rowreg_chain_kernel<NP_, PRE_, 0>), grid, dim3(256), 0, st, a);   \
-    else if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8>), grid, dim3(512), 0, st, a); \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8>), grid, dim3(512), 0, st, a); \
     else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
   } while (0)
   if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }
@@ -374,10 +354,10 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
       (b0 && misaligned(b0)) || (b1 && misaligned(b1)) || misaligned(gamma0) || misaligned(beta0))
     return BEVMSDA_ERR_MISALIGNED;
   int shape = d->reserved[1];
-  if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
   if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
-  if (shape == 2 && d->F % 64 != 0) shape = 1; // the 32-row shape walks 64-column tiles
-  const int bm = shape == 3 ? bevmsda::kRowRegRows : shape == 1 ? 64 : 32;
+  if (d->F % 64 != 0) shape = 1;               // the 32-row shape walks 64-column tiles
+  const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::ChainArgs a{};
@@ -389,8 +369,7 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
   const dim3 grid(static_cast<unsigned>(nb));
 #define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
   do {                                                                                                                  \
-    if (shape == 3) hipLaunchKernelGGL((bevmsda::linear_rowreg_chain_kernel<NP_, PRE_, 1>), grid, dim3(256), 0, st, a);   \
-    else if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8>), grid, dim3(512), 0, st, a); \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8>), grid, dim3(512), 0, st, a); \
     else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
   } while (0)
   if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }

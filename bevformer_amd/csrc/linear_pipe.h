@@ -42,6 +42,13 @@ constexpr int kWaitVm4 = 0x0F74;       // vmcnt(4)
 // fragment reads of the NEXT chunk were sunk below it, next to their MFMAs — and into a race with the stage's
 // refill), without the vmcnt(0) a workgroup-scope fence would cost
 __device__ __forceinline__ void pipe_barrier() { asm volatile("s_barrier" ::: "memory"); }
+// LDS-DMA issued from inline assembly: through the builtin, the compiler puts s_waitcnt vmcnt(0) in front of fragment
+// reads of the OTHER stage (it cannot tell them from reads that alias the DMA in flight) — half of the iterations
+// waited for the weight chunk they had just requested.  The kernel's own counted waits order the stages.
+__device__ __forceinline__ void pipe_dma16(const void *src, uint16_t *lds_dst) {
+  const unsigned d = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) uint16_t *)lds_dst)));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(d) : "memory", "m0");
+}
 
 constexpr int kPipeRow = 40;                         // bf16 elements per LDS row (32 + 8 pad)
 constexpr int kPipePlane = 128 * kPipeRow;           // one plane
@@ -119,8 +126,7 @@ linear_pipe_kernel(const LinArgs a) {
     for (int i = 0; i < WITER; ++i) {
       if (WPIECES % 256 == 0 || (i * 256 + (tid & ~63)) < WPIECES) {       // wave-uniform tail guard
         uint16_t *dst = ws + (i * 256 + (tid & ~63)) * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256 + tid),
-                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+        pipe_dma16(src + i * 256 + tid, dst);
       }
     }
   };

@@ -624,58 +624,6 @@ def panel_weight(weight):
     return blob
 
 
-def rowreg_weight(weight, kmajor=False):
-    """Weight image of the register-resident chain kernels (``bevmsda_linear_rowreg_pack_weight_f32``,
-    csrc/linear_rowreg.h), cached on the tensor like ``panel_weight``."""
-    key = (weight._version, weight.data_ptr(), tuple(weight.shape), weight.stride(0), bool(kmajor))
-    hit = getattr(weight, "_bevmsda_rowreg", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    lib = _lib.load()
-    N, K = weight.shape
-    nbytes = lib.bevmsda_linear_rowreg_packed_bytes(N, K)
-    if nbytes == 0:
-        return None
-    blob = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
-    with torch.cuda.device(weight.device):
-        rc = lib.bevmsda_linear_rowreg_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, int(bool(kmajor)), _ptr(blob),
-                                                       torch.cuda.current_stream().cuda_stream)
-    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
-        return None
-    _lib.check(rc, "linear_rowreg_pack_weight")
-    try:
-        weight._bevmsda_rowreg = (key, blob)
-    except AttributeError:
-        pass
-    return blob
-
-
-_CU_COUNT = {}
-
-
-def _chain_segments(M, device):
-    """How the rows of a chain launch are dealt to the two kernel families: [(m0, m1, shape)].  The register-resident
-    kernel (shape 3: 128 rows per workgroup, one workgroup per CU) takes whole rounds of workgroups — a partial last
-    round costs a full one — and the panel kernels (shape by row count) the remainder, unless that is most of a round
-    anyway.  ``chain_shape``: 0 this policy, 1 / 2 panel kernels only, 3 register-resident only, 4 = 0."""
-    shape = _m().chain_shape
-    if shape in (1, 2, 3):
-        return [(0, M, shape)]
-    cus = _CU_COUNT.get(device)
-    if cus is None:
-        cus = _CU_COUNT[device] = torch.cuda.get_device_properties(device).multi_processor_count
-    per_round = 128 * cus
-    full, rem = divmod(M, per_round)
-    if rem >= 0.55 * per_round:
-        return [(0, M, 3)]
-    if full == 0:
-        return [(0, M, 0)]
-    segs = [(0, full * per_round, 3)]
-    if rem:
-        segs.append((full * per_round, M, 0))
-    return segs
-
-
 def _panel_covers(N, K0, K1, groups, ln):
     """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h) and, unless a kernel is forced, the ones it is
     faster on (tools/gemm_ab.py, profiles/r3): the hoisted value projections (N >= 1024: 510-570 vs 630 us and 254 vs
@@ -1021,17 +969,16 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
     y = torch.empty((M, 256), dtype=torch.float32, device=rows.device)
     if M == 0:
         return y.view(*lead, 256)
-    segs = _chain_segments(M, rows.device)
-    wsrc = [w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
-            for w in (weight, fc1.weight, fc2.weight)]
-    images = {}
-    for _, _, shape in segs:
-        fam = shape == 3
-        if fam not in images:
-            images[fam] = [rowreg_weight(w, kmajor=(i == 2)) for i, w in enumerate(wsrc)] if fam \
-                else [panel_weight(w) for w in wsrc]
-            if any(b is None for b in images[fam]):
-                return None
+    ws = []
+    for w in (weight, fc1.weight, fc2.weight):
+        w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
+        blob = panel_weight(w)
+        if blob is None:
+            return None
+        ws.append(blob)
+    desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=512, precision=0 if m.gemm == "split" else 1,
+                          eps0=float(norm0.eps), eps1=float(norm1.eps))
+    desc.reserved[1] = m.chain_shape
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     flops = 2.0 * M * (256 * 256 + 2 * 256 * 512)
@@ -1040,22 +987,14 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
     p = lambda t: _ptr(t) if t is not None else None
     bc = lambda t: t.contiguous() if t is not None else None
-    b0, b1, b2 = bc(bias), bc(fc1.bias), bc(fc2.bias)
     with torch.cuda.device(rows.device), ctx:
-        for m0, m1, shape in segs:
-            ws = images[shape == 3]
-            desc = _lib.ChainDesc(M=m1 - m0, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=512,
-                                  precision=0 if m.gemm == "split" else 1, eps0=float(norm0.eps), eps1=float(norm1.eps))
-            desc.reserved[1] = shape
-            rc = lib.bevmsda_proj_ffn_chain_f32(
-                _ptr(x0 if gather is not None else x0[m0:m1]), p(idx[m0:m1] if idx is not None else None),
-                p(scale[m0:m1] if scale is not None else None), _ptr(ws[0]), p(b0),
-                p(r2[m0:m1] if r2 is not None else None), _ptr(norm0.weight), _ptr(norm0.bias),
-                _ptr(ws[1]), p(b1), _ptr(ws[2]), p(b2), _ptr(norm1.weight), _ptr(norm1.bias),
-                ctypes.byref(desc), _ptr(y[m0:m1]), torch.cuda.current_stream().cuda_stream)
-            if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
-                return None
-            _lib.check(rc, "proj_ffn_chain")
+        rc = lib.bevmsda_proj_ffn_chain_f32(
+            _ptr(x0), p(idx), p(scale), _ptr(ws[0]), p(bc(bias)), p(r2), _ptr(norm0.weight), _ptr(norm0.bias),
+            _ptr(ws[1]), p(bc(fc1.bias)), _ptr(ws[2]), p(bc(fc2.bias)), _ptr(norm1.weight), _ptr(norm1.bias),
+            ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "proj_ffn_chain")
     return y.view(*lead, 256)
 
 
@@ -1093,36 +1032,29 @@ def proj_ln_proj_chain(rows, weight, bias, res, norm0, w1, b1, *, tag="proj_ln_p
     lead = res.shape[:-1]
     if M == 0:
         return x.view(*lead, 256), pr
-    segs = _chain_segments(M, rows.device)
-    wsrc = [w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
-            for w in (weight, w1)]
-    images = {}
-    for _, _, shape in segs:
-        fam = shape == 3
-        if fam not in images:
-            images[fam] = [rowreg_weight(w) if fam else panel_weight(w) for w in wsrc]
-            if any(b is None for b in images[fam]):
-                return None
+    blobs = []
+    for w in (weight, w1):
+        w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
+        blob = panel_weight(w)
+        if blob is None:
+            return None
+        blobs.append(blob)
+    desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=N2, precision=0 if m.gemm == "split" else 1,
+                          eps0=float(norm0.eps), eps1=0.0)
+    desc.reserved[0] = N2
+    desc.reserved[1] = m.chain_shape
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, 2.0 * M * 256 * (256 + N2), 4.0 * (M * 256 * 3 + M * N2 + 256 * 256 + N2 * 256)) if cb is not None else _NoTimer()
     p = lambda t: _ptr(t) if t is not None else None
     bc = lambda t: t.contiguous() if t is not None else None
-    b0c, b1c = bc(bias), bc(b1)
     with torch.cuda.device(rows.device), ctx:
-        for m0, m1, shape in segs:
-            blobs = images[shape == 3]
-            desc = _lib.ChainDesc(M=m1 - m0, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=N2,
-                                  precision=0 if m.gemm == "split" else 1, eps0=float(norm0.eps), eps1=0.0)
-            desc.reserved[0] = N2
-            desc.reserved[1] = shape
-            rc = lib.bevmsda_proj_ln_proj_chain_f32(_ptr(x0[m0:m1]), None, None, _ptr(blobs[0]), p(b0c), _ptr(r2[m0:m1]),
-                                                    _ptr(norm0.weight), _ptr(norm0.bias), _ptr(blobs[1]), p(b1c),
-                                                    ctypes.byref(desc), _ptr(x[m0:m1]), _ptr(pr[m0:m1]),
-                                                    torch.cuda.current_stream().cuda_stream)
-            if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
-                return None
-            _lib.check(rc, "proj_ln_proj_chain")
+        rc = lib.bevmsda_proj_ln_proj_chain_f32(_ptr(x0), None, None, _ptr(blobs[0]), p(bc(bias)), _ptr(r2), _ptr(norm0.weight),
+                                                _ptr(norm0.bias), _ptr(blobs[1]), p(bc(b1)), ctypes.byref(desc), _ptr(x), _ptr(pr),
+                                                torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "proj_ln_proj_chain")
     return x.view(*lead, 256), pr
 
 

@@ -411,14 +411,6 @@ int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, c
                                       const bevmsda_linear_desc *desc, const int32_t *seg_start, int64_t seg_len,
                                       const int64_t *level_shapes, int num_levels, float *y, void *stream);
 
-/* Weight image of the register-resident form of the chain kernels below (csrc/linear_rowreg.h; chain desc
- * reserved[1] = 3): fragment units of [64 lanes x 8 bf16 hi | lo] with the k order that makes an accumulator tile the next
- * GEMM's operand as it lies; N * K * 4 bytes.  kmajor = 0: units ordered (32-row tile of w, k16 step) — for weights
- * applied to 256 features (K = 256: out-projection, FFN layer 1, the second projection); kmajor = 1: by pairs of k16
- * steps, then tile — FFN layer 2 (N = 256, K = 512).  N, K multiples of 32. */
-int64_t bevmsda_linear_rowreg_packed_bytes(int N, int K);
-int bevmsda_linear_rowreg_pack_weight_f32(const float *w, int64_t ldw, int N, int K, int kmajor, uint16_t *out, void *stream);
-
 /* The row-local tail of an encoder layer in one kernel (csrc/linear_chain.h):
  *     x = LayerNorm0(A w0^T + b0 + res)                          attention output projection, "+ identity", norm
  *     y = LayerNorm1(x + relu(x w1^T + b1) w2^T + b2)            FFN (C -> F -> C), "+ identity", norm

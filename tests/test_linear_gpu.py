@@ -478,16 +478,15 @@ def test_linear_row_panel_layernorm_and_gather(gemm_mode, kernel):
     torch.testing.assert_close(got5.double(), want5, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape,M,with_gather", [(sh, M, wg) for sh in (1, 2, 3) for M, wg in ((641, True), (4099, False), (64, True), (1, False))]
-                         + [(0, 40000, True), (0, 55000, False), (0, 33000, True)])
+@pytest.mark.parametrize("shape,M,with_gather", [(sh, M, wg) for sh in (1, 2) for M, wg in ((641, True), (4099, False), (64, True), (1, False))]
+                         + [(0, 40000, True)])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
 def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, with_gather, shape):
     """``bevmsda_proj_ffn_chain_f32`` (csrc/linear_chain.h): output projection (+ camera gather) + residual + LayerNorm
     + FFN + residual + LayerNorm in one kernel against the same chain as three launches of the row-panel kernel (the
     intermediate x and hidden activations are split from the same fp32 values: differences come from the order of the
-    LayerNorm statistics only) and against the fp64 statement.  Shapes 1 / 2: the panel kernels; 3: rows resident in
-    registers (csrc/linear_rowreg.h; another k order inside the MFMAs); 0: the row-count policy that deals whole
-    rounds of workgroups to shape 3 and the rest to the panel kernels (``ops._chain_segments``)."""
+    LayerNorm statistics only) and against the fp64 statement.  Shapes 1 / 2: 64- / 32-row panels; 0: the library's
+    choice by row count (here at the base row count)."""
     gemm_mode(mode)
     g = torch.Generator().manual_seed(M)
     R = max(M + 37, 100)
@@ -515,11 +514,8 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
             want = ops.linear_layernorm(h, fc2.weight, fc2.bias, x, n1)
         assert got is not None and x is not None and want is not None and got.shape == (M, 256)
         # (bf16 operands: a last-bit difference of x flips its bf16 rounding for single elements)
-        t3 = (2e-5 if shape in (1, 2) else 5e-5) if mode == "split" else 2e-2
+        t3 = 2e-5 if mode == "split" else 2e-2
         torch.testing.assert_close(got, want, rtol=t3, atol=t3)
-        if shape == 0:
-            kinds = [sg[2] for sg in ops._chain_segments(M, DEV)]
-            assert kinds == {40000: [3, 0], 55000: [3], 33000: [3, 0]}[M] or torch.cuda.get_device_properties(DEV).multi_processor_count != 256
         # fp64 statement
         a = src.double() if not with_gather else sum(
             torch.where((idx[:, j] >= 0)[:, None], rows.double()[idx[:, j].clamp(min=0).long()], torch.zeros(1, dtype=torch.float64, device=DEV))
@@ -532,8 +528,8 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
     torch.testing.assert_close(got.double(), y64, rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("shape,M,N2", [(sh, M, n2) for sh in (1, 2, 3) for M, n2 in ((641, 768), (4099, 192), (64, 96), (5000, 768))]
-                         + [(0, 40000, 768), (0, 55000, 192)])
+@pytest.mark.parametrize("shape,M,N2", [(sh, M, n2) for sh in (1, 2) for M, n2 in ((641, 768), (4099, 192), (64, 96), (5000, 768))]
+                         + [(0, 40000, 768)])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
 def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M, N2, shape):
     """``bevmsda_proj_ln_proj_chain_f32`` (csrc/linear_chain.h, MODE 1): output projection + residual + LayerNorm (stored)
@@ -555,7 +551,7 @@ def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M
         assert got is not None and x is not None
         gx, gp = got
         assert gx.shape == (M, 256) and gp.shape == (M, N2)
-        t2 = (2e-5 if shape in (1, 2) else 5e-5) if mode == "split" else 2e-2
+        t2 = 2e-5 if mode == "split" else 2e-2
         torch.testing.assert_close(gx, x, rtol=t2, atol=t2)
         torch.testing.assert_close(gp, p, rtol=max(t2, 5e-5), atol=max(t2, 5e-5))
         ln = torch.nn.functional.layer_norm

@@ -30,7 +30,11 @@
 //
 // Registers at the FFN peak: x fragments 128 + FFN accumulators 128 + hidden fragments 16 + hidden accumulator 16 +
 // weight fragments: one wavefront per SIMD (amdgpu_waves_per_eu(1, 1)).  128 rows per workgroup; the launcher gives this
-// kernel whole rounds of workgroups and linear_chain.h the remainder (bevmsda_linear.hip).
+// kernel whole rounds of workgroups and linear_chain.h the remainder.
+//
+// RETIRED (round 3): parity-green, at par with linear_chain.h per row — at one wavefront per SIMD the wavefront's vector /
+// scalar instructions are not hidden behind its own MFMAs (profiles/r3/r3l_register_resident_chain_notes.txt).  Not built
+// into the library; tools/gemm_diag/chain_run.py 3 <rows> still runs it.
 #pragma once
 #include <utility>
 

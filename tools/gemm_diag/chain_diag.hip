@@ -2,7 +2,7 @@
 #define BEVMSDA_CHAIN_PROF 1
 #include "../../include/bevmsda.h"
 #include "../../bevformer_amd/csrc/linear_chain.h"
-#include "../../bevformer_amd/csrc/linear_rowreg.h"
+#include "../experimental/linear_rowreg.h"   // (retired from the library: includes "linear_chain.h" from csrc via -I)
 
 extern "C" int diag_chain(const float *rows, long ld_rows, const int32_t *idx, const float *scale, const uint16_t *w0, const float *b0,
                           const float *res, const float *g0, const float *be0, const uint16_t *w1, const float *b1, const uint16_t *w2,
@@ -27,4 +27,10 @@ extern "C" int diag_chain(const float *rows, long ld_rows, const int32_t *idx, c
     else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 0, 1, 2, 4>), grid, block, 0, st, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" void diag_rowreg_pack(const float *w, long ldw, int N, int K, int kmajor, uint16_t *out, void *stream) {
+  const long total = static_cast<long>(N / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(bevmsda::lin_rowreg_pack_weight_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, ldw, N, K, kmajor, out);
 }

@@ -13,8 +13,19 @@ from bevformer_amd import ops  # noqa: E402
 
 so, src = os.path.join(HERE, "libchaindiag.so"), os.path.join(HERE, "chain_diag.hip")
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", src, "-o", so], check=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+                    "-I" + os.path.join(os.path.dirname(os.path.dirname(HERE)), "bevformer_amd", "csrc"), src, "-o", so], check=True)
 lib = ctypes.CDLL(so)
+lib.diag_rowreg_pack.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+
+
+def rowreg_weight(w, kmajor=False):
+    """Weight image of the retired register-resident kernel (tools/experimental/linear_rowreg.h)."""
+    blob = torch.empty(w.shape[0] * w.shape[1] * 2, dtype=torch.int16, device=w.device)
+    lib.diag_rowreg_pack(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], int(kmajor), blob.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return blob
+
+
 lib.diag_chain.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 13 + [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 DEV = torch.device("cuda:0")
 SHAPE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -32,7 +43,7 @@ b0, b1, b2 = torch.randn(256, device=DEV) * 0.1, torch.randn(512, device=DEV) * 
 res = torch.randn(M, 256, generator=g).to(DEV)
 ga, be = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
 if SHAPE == 3:
-    p0, p1, p2 = ops.rowreg_weight(w0), ops.rowreg_weight(w1), ops.rowreg_weight(w2, kmajor=True)
+    p0, p1, p2 = rowreg_weight(w0), rowreg_weight(w1), rowreg_weight(w2, kmajor=True)
 else:
     p0, p1, p2 = ops.panel_weight(w0), ops.panel_weight(w1), ops.panel_weight(w2)
 y = torch.empty(M, 256, device=DEV)
