@@ -49,6 +49,12 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1; a.relu = d->relu ? 1 : 0;
   a.group_cols = gcols;
   a.out_bf16 = d->out_bf16 ? 1 : 0;
+  // desc->reserved[0] = 1: y += result (first kernel, float4 epilogue: fp32 y, N and ldy multiples of 4, aligned y / bias)
+  a.accum = d->reserved[0] == 1 ? 1 : 0;
+  if (d->reserved[0] != 0 && d->reserved[0] != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (a.accum && (d->out_bf16 || d->N % 4 != 0 || d->ldy % 4 != 0 || gcols % 4 != 0 || misaligned(y) || (bias && misaligned(bias)) ||
+                  d->variant == 131))
+    return BEVMSDA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool add = a.a0 != nullptr || a.a1 != nullptr || gidx != nullptr;
   // desc->variant: 0 = library default; 1 = the first kernel over the fp32 weight matrix, 13 = over the packed weight
@@ -58,7 +64,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   // software-pipelined kernel (linear_pipe.h)
   {
     const int nch = (d->K0 + d->K1) / 32;
-    const bool covered = wpack && !add && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
+    const bool covered = wpack && !add && !a.accum && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
                          (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) &&
                          (nch == 8 || nch == 16);
     if (d->variant == 131 && !covered) return BEVMSDA_ERR_UNSUPPORTED;

@@ -60,6 +60,7 @@ struct LinArgs {
   int relu;
   int group_cols;                  // > 0: output column n goes to matrix n / group_cols (each (M, ldy))
   int out_bf16;                    // 1: y holds bf16 (round-to-nearest-even of the fp32 result), ldy in elements
+  int accum;                       // 1: y += result (fp32 y, float4 epilogue): gradients of a tensor with several consumers
   int nblk_m, nblk_n;
 #ifdef BEVMSDA_LIN_DIAG
   int diag;                        // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 A loads of chunk 0 only,
@@ -468,6 +469,7 @@ linear_splitbf16_kernel(const LinArgs a) {
                 uint16_t *yb = reinterpret_cast<uint16_t *>(a.y) + (yrow - a.y) + n;
                 *reinterpret_cast<uint2 *>(yb) = pk;
               } else {
+                if (a.accum) v = lin_add4(v, *reinterpret_cast<const float4 *>(yrow + n));
                 *reinterpret_cast<float4 *>(yrow + n) = v;
               }
             }

@@ -213,8 +213,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         bev_query = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2)
         len_bev = ref_2d.shape[1]
+        history = None
         if prev_bev is not None:
             prev_bev = prev_bev.permute(1, 0, 2)
+            history = prev_bev
             prev_bev = torch.stack([prev_bev, bev_query], 1).reshape(bs * 2, len_bev, -1)
             hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
         else:
@@ -223,8 +225,17 @@ class BEVFormerEncoder(TransformerLayerSequence):
         output = bev_query
         intermediate = []
         sca_vals, tsa_vals = self.hoisted_value_projections(value, prev_bev)
+        share = None
+        if torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda:
+            # training: the camera features and [prev_bev, bev_query] feed every layer's value projection — their six
+            # input gradients are summed inside the GEMMs instead of by autograd's adds (ops.GradThread)
+            share = {"sca": ops.GradThread(), "tsa": ops.GradThread()}
         for li, layer in enumerate(self.layers):
             hoisted = {}
+            if share is not None:
+                hoisted["value_grad_share"] = share
+                if history is not None:
+                    hoisted["tsa_history"] = history
             if sca_vals is not None:
                 hoisted["projected_value"] = sca_vals[li]
                 if li == 0 and getattr(self, "_sca_ready", None) is not None:

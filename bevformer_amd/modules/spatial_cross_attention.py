@@ -128,10 +128,11 @@ class MSDeformableAttention3D(BaseModule):
         return out
 
     # -- ragged call used by SpatialCrossAttention ---------------------------
-    def project_value(self, value):
-        """(N, S, C) camera features -> (N, S, M, D)."""
+    def project_value(self, value, shared=None):
+        """(N, S, C) camera features -> (N, S, M, D).  ``shared``: the ``ops.GradThread`` of all layers' projections of
+        these features."""
         v = ops.linear_or_torch(value, self.value_proj.weight, self.value_proj.bias,
-                                tag="sca_value_proj")
+                                tag="sca_value_proj", thread=shared)
         return v.view(value.shape[0], value.shape[1], self.num_heads, -1)
 
     def forward_rows_shared_projection(self, queries, value, row_ref, row_batch, row_src,
@@ -250,7 +251,8 @@ class SpatialCrossAttention(BaseModule):
         if projected_value is None:
             Nc, S, _, _ = value.shape
             feats = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, S, self.embed_dims)
-            projected_value = self.deformable_attention.project_value(feats)
+            share = kwargs.get("value_grad_share")
+            projected_value = self.deformable_attention.project_value(feats, None if share is None else share.get("sca"))
 
         da = self.deformable_attention
         slots, projected = None, False

@@ -164,6 +164,12 @@ class TemporalSelfAttention(BaseModule):
             first = query_in if bs == 1 else query_in[torch.arange(bs, device=query.device) // 2]
         else:
             first = value[:bs]
+            hist = kwargs.get("tsa_history")
+            if hist is not None and bs == 1 and hist.shape == first.shape:
+                # value[:1] IS the history BEV (stack([prev_bev, bev_query], 1)[0]); taken from the tensor it was stacked
+                # from, it needs no gradient when the history is detached (the reference computes it under no_grad,
+                # bevformer.py:158-177) — through the stacked tensor autograd computes one, pads it and adds it, per layer
+                first = hist
             if bev_slice is not None:
                 first = first[:, bev_slice[0]:bev_slice[1]]
         src = query_in if shared_value else value
@@ -171,8 +177,9 @@ class TemporalSelfAttention(BaseModule):
         if tsa_projected_value is not None and not shared_value and key_padding_mask is None:
             v = tsa_projected_value
         else:
+            share = kwargs.get("value_grad_share") if not shared_value else None
             v = ops.linear_or_torch(src, self.value_proj.weight, self.value_proj.bias,
-                                    tag="tsa_value_proj")
+                                    tag="tsa_value_proj", thread=None if share is None else share.get("tsa"))
             if key_padding_mask is not None:
                 v = v.masked_fill(key_padding_mask[..., None], 0.0)
             v = v.reshape(v.shape[0], num_value, M, -1)

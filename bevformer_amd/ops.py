@@ -702,7 +702,7 @@ def _rows2d(t, K):
 
 
 def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None, groups=1,
-           out_dtype=torch.float32, tag="linear", _inside_autograd=False, segments=None):
+           out_dtype=torch.float32, tag="linear", _inside_autograd=False, segments=None, accumulate_into=None):
     """``act(cat([x (+ x_add), x2 (+ x2_add)], -1) @ weight.T + bias)`` through
     ``bevmsda_linear_f32`` (include/bevmsda.h).  Returns ``None`` when this call is not
     covered (mode ``native``, autograd needed, CPU / non-fp32 tensors, K not a multiple of
@@ -713,7 +713,10 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
 
     ``segments = (seg_start, seg_len[, spatial_shapes])``: the rows of x are segments of ``seg_len`` rows of which only those with
     ``seg_start[s + 1] > seg_start[s]`` (int32 DEVICE tensor, read by the kernel) will be read by anyone: the others'
-    output rows may be left unwritten (row-panel kernel only; other kernels compute everything)."""
+    output rows may be left unwritten (row-panel kernel only; other kernels compute everything).
+
+    ``accumulate_into``: an fp32 (rows, N) tensor the result is ADDED to in the kernel's epilogue (and which is
+    returned) instead of a fresh output — ``SharedInputGrad``."""
     mode = _m().gemm
     if mode == "native" or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 \
             or not (_inside_autograd or fused_wanted(x, weight, bias, x_add, x2, x2_add)):
@@ -752,7 +755,14 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     ncol = N // groups
     if out_dtype not in (torch.float32, torch.bfloat16) or (out_dtype == torch.bfloat16 and N % 4):
         return None
-    y = torch.empty((groups, M, ncol), dtype=out_dtype, device=x.device)
+    if accumulate_into is not None:
+        if groups != 1 or out_dtype != torch.float32 or relu or accumulate_into.dtype != torch.float32 \
+                or tuple(accumulate_into.shape) != (M, N) or not accumulate_into.is_contiguous() or N % 4 \
+                or accumulate_into.data_ptr() % 16:
+            return None
+        y = accumulate_into.view(1, M, N)
+    else:
+        y = torch.empty((groups, M, ncol), dtype=out_dtype, device=x.device)
     if segments is not None and _SEGMENT_POISON["on"]:
         y.fill_(float("nan"))
         _SEGMENT_POISON["launches"] += 1
@@ -763,7 +773,9 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
                            precision=0 if mode == "split" else 1,
                            group_cols=ncol if groups > 1 else 0,
                            out_bf16=int(out_dtype == torch.bfloat16))
-    if _m().gemm_pack and _panel_covers(N, K0, K1, groups, False):
+    if accumulate_into is not None:
+        desc.reserved[0] = 1                # y += result (first kernel)
+    if accumulate_into is None and _m().gemm_pack and _panel_covers(N, K0, K1, groups, False):
         nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
         if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes,
                        segments=segments):
@@ -772,7 +784,7 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     blob = packed_weight(w) if _m().gemm_pack and (variant is None or variant >= 4) else None
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
-    elif blob is not None and _m().gemm_kernel == "pipe":
+    elif blob is not None and _m().gemm_kernel == "pipe" and accumulate_into is None:
         if a0 is None and a1 is None and (K0 + K1) // 32 in (8, 16):
             desc.variant = 131              # force the software-pipelined kernel
     elif _m().gemm_kernel == "first":
@@ -1112,6 +1124,28 @@ def linear_wgrad(g, x, with_bias, *, tag="linear_dw"):
     return gw, gb
 
 
+class GradThread:
+    """Several projections of the SAME tensor with their input gradients summed inside the GEMMs.  The camera features go
+    through every encoder layer's ``value_proj`` (``[prev_bev, bev_query]`` through every TemporalSelfAttention's):
+    autograd would sum the six input gradients with five elementwise adds over a 189 MB (82 MB) tensor each.  Instead the
+    tensor is THREADED through the projections: every ``_LinearFunction`` hands out an alias of its input next to its
+    result, the next projection consumes the alias, and in backward each function receives the sum so far as the alias'
+    gradient, adds its own contribution in its GEMM's epilogue (``linear(accumulate_into=...)``) and passes the same
+    buffer on.  Plain autograd data flow: no state outside the graph, a retained graph or a consumer that takes no part
+    in the loss need no special case.  ``take(x)`` gives the tensor the next projection must consume, ``put`` stores the
+    alias it returned."""
+    __slots__ = ("alias",)
+
+    def __init__(self):
+        self.alias = None
+
+    def take(self, x):
+        return x if self.alias is None or self.alias.shape != x.shape else self.alias
+
+    def put(self, alias):
+        self.alias = alias
+
+
 class _LinearFunction(Function):
     """``act(x @ weight.T + bias)`` under autograd, all three GEMMs on this package's MFMA kernels: the
     forward (the projection kernel), the input gradient (``grad_y @ weight``: the projection kernel over the
@@ -1130,8 +1164,10 @@ class _LinearFunction(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, weight, bias, relu, tag):
+    def forward(ctx, x, weight, bias, relu, tag, thread=False):
         ctx.modes = _m().snapshot()
+        ctx.thread = bool(thread)
+        ctx.set_materialize_grads(False)
         if _m().train_forward_mfma:
             # `weight` itself (not a detached temporary): the packed-weight cache lives on the parameter
             with torch.no_grad():
@@ -1145,25 +1181,41 @@ class _LinearFunction(Function):
         ctx.has_bias = bias is not None
         ctx.tag = tag
         ctx.save_for_backward(x, weight, y if relu else None)
+        if thread:
+            return y, x.view_as(x)          # (GradThread: the next projection of x consumes this alias)
         return y
 
     @staticmethod
     @once_differentiable
     @torch.amp.custom_bwd(device_type="cuda")
     @_forward_modes
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_alias=None):
         x, weight, y = ctx.saved_tensors
+        K = x.shape[-1]
+        if gy is None:                      # my result takes no part in the loss: only the thread passes through
+            return (g_alias if ctx.needs_input_grad[0] else None), None, None, None, None, None
         gy = gy.float()
         if ctx.relu:
             gy = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0.0)     # one pass: gy where y > 0
-        K = x.shape[-1]
         g2 = gy.reshape(-1, gy.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = linear(g2, transposed_weight(weight), None, tag=ctx.tag + "_dx", _inside_autograd=True)
-            if gx is None:
-                gx = g2 @ weight
-            gx = gx.view(x.shape)
+            acc = None
+            if g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous() \
+                    and g_alias.numel() == g2.shape[0] * K:
+                acc = g_alias.view(-1, K)   # the sum of the later projections' gradients: add mine in the epilogue
+                if linear(g2, transposed_weight(weight), None, tag=ctx.tag + "_dx", _inside_autograd=True,
+                          accumulate_into=acc) is None:
+                    acc = None
+            if acc is not None:
+                gx = g_alias
+            else:
+                gx = linear(g2, transposed_weight(weight), None, tag=ctx.tag + "_dx", _inside_autograd=True)
+                if gx is None:
+                    gx = g2 @ weight
+                gx = gx.view(x.shape)
+                if g_alias is not None:
+                    gx = gx + g_alias
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw, gb_k = linear_wgrad(g2, x.reshape(-1, K), want_b, tag=ctx.tag + "_dw")
@@ -1173,12 +1225,15 @@ class _LinearFunction(Function):
                 gb = gb_k
         if want_b and gb is None:
             gb = g2.sum(0)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
+def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear", thread=None):
     """``linear`` with the torch statement as the not-covered path (single-source form).  Under
-    autograd (GEMM mode not ``native``) the MFMA kernel runs inside ``_LinearFunction``."""
+    autograd (GEMM mode not ``native``) the MFMA kernel runs inside ``_LinearFunction``; ``thread``: the
+    ``GradThread`` common to all the projections of this same ``x``."""
+    if thread is not None:
+        x = thread.take(x)
     y = linear(x, weight, bias, relu=relu, tag=tag)
     if y is not None:
         return y
@@ -1187,7 +1242,11 @@ def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear"):
             and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] % 32 == 0 \
             and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1] \
             and (x.requires_grad or weight.requires_grad):
-        return _LinearFunction.apply(x, weight, bias, relu, tag)
+        if thread is not None and x.requires_grad:
+            y, alias = _LinearFunction.apply(x, weight, bias, relu, tag, True)
+            thread.put(alias)
+            return y
+        return _LinearFunction.apply(x, weight, bias, relu, tag, False)
     y = torch.nn.functional.linear(x, weight, bias)
     if relu:
         y = torch.relu_(y)

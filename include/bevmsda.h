@@ -293,7 +293,10 @@ typedef struct bevmsda_linear_desc {
                                                  nearest even; ldy / group layout in elements) — the
                                                  projected value of the bf16-storage sampling path;
                                                  float4-epilogue variants only, N and ldy % 4 == 0 */
-  int32_t reserved[4];                        /* [1] = 1: the default never picks the software-pipelined kernel;
+  int32_t reserved[4];                        /* [0] = 1: y += result instead of y = result (fp32 y, N and ldy multiples of
+                                                 4, 16-byte aligned y / bias; bevmsda_linear_f32 / _packed_f32 only): the
+                                                 input gradients of several projections of one tensor summed in place;
+                                                 [1] = 1: the default never picks the software-pipelined kernel;
                                                  [2]: panel shape of bevmsda_linear_panel_f32 */
 } bevmsda_linear_desc;
 

@@ -560,3 +560,41 @@ def test_proj_ln_proj_chain_kernel_is_the_two_launch_sequence(gemm_mode, mode, M
     tol = 2e-4 if mode == "split" else 5e-2
     torch.testing.assert_close(gx.double(), x64, rtol=tol, atol=tol)
     torch.testing.assert_close(gp.double(), p64, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_shared_input_gradient_is_the_sum_autograd_would_form(gemm_mode, mode):
+    """``ops.GradThread``: several projections of one tensor sum their input gradients inside the GEMM epilogue
+    (``bevmsda_linear_desc.reserved[0] = 1``) instead of through autograd's adds — same gradients as without it (to the
+    order of the fp32 additions), for the shared input, for every weight / bias, on a second backward through a retained
+    graph too, when some consumers' outputs do not reach the loss, and when the tensor has other consumers as well."""
+    gemm_mode(mode)
+    M, K = 3001, 256
+    ws = [(_rand(256, K, seed=101 + i) / 16).requires_grad_(True) for i in range(4)]
+    bs = [(_rand(256, seed=111 + i) * 0.1).requires_grad_(True) for i in range(4)]
+    x = _rand(7, M // 7 + 1, K, seed=121)[:, :M // 7].contiguous()            # a leading shape that needs reshaping
+    coef = [_rand(*x.shape[:-1], 256, seed=131 + i) for i in range(4)]
+
+    def run(share, used=(0, 1, 2, 3)):
+        xi = x.clone().requires_grad_(True)
+        sh = ops.GradThread() if share else None
+        ys = [ops.linear_or_torch(xi, ws[i], bs[i], tag=f"p{i}", thread=sh) for i in range(4)]
+        loss = sum((ys[i] * coef[i]).sum() for i in used) + (xi[:3] * coef[0][:3]).sum() * 0.5      # + a consumer outside the thread
+        params = [xi] + [ws[i] for i in used] + [bs[i] for i in used]
+        g1 = torch.autograd.grad(loss, params, retain_graph=True)
+        g2 = torch.autograd.grad(loss, params)
+        return g1, g2
+
+    want, _ = run(False)
+    got1, got2 = run(True)
+    tol = 2e-5 if mode == "split" else 1e-4
+    for a_, b_, c_ in zip(want, got1, got2):
+        scale = a_.abs().max().item()
+        assert (a_ - b_).abs().max().item() <= tol * scale and (a_ - c_).abs().max().item() <= tol * scale
+    # the adds are gone: the shared run issues accumulate launches (same launch count, no elementwise sum) — and a
+    # consumer that takes no part in the loss must not leave the accumulator half-finished for the next use
+    want3, _ = run(False, used=(0, 2))
+    got3, got3b = run(True, used=(0, 2))
+    for a_, b_, c_ in zip(want3, got3, got3b):
+        scale = a_.abs().max().item()
+        assert (a_ - b_).abs().max().item() <= tol * scale and (a_ - c_).abs().max().item() <= tol * scale
