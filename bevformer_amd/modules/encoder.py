@@ -226,7 +226,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         intermediate = []
         sca_vals, tsa_vals = self.hoisted_value_projections(value, prev_bev)
         share = None
-        if torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda:
+        if torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda and ops.modes().grad_thread:
             # training: the camera features and [prev_bev, bev_query] feed every layer's value projection — their six
             # input gradients are summed inside the GEMMs instead of by autograd's adds (ops.GradThread)
             share = {"sca": ops.GradThread(), "tsa": ops.GradThread()}
