@@ -1140,7 +1140,10 @@ class GradThread:
         self.alias = None
 
     def take(self, x):
-        return x if self.alias is None or self.alias.shape != x.shape else self.alias
+        a = self.alias                      # (only for the very tensor the thread started from: same memory, same layout)
+        if a is None or a.shape != x.shape or a.data_ptr() != x.data_ptr() or a.stride() != x.stride() or a.dtype != x.dtype:
+            return x
+        return a
 
     def put(self, alias):
         self.alias = alias
