@@ -24,7 +24,7 @@ if [ "${PMC:-1}" = "1" ]; then
     # PMC_ONLY="3 4": only those passes (1-based)
     if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $pi "; then continue; fi
     name=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
-    timeout -k 5 $PASS_TIMEOUT rocprofv3 --pmc $pass --kernel-include-regex "msda|bevsca|bevtsa|linear_splitbf16|linear_panel|linear_pipe|wgrad|plan_|layernorm" --output-format csv \
+    timeout -k 5 $PASS_TIMEOUT rocprofv3 --pmc $pass --kernel-include-regex "msda|bevsca|bevtsa|linear_splitbf16|linear_panel|linear_chain|linear_pipe|wgrad|plan_|layernorm" --output-format csv \
         -d "$out/pmc_$name" -- "$@" > "$out/pmc_$name.log" 2>&1 || echo "pass '$pass' failed/timed out" >> "$out/failed_passes.txt"
   done
 fi

@@ -41,6 +41,8 @@ def classify(name):
         return "grad_value_sort:" + re.sub(r".*kernel", "", name)
     if "msda_gradloc_d32" in name:
         return "grad_loc_gather:" + re.sub(r".*kernel", "", name)
+    if "linear_chain_kernel" in name:
+        return "linear_chain:" + re.sub(r".*kernel", "", name)
     if "linear_panel_kernel" in name:
         return "linear_panel:" + re.sub(r".*kernel", "", name)
     if "linear_splitbf16_kernel" in name or "linear_pipe_kernel" in name:
