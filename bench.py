@@ -77,6 +77,9 @@ def parse():
                          "per-kernel HIP-event timings come from an eager pass right before)")
     ap.add_argument("--force-tiling", action="store_true",
                     help="run the multi-GPU schedule (row blocks + RCCL all-gather) even on 1 rank")
+    ap.add_argument("--tile-layout", default="auto", choices=["auto", "rows", "sectors"],
+                    help="BEV tiling over GPUs: contiguous blocks of BEV rows, or angular sectors around the ego vehicle "
+                         "(a rank then sees 1-3 cameras instead of 3-4 and projects only those)")
     ap.add_argument("--simulate-rank", default=None, metavar="R,G",
                     help="time rank R's schedule of a G-GPU BEV-tiled job on this one GPU (no process group; the "
                          "all-gather is replaced by a local copy: bev_tiling.BevTiling.simulate)")
@@ -261,9 +264,9 @@ class Config:
         self.enc.device_plans = not args.host_plans
         if getattr(args, "simulate_rank", None) and world == 1 and not tiling:
             r, g = (int(v) for v in args.simulate_rank.split(","))
-            bev_tiling.enable_bev_tiling(self.enc, simulate=(r, g))
+            bev_tiling.enable_bev_tiling(self.enc, simulate=(r, g), layout=args.tile_layout)
         elif tiling:
-            bev_tiling.enable_bev_tiling(self.enc)
+            bev_tiling.enable_bev_tiling(self.enc, layout=args.tile_layout)
         self.q, self.f, self.kw = S.make_inputs(workload, seed=0, temporal=not first_frame, device=dev)
         self.metas0 = self.kw["img_metas"]
         self.rigs = jittered_rigs(workload, N_RIGS, dev)
@@ -518,33 +521,44 @@ def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 
                                          "min(G - 1, 7) links in parallel"},
            "t1_ms": t1_ms, "replicated_value_projections_us": replicated_us,
            "status": "per-rank times measured on one GPU; collective modelled; unmeasured on multi-GPU hardware"}
+    def one_layout(layout):
+        res = {}
+        for G in worlds:
+            per_rank, cams = [], []
+            for r in range(G):
+                bev_tiling.enable_bev_tiling(cfg.enc, simulate=(r, G), layout=layout)
+                for _ in range(2):
+                    cfg.encoder_step()
+                fence()
+                graph = None
+                if args.graph != "off":
+                    try:
+                        graph, _ = capture(cfg.encoder_step, fence)
+                    except Exception:      # noqa: BLE001
+                        graph = None
+                        torch.cuda.synchronize()
+                ts = timed_windows(cfg, cfg.encoder_step, fence, 10, 3, graph)
+                per_rank.append(statistics.median(ts) / 10 * 1e3)
+                seg = getattr(cfg.enc, "_last_segments", None)
+                cams.append(int(((seg[0][1:] - seg[0][:-1]) > 0).sum()) if seg is not None else None)
+                del graph
+            shard = cfg.Q / G * 256 * 4
+            ag_us = LAT_US + shard * (G - 1) / (min(G - 1, 7) * LINK_GBS * 1e9) * 1e6
+            T = max(per_rank) + ag_us * 1e-3
+            res[str(G)] = dict(per_rank_ms=[round(p, 4) for p in per_rank], cameras_projected_per_rank=cams,
+                               all_gather_model_us=ag_us, step_ms=T,
+                               queries_per_s=cfg.Q / (T * 1e-3), efficiency=t1_ms / (G * T),
+                               amdahl_bound_efficiency=t1_ms / (G * (replicated_us * 1e-3 + (t1_ms - replicated_us * 1e-3) / G))
+                               if replicated_us else None)
+        return res
+
+    # the layout that would run (auto: rows at 2 ranks, sectors from 3 on) and, beside it, both fixed layouts
+    out["layout"] = args.tile_layout
+    fixed = {lay: one_layout(lay) for lay in ("rows", "sectors")}
     for G in worlds:
-        per_rank, cams = [], []
-        for r in range(G):
-            bev_tiling.enable_bev_tiling(cfg.enc, simulate=(r, G))
-            for _ in range(2):
-                cfg.encoder_step()
-            fence()
-            graph = None
-            if args.graph != "off":
-                try:
-                    graph, _ = capture(cfg.encoder_step, fence)
-                except Exception:      # noqa: BLE001
-                    graph = None
-                    torch.cuda.synchronize()
-            ts = timed_windows(cfg, cfg.encoder_step, fence, 10, 3, graph)
-            per_rank.append(statistics.median(ts) / 10 * 1e3)
-            seg = getattr(cfg.enc, "_last_segments", None)
-            cams.append(int(((seg[0][1:] - seg[0][:-1]) > 0).sum()) if seg is not None else None)
-            del graph
-        shard = cfg.Q / G * 256 * 4
-        ag_us = LAT_US + shard * (G - 1) / (min(G - 1, 7) * LINK_GBS * 1e9) * 1e6
-        T = max(per_rank) + ag_us * 1e-3
-        out[str(G)] = dict(per_rank_ms=[round(p, 4) for p in per_rank], cameras_projected_per_rank=cams,
-                           all_gather_model_us=ag_us, step_ms=T,
-                           queries_per_s=cfg.Q / (T * 1e-3), efficiency=t1_ms / (G * T),
-                           amdahl_bound_efficiency=t1_ms / (G * (replicated_us * 1e-3 + (t1_ms - replicated_us * 1e-3) / G))
-                           if replicated_us else None)
+        lay = args.tile_layout if args.tile_layout != "auto" else ("sectors" if G >= 3 else "rows")
+        out[str(G)] = dict(fixed[lay][str(G)], layout=lay)
+    out["by_layout"] = fixed
     bev_tiling.disable_bev_tiling(cfg.enc)
     del cfg
     torch.cuda.empty_cache()

@@ -2,9 +2,17 @@
 
 The reference only knows data parallelism (one sample per GPU,
 bevformer/apis/mmdet_train.py:75-79).  This module adds the partition named by
-the north star: the ``bev_h x bev_w`` grid is cut into contiguous row blocks,
-rank r runs the whole layer stack on its block, and the grid is reassembled
-with an all-gather (RCCL over xGMI; ``gloo`` in the CPU tests).
+the north star: the ``bev_h x bev_w`` grid is cut into tiles, rank r runs the
+whole layer stack on its tile, and the grid is reassembled with an all-gather
+(RCCL over xGMI; ``gloo`` in the CPU tests).  Two layouts: ``rows`` —
+contiguous blocks of BEV rows — and ``sectors`` — equal ranges of the cells
+ordered by azimuth around the ego vehicle (``geometry.sector_permutation``): a
+sector is seen by 1-3 of the 6 cameras where a row block is seen by 3-4, and
+the replicated camera-value projection skips the cameras a rank cannot see.
+In the sector layout the per-query tensors of a rank (queries, positional
+encoding, frame plan, reference points) are in sector order; everything that is
+SAMPLED spatially (camera features, the history / current BEV grid) and the
+encoder's output stay in grid order.
 
 Why this is exact: every per-query operation of a layer (projections, softmax,
 sampling, scatter-mean, output projection, FFN, LayerNorm; encoder.py:356-404)
@@ -37,6 +45,7 @@ class BevTiling:
     GPU (bench.py's ``multi_gpu_model``); the output is NOT the encoder's output."""
     group: Optional[object] = None
     simulate: Optional[tuple] = None
+    layout: str = "rows"                 # "rows" | "sectors" (enable_bev_tiling resolves "auto")
 
     @property
     def world(self):
@@ -47,12 +56,23 @@ class BevTiling:
         return self.simulate[0] if self.simulate else dist.get_rank(self.group)
 
 
-def enable_bev_tiling(encoder, group=None, simulate=None):
+LAYOUTS = ("auto", "rows", "sectors")
+
+
+def enable_bev_tiling(encoder, group=None, simulate=None, layout="auto"):
     """Switch ``encoder.forward`` to the tiled schedule on an initialised
-    ``torch.distributed`` process group (one process per GPU); ``simulate``: see ``BevTiling``."""
+    ``torch.distributed`` process group (one process per GPU); ``simulate``: see ``BevTiling``;
+    ``layout``: ``rows``, ``sectors`` (module docstring) or ``auto`` = by measurement (bench.py ``multi_gpu_model``,
+    profiles/r3): two half-planes see as many cameras as two row blocks and sample less locally (0.65 vs 0.68 modelled
+    efficiency), from 3 ranks on the sectors win (8 ranks: 2 cameras per rank instead of 3-4, 0.32 vs 0.30)."""
     if simulate is None and not dist.is_initialized():
         raise RuntimeError("enable_bev_tiling needs an initialised torch.distributed group")
-    encoder.bev_tiling = BevTiling(group, tuple(simulate) if simulate is not None else None)
+    if layout not in LAYOUTS:
+        raise ValueError(f"layout must be one of {LAYOUTS}")
+    t = BevTiling(group, tuple(simulate) if simulate is not None else None, layout)
+    if layout == "auto":
+        t.layout = "sectors" if t.world >= 3 else "rows"
+    encoder.bev_tiling = t
     return encoder
 
 
@@ -71,6 +91,33 @@ def row_blocks(bev_h, world):
         out.append((h, h + n))
         h += n
     return out
+
+
+def query_blocks(num_queries, world):
+    """Equal contiguous ranges of a query order (the sector layout): -> list of (q0, q1)."""
+    base, extra = divmod(num_queries, world)
+    out, q = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((q, q + n))
+        q += n
+    return out
+
+
+_PERMS = {}
+
+
+def sector_order(bev_h, bev_w, pc_range, device):
+    """(name, perm, inverse) of the sector layout on ``device``: ``perm[q'] = cell``, ``inverse[cell] = q'``."""
+    key = (bev_h, bev_w, tuple(float(v) for v in pc_range), str(device))
+    hit = _PERMS.get(key)
+    if hit is None:
+        from .modules.geometry import sector_permutation
+        perm = sector_permutation(bev_h, bev_w, [float(v) for v in pc_range])
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        hit = _PERMS[key] = (f"sectors{bev_h}x{bev_w}", perm.to(device), inv.to(device), perm)
+    return hit
 
 
 def slice_plan(plan, q0, q1):
@@ -95,11 +142,14 @@ def slice_plan(plan, q0, q1):
         max_cam_rows=max_cam_rows)
 
 
-def all_gather_rows(local, blocks, bev_w, group=None, simulate=None):
+def all_gather_rows(local, blocks, bev_w, group=None, simulate=None, inverse=None):
     """local (bs, rows_r*bev_w, C) on every rank -> (bs, Q, C).  Blocks may be
-    uneven (padded to the largest for the collective)."""
+    uneven (padded to the largest for the collective).  ``inverse`` (sector layout): the gathered queries are in
+    sector order; ``inverse[cell]`` is the position of a grid cell in it — the result is in grid order."""
     world = len(blocks)
     sizes = [(h1 - h0) * bev_w for h0, h1 in blocks]
+    if inverse is not None:
+        return all_gather_rows(local, blocks, bev_w, group, simulate).index_select(1, inverse)
     if simulate is not None:                 # single-process timing run: my shard into an otherwise empty grid
         full = local.new_zeros(local.shape[0], sum(sizes), local.shape[2])
         q0 = sum(sizes[:simulate[0]])
@@ -131,17 +181,27 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
         # all_gather_into_tensor is not differentiable: the tiled schedule is inference-only
         raise RuntimeError("BEV tiling is an inference schedule (its all-gather has no autograd); "
                            "call it under torch.no_grad() or disable_bev_tiling() for training")
-    blocks = row_blocks(bev_h, world)
-    h0, h1 = blocks[rank]
-    q0, q1 = h0 * bev_w, h1 * bev_w
+    sectors = tiling.layout == "sectors"
+    cell_perm = rows_idx = inverse = None
+    if sectors:
+        # queries in sector order: tile = a contiguous range of that order; blocks in units of ONE query
+        pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, bev_query.device)
+        cell_perm = (pname, perm_cpu)
+        blocks, unit = query_blocks(bev_h * bev_w, world), 1
+        q0, q1 = blocks[rank]
+        rows_idx = perm[q0:q1]                  # the grid cells of my queries
+    else:
+        blocks, unit = row_blocks(bev_h, world), bev_w
+        h0, h1 = blocks[rank]
+        q0, q1 = h0 * bev_w, h1 * bev_w
     if encoder.device_plans and bev_query.is_cuda:
         # device-side plan of my tile: rows only for queries [q0, q1), tile-local slot numbering
         tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                                  bev_query.dtype, tile=(q0, q1))
+                                  bev_query.dtype, tile=(q0, q1), cell_perm=cell_perm)
         full_ref_2d = tile.ref_2d_full
     else:
         plan = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                                  bev_query.dtype)
+                                  bev_query.dtype, cell_perm=cell_perm)
         full_ref_2d = plan.ref_2d
         cache = getattr(plan, "_tiles", None)
         if cache is None:
@@ -153,7 +213,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     ref_2d = full_ref_2d
     shift_ref_2d = ref_2d + shift[:, None, None, :]
     full_query = bev_query.permute(1, 0, 2)
-    pos_local = bev_pos.permute(1, 0, 2)[:, q0:q1]
+    take = (lambda t: t.index_select(1, rows_idx)) if sectors else (lambda t: t[:, q0:q1])
+    pos_local = take(bev_pos.permute(1, 0, 2))
     Q = ref_2d.shape[1]
     if prev_bev is not None:
         tsa_value = torch.stack([prev_bev.permute(1, 0, 2), full_query], 1).reshape(bs * 2, Q, -1)
@@ -163,7 +224,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
         hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
     hybrid = hybrid[:, q0:q1].contiguous()
 
-    x = full_query[:, q0:q1].contiguous()
+    x = take(full_query).contiguous()
     inter = []
     # replicated, layer-invariant value projections: one grouped GEMM each (encoder.py docstring)
     # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
@@ -179,7 +240,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
             hoisted["tsa_projected_value"] = tsa_vals[li]
         if prev_bev is None:
             # no history: TSA's value is the CURRENT full BEV -> exchange per layer
-            full = full_query if li == 0 else all_gather_rows(x, blocks, bev_w, group, tiling.simulate)
+            full = full_query if li == 0 else all_gather_rows(x, blocks, unit, group, tiling.simulate, inverse)
             layer_value = torch.stack([full, full], 1).reshape(bs * 2, Q, -1)
         else:
             layer_value = tsa_value
@@ -187,9 +248,9 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                   bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
                   level_start_index=level_start_index,
                   reference_points_cam=tile.reference_points_cam, bev_mask=tile.bev_mask,
-                  prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), **hoisted, **kwargs)
+                  prev_bev=layer_value, frame_plan=tile, bev_slice=(q0, q1), bev_rows=rows_idx, **hoisted, **kwargs)
         if encoder.return_intermediate:
-            inter.append(all_gather_rows(x, blocks, bev_w, group, tiling.simulate))
+            inter.append(all_gather_rows(x, blocks, unit, group, tiling.simulate, inverse))
     if encoder.return_intermediate:
         return torch.stack(inter)
-    return all_gather_rows(x, blocks, bev_w, group, tiling.simulate)
+    return all_gather_rows(x, blocks, unit, group, tiling.simulate, inverse)

@@ -91,34 +91,36 @@ class BEVFormerEncoder(TransformerLayerSequence):
             return self.sca_row_order
         return "image"
 
-    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None):
+    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None, cell_perm=None):
         """The per-frame geometry.  On a GPU: two kernel launches into the planner's buffers, no
         host synchronisation (under autograd the plan is then materialised: one read of the row
         count, the torch statements of that path need sizes).  ``tile = (q0, q1)``: rows only for
-        those BEV queries (bev_tiling)."""
+        those BEV queries (bev_tiling).  ``cell_perm = (name, perm)``: the plan's queries are the BEV cells in that order
+        (bev_tiling's sector layout; ``name`` keys the caches)."""
         device = torch.device(device)
         order = self.row_order()
+        pname, perm = cell_perm if cell_perm is not None else (None, None)
         if self.device_plans and device.type == "cuda":
             num_cams = len(img_metas[0]["lidar2img"])
-            key = (bev_h, bev_w, bs, str(device), order, tile, num_cams, self.num_points_in_pillar)
+            key = (bev_h, bev_w, bs, str(device), order, tile, num_cams, self.num_points_in_pillar, pname)
             planner = self._planners.get(key)
             if planner is None:
                 if len(self._planners) >= 8:
                     self._planners.pop(next(iter(self._planners)))
                 planner = self._planners[key] = geometry.DevicePlanner(
                     bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar, num_cams, device,
-                    row_order=order, tile=tile)
+                    row_order=order, tile=tile, cell_perm=perm)
             plan = planner.plan(img_metas)
             return plan.materialize() if torch.is_grad_enabled() else plan
         assert tile is None, "tiles of a host-built plan come from bev_tiling.slice_plan"
         assert order in geometry.ROW_ORDERS, f"host-built plans know the row orders {geometry.ROW_ORDERS}"
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
-                                img_metas, device, dtype) + (order,)
+                                img_metas, device, dtype) + (order, pname)
         plan = self._plan_cache.get(key)
         if plan is None:
             plan = geometry.build_frame_plan(bev_h, bev_w, bs, self.pc_range,
                                              self.num_points_in_pillar, img_metas, device, dtype,
-                                             row_order=order)
+                                             row_order=order, cell_perm=perm)
             if len(self._plan_cache) >= self.plan_cache_size:
                 self._plan_cache.pop(next(iter(self._plan_cache)))
             self._plan_cache[key] = plan

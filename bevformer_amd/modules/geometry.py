@@ -215,11 +215,27 @@ def build_q_rows(row_query, num_slots):
     return table
 
 
+def sector_permutation(bev_h, bev_w, pc_range):
+    """BEV cells ordered by azimuth around the ego origin (ties by range): ``perm[q'] = cell``.  Contiguous ranges of
+    this order are angular sectors — the partition of bev_tiling's ``sectors`` layout: a sector's queries are seen by
+    1-3 of the 6 cameras where a block of BEV rows is seen by 3-4.  (H * W,) int64, on the CPU."""
+    xs = (np.arange(bev_w) + 0.5) / bev_w * (pc_range[3] - pc_range[0]) + pc_range[0]
+    ys = (np.arange(bev_h) + 0.5) / bev_h * (pc_range[4] - pc_range[1]) + pc_range[1]
+    qx, qy = np.tile(xs, bev_h), np.repeat(ys, bev_w)
+    az = np.round(np.arctan2(qy, qx), 9)
+    return torch.from_numpy(np.lexsort((np.hypot(qx, qy), az)).astype(np.int64))
+
+
 def build_frame_plan(bev_h, bev_w, bs, pc_range, num_points_in_pillar, img_metas, device,
-                     dtype=torch.float32, row_order="raster"):
+                     dtype=torch.float32, row_order="raster", cell_perm=None):
+    """``cell_perm`` (Q,) long: query q' of the plan is BEV cell ``cell_perm[q']`` (bev_tiling's sector layout); every
+    per-query tensor of the plan is then in that order."""
     ref_3d = get_reference_points(bev_h, bev_w, pc_range[5] - pc_range[2], num_points_in_pillar,
                                   dim="3d", bs=bs, device=device, dtype=dtype)
     ref_2d = get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device=device, dtype=dtype)
+    if cell_perm is not None:
+        cp = cell_perm.to(ref_3d.device)
+        ref_3d, ref_2d = ref_3d.index_select(2, cp).contiguous(), ref_2d.index_select(1, cp).contiguous()
     ref_cam, bev_mask = point_sampling(ref_3d, pc_range, img_metas)
     plan = FramePlan(bs=bs, bev_h=bev_h, bev_w=bev_w, ref_3d=ref_3d, ref_2d=ref_2d,
                      reference_points_cam=ref_cam, bev_mask=bev_mask,
@@ -312,7 +328,7 @@ class DevicePlanner:
     and a captured HIP graph of the step keeps pointing at the right memory."""
 
     def __init__(self, bev_h, bev_w, bs, pc_range, num_points_in_pillar, num_cams, device,
-                 row_order="polar", tile=None, row_capacity=None):
+                 row_order="polar", tile=None, row_capacity=None, cell_perm=None):
         from .. import _lib
         self.bev_h, self.bev_w, self.bs, self.D, self.Nc = bev_h, bev_w, bs, num_points_in_pillar, num_cams
         self.pc_range = [float(v) for v in pc_range]
@@ -328,6 +344,14 @@ class DevicePlanner:
                                            dim="3d", bs=bs, device="cpu", dtype=torch.float32).to(device)
         self.ref_2d = get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device="cpu",
                                            dtype=torch.float32).to(device)
+        # query q' = BEV cell cell_perm[q'] (bev_tiling's sector layout): the kernels only ever see per-query tables
+        self.cell_perm = None if cell_perm is None else cell_perm.cpu().long()
+        if self.cell_perm is not None:
+            cp = self.cell_perm.to(device)
+            self.ref_3d = self.ref_3d.index_select(2, cp).contiguous()
+            self.ref_2d = self.ref_2d.index_select(1, cp).contiguous()
+            self._inv_perm = torch.empty_like(self.cell_perm)
+            self._inv_perm[self.cell_perm] = torch.arange(Q)
         if row_order == "polar":
             order = polar_order(bev_h, bev_w, self.pc_range)
         elif row_order == "raster":
@@ -337,6 +361,8 @@ class DevicePlanner:
         else:
             raise ValueError(f"device plans know the row orders 'image', 'polar' and 'raster', not {row_order!r}")
         self.row_order = row_order
+        if order is not None and self.cell_perm is not None:
+            order = self._inv_perm.numpy()[order].astype(np.int32)      # the same walk over the cells, in query ids
         self.order = torch.from_numpy(order).to(device) if order is not None else None
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         self.l2i = torch.zeros(bs, num_cams, 4, 4, dtype=f32, device=device)
@@ -367,8 +393,10 @@ class DevicePlanner:
         first = img_metas[0]["lidar2img"]
         shp = img_metas[0]["img_shape"][0]
         if self.order is None:                  # one-time calibration of the static row order (host work)
-            self.order = torch.from_numpy(calibrated_image_order(
-                self.bev_h, self.bev_w, self.pc_range, self.D, img_metas)).to(self.device)
+            order = calibrated_image_order(self.bev_h, self.bev_w, self.pc_range, self.D, img_metas)
+            if self.cell_perm is not None:
+                order = self._inv_perm.numpy()[order].astype(np.int32)
+            self.order = torch.from_numpy(order).to(self.device)
         if torch.is_tensor(first):
             self._last = None
             for j, m in enumerate(img_metas):

@@ -170,7 +170,9 @@ class TemporalSelfAttention(BaseModule):
                 # from, it needs no gradient when the history is detached (the reference computes it under no_grad,
                 # bevformer.py:158-177) — through the stacked tensor autograd computes one, pads it and adds it, per layer
                 first = hist
-            if bev_slice is not None:
+            if kwargs.get("bev_rows") is not None:                      # (BEV tiling, sector layout: my queries' cells)
+                first = first.index_select(1, kwargs["bev_rows"])
+            elif bev_slice is not None:
                 first = first[:, bev_slice[0]:bev_slice[1]]
         src = query_in if shared_value else value
         num_value = src.shape[1]

@@ -252,8 +252,19 @@ def test_encoder_when_no_camera_sees_anything(temporal):
     torch.testing.assert_close(out.detach().cpu(), want, rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("name,world,temporal", [("micro4", 2, True), ("tiny", 5, True), ("micro4", 3, False)])
-def test_simulated_rank_on_the_gpu_equals_its_rows_of_the_untiled_encoder(name, world, temporal):
+def _rank_cells(w, world, rank, layout):
+    from bevformer_amd import bev_tiling
+    if layout == "rows":
+        h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+        return torch.arange(h0 * w["bev_w"], h1 * w["bev_w"], device=DEV)
+    q0, q1 = bev_tiling.query_blocks(w["bev_h"] * w["bev_w"], world)[rank]
+    return bev_tiling.sector_order(w["bev_h"], w["bev_w"], S.PC_RANGE, DEV)[1][q0:q1]
+
+
+@pytest.mark.parametrize("name,world,temporal,layout", [("micro4", 2, True, "rows"), ("tiny", 5, True, "rows"), ("micro4", 3, False, "rows"),
+                                                        ("tiny", 5, True, "sectors"), ("micro4", 3, True, "sectors"),
+                                                        ("micro4", 2, False, "sectors")])
+def test_simulated_rank_on_the_gpu_equals_its_rows_of_the_untiled_encoder(name, world, temporal, layout):
     """The N > 1 schedule on the HIP path, one rank at a time in one process (``BevTiling.simulate``): device plan
     of the rank's tile (tile-local row tables), fused kernels over the tile's rows, hoisted projections — the
     rows of the rank's shard must be the untiled encoder's rows.  (With history only: without it TemporalSelfAttention
@@ -269,16 +280,15 @@ def test_simulated_rank_on_the_gpu_equals_its_rows_of_the_untiled_encoder(name, 
     with torch.no_grad():
         want = enc(q, f, f, **kw)
         for rank in range(world):
-            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world), layout=layout)
             got = enc(q, f, f, **kw)
             bev_tiling.disable_bev_tiling(enc)
-            h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
-            q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
-            torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-4, atol=1e-4)
+            mine = _rank_cells(w, world, rank, layout)
+            torch.testing.assert_close(got[:, mine], want[:, mine], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("name,world", [("tiny", 5), ("micro4", 3)])
-def test_tiled_rank_skips_the_value_projection_of_cameras_it_cannot_see(name, world):
+@pytest.mark.parametrize("name,world,layout", [("tiny", 5, "rows"), ("micro4", 3, "rows"), ("tiny", 5, "sectors"), ("tiny", 8, "sectors")])
+def test_tiled_rank_skips_the_value_projection_of_cameras_it_cannot_see(name, world, layout):
     """BEV tiling over GPUs: the camera-feature value projection is replicated work, but a rank's tile only samples
     cameras that some of its queries project into — the tile plan's device-side camera starts gate the projection's
     workgroups (``ops.linear(segments=...)``).  With the projection's output pre-filled with NaN, every rank's rows
@@ -303,13 +313,12 @@ def test_tiled_rank_skips_the_value_projection_of_cameras_it_cannot_see(name, wo
             want = enc(q, f, f, **kw)
             assert not seen                         # the untiled encoder projects every camera
             for rank in range(world):
-                bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+                bev_tiling.enable_bev_tiling(enc, simulate=(rank, world), layout=layout)
                 got = enc(q, f, f, **kw)
                 bev_tiling.disable_bev_tiling(enc)
-                h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
-                q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
-                assert torch.isfinite(got[:, q0:q1]).all()
-                torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-4, atol=1e-4)
+                mine = _rank_cells(w, world, rank, layout)
+                assert torch.isfinite(got[:, mine]).all()
+                torch.testing.assert_close(got[:, mine], want[:, mine], rtol=1e-4, atol=1e-4)
     finally:
         ops.linear = real
         ops._SEGMENT_POISON["on"] = False

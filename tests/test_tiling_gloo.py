@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, temporal, bs, ret):
+def _worker(rank, world, port, name, temporal, bs, layout, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,7 +37,7 @@ def _worker(rank, world, port, name, temporal, bs, ret):
         q, f, kw = S.make_inputs(name, seed=0, temporal=temporal, bs=bs)
         with oracle_ops(), torch.no_grad():
             want = enc(q, f, f, **kw)
-            bev_tiling.enable_bev_tiling(enc)
+            bev_tiling.enable_bev_tiling(enc, layout=layout)
             got = enc(q, f, f, **kw)
             bev_tiling.disable_bev_tiling(enc)
         err = (got - want).abs().max().item()
@@ -50,11 +50,14 @@ def _worker(rank, world, port, name, temporal, bs, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,temporal,bs,world", [("micro", True, 1, 2), ("micro", False, 1, 2),
-                                                    ("micro4", True, 2, 2), ("micro", True, 1, 5)])
-def test_two_rank_tiling_matches_single(name, temporal, bs, world):
+@pytest.mark.parametrize("name,temporal,bs,world,layout", [("micro", True, 1, 2, "rows"), ("micro", False, 1, 2, "rows"),
+                                                           ("micro4", True, 2, 2, "rows"), ("micro", True, 1, 5, "rows"),
+                                                           ("micro", True, 1, 2, "sectors"), ("micro", False, 1, 3, "sectors"),
+                                                           ("micro4", True, 2, 5, "sectors")])
+def test_two_rank_tiling_matches_single(name, temporal, bs, world, layout):
     """world 2 (even row blocks) and world 5 (12 BEV rows -> blocks of 3, 3, 2, 2, 2: padded shards
-    in the all-gather)."""
+    in the all-gather); the sector layout (queries in azimuth order, output back in grid order) with and without
+    history and with uneven shards."""
     from bevformer_amd import synthetic as S
     try:
         S.make_inputs(name, seed=0, temporal=temporal, bs=bs)
@@ -63,7 +66,7 @@ def test_two_rank_tiling_matches_single(name, temporal, bs, world):
     port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, name, temporal, bs, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, name, temporal, bs, layout, ret), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
         err, same, shape = ret[r]
@@ -83,8 +86,27 @@ def test_row_blocks_cover_grid_unevenly():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 5])
-def test_simulated_rank_equals_its_rows_of_the_untiled_encoder(world):
+def test_sector_permutation_is_a_permutation_by_azimuth():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from bevformer_amd.modules.geometry import sector_permutation
+    from bevformer_amd import bev_tiling
+    pc = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    for h, w in ((12, 10), (50, 50), (7, 9)):
+        perm = sector_permutation(h, w, pc)
+        assert sorted(perm.tolist()) == list(range(h * w))
+        xs = (np.arange(w) + 0.5) / w * 102.4 - 51.2
+        ys = (np.arange(h) + 0.5) / h * 102.4 - 51.2
+        az = np.arctan2(np.repeat(ys, w), np.tile(xs, h))[perm.numpy()]
+        assert (np.diff(az) >= -1e-8).all()
+        for world in (2, 3, 8):
+            b = bev_tiling.query_blocks(h * w, world)
+            assert b[0][0] == 0 and b[-1][1] == h * w and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(q1 - q0 for q0, q1 in b) - min(q1 - q0 for q0, q1 in b) <= 1
+
+
+@pytest.mark.parametrize("world,layout", [(2, "rows"), (5, "rows"), (3, "sectors")])
+def test_simulated_rank_equals_its_rows_of_the_untiled_encoder(world, layout):
     """``BevTiling.simulate = (rank, world)`` (bench.py's ``multi_gpu_model`` / ``--simulate-rank``): one process, no
     process group, the all-gather replaced by the copy of the rank's own shard — the rows of that shard must be the
     untiled encoder's rows, for every rank (host logic on the CPU, operator calls through the oracle)."""
@@ -100,10 +122,16 @@ def test_simulated_rank_equals_its_rows_of_the_untiled_encoder(world):
     with oracle_ops(), torch.no_grad():
         want = enc(q, f, f, **kw)
         for rank in range(world):
-            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world))
+            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world), layout=layout)
             got = enc(q, f, f, **kw)
             bev_tiling.disable_bev_tiling(enc)
-            h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
-            q0, q1 = h0 * w["bev_w"], h1 * w["bev_w"]
-            torch.testing.assert_close(got[:, q0:q1], want[:, q0:q1], rtol=1e-5, atol=1e-5)
-            assert (got[:, :q0] == 0).all() and (got[:, q1:] == 0).all()
+            if layout == "rows":
+                h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+                mine = torch.arange(h0 * w["bev_w"], h1 * w["bev_w"])
+            else:
+                q0, q1 = bev_tiling.query_blocks(w["bev_h"] * w["bev_w"], world)[rank]
+                mine = bev_tiling.sector_order(w["bev_h"], w["bev_w"], S.PC_RANGE, "cpu")[1][q0:q1]
+            other = torch.ones(got.shape[1], dtype=torch.bool)
+            other[mine] = False
+            torch.testing.assert_close(got[:, mine], want[:, mine], rtol=1e-5, atol=1e-5)
+            assert (got[:, other] == 0).all()
