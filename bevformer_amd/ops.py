@@ -624,14 +624,16 @@ def panel_weight(weight):
     return blob
 
 
-def _panel_covers(N, K0, K1, groups, ln):
+def _panel_covers(N, K0, K1, groups, ln, M=None):
     """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h) and, unless a kernel is forced, the ones it is
     faster on (tools/gemm_ab.py, profiles/r3): the hoisted value projections (N >= 1024: 510-570 vs 630 us and 254 vs
-    270 us per frame in split mode) and the LayerNorm-fused projections (45 vs 52 us, 59 vs 66 us); the plain
-    per-layer projections (N <= 768, 40 k rows) stay on the first kernel (30-70 us, 5-10 % ahead)."""
+    270 us per frame in split mode), the LayerNorm-fused projections (45 vs 52 us, 59 vs 66 us) and the two-source
+    projection of TemporalSelfAttention at tile-sized row counts (a rank's share of a BEV-tiled frame: 64-row panels give
+    twice the workgroups of 128-row tiles — 19.0 vs 26.1 us at 5,000 rows, level from 20,000 on: tools/tsa_proj_small_m.py);
+    the plain per-layer projections (N <= 768, 40 k rows) stay on the first kernel (30-70 us, 5-10 % ahead)."""
     K = K0 + K1
     kern = _m().gemm_kernel
-    want = (ln or N >= 1024) if kern is None else kern.startswith("panel")
+    want = (ln or N >= 1024 or (K1 > 0 and M is not None and M <= 16384)) if kern is None else kern.startswith("panel")
     if not want or _m().gemm_variant is not None or K not in (256, 512) or K0 not in (256, 512) \
             or K1 not in (0, 256) or N % 4:
         return False
@@ -775,7 +777,7 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
                            out_bf16=int(out_dtype == torch.bfloat16))
     if accumulate_into is not None:
         desc.reserved[0] = 1                # y += result (first kernel)
-    if accumulate_into is None and _m().gemm_pack and _panel_covers(N, K0, K1, groups, False):
+    if accumulate_into is None and _m().gemm_pack and _panel_covers(N, K0, K1, groups, False, M):
         nbytes = 4 * (M * (K0 + K1) * (1 + (a0 is not None)) + N * (K0 + K1) + M * N)
         if _panel_call(desc, x0, a0, x1, a1, None, None, w, b, None, y, tag, 2.0 * M * N * (K0 + K1), nbytes,
                        segments=segments):
