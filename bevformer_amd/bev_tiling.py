@@ -214,7 +214,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     shift_ref_2d = ref_2d + shift[:, None, None, :]
     full_query = bev_query.permute(1, 0, 2)
     take = (lambda t: t.index_select(1, rows_idx)) if sectors else (lambda t: t[:, q0:q1])
-    pos_local = take(bev_pos.permute(1, 0, 2))
+    pos_local = take(bev_pos.permute(1, 0, 2)).contiguous()     # (once per frame, not once per layer)
     Q = ref_2d.shape[1]
     if prev_bev is not None:
         tsa_value = torch.stack([prev_bev.permute(1, 0, 2), full_query], 1).reshape(bs * 2, Q, -1)

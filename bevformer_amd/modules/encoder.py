@@ -213,7 +213,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
         shift_ref_2d = ref_2d + shift[:, None, None, :]
 
         bev_query = bev_query.permute(1, 0, 2)
-        bev_pos = bev_pos.permute(1, 0, 2)
+        # (through get_bev_features the positional encoding arrives as a transposed view of (bs, C, H*W): made contiguous
+        # HERE, once per frame — left to the kernels' argument checks it was copied by every layer, 60 us each)
+        bev_pos = bev_pos.permute(1, 0, 2).contiguous()
         len_bev = ref_2d.shape[1]
         history = None
         if prev_bev is not None:
