@@ -126,6 +126,22 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._plan_cache[key] = plan
         return plan
 
+    def _contiguous_pos(self, pos):
+        """``pos`` (bs, Q, C) with unit stride along C.  The positional encoding of the BEV grid does not change from
+        frame to frame: at inference the copy is kept for as long as the caller hands in the same (unmodified) memory —
+        the cache holds the source's storage, so its address cannot be recycled for other values behind its back."""
+        if pos.is_contiguous():
+            return pos
+        if torch.is_grad_enabled() and pos.requires_grad:
+            return pos.contiguous()
+        storage = pos.untyped_storage()
+        key = (storage.data_ptr(), pos.storage_offset(), pos._version, tuple(pos.shape), tuple(pos.stride()), pos.dtype)
+        hit = self.__dict__.get("_pos_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, pos.detach().contiguous(), storage)
+            self.__dict__["_pos_cache"] = hit
+        return hit[1]
+
     def hoisted_value_projections(self, value, tsa_value, plan=None, spatial_shapes=None):
         """The layer-invariant projections, issued once for all layers.
 
@@ -215,7 +231,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         bev_query = bev_query.permute(1, 0, 2)
         # (through get_bev_features the positional encoding arrives as a transposed view of (bs, C, H*W): made contiguous
         # HERE, once per frame — left to the kernels' argument checks it was copied by every layer, 60 us each)
-        bev_pos = bev_pos.permute(1, 0, 2).contiguous()
+        bev_pos = self._contiguous_pos(bev_pos.permute(1, 0, 2))
         len_bev = ref_2d.shape[1]
         history = None
         if prev_bev is not None:

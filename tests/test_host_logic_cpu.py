@@ -119,3 +119,25 @@ def test_modes_are_thread_local_overrides_of_process_defaults():
     with pytest.raises(AttributeError):
         with ops.using(no_such_mode=1):
             pass
+
+
+def test_positional_encoding_copy_is_cached_only_for_unmodified_memory():
+    """``BEVFormerEncoder._contiguous_pos``: the contiguous copy of a transposed positional encoding is reused while the
+    caller hands in the same, unmodified memory — and never after an in-place write or for another tensor."""
+    import torch
+    import bevformer_amd
+    from bevformer_amd import synthetic as S
+    enc = bevformer_amd.build_transformer_layer_sequence(S.encoder_cfg("micro")).eval()
+    base = torch.randn(1, 8, 12)                       # (bs, C, Q): the layout get_bev_features flattens from
+    with torch.no_grad():
+        a = enc._contiguous_pos(base.permute(0, 2, 1))
+        b = enc._contiguous_pos(base.permute(0, 2, 1))
+        assert a is b and a.is_contiguous() and torch.equal(a, base.permute(0, 2, 1))
+        base.mul_(2.0)                                 # in-place write: version counter moves
+        c = enc._contiguous_pos(base.permute(0, 2, 1))
+        assert c is not a and torch.equal(c, base.permute(0, 2, 1))
+        other = torch.randn(1, 8, 12)
+        d = enc._contiguous_pos(other.permute(0, 2, 1))
+        assert torch.equal(d, other.permute(0, 2, 1))
+        cont = torch.randn(1, 12, 8)
+        assert enc._contiguous_pos(cont) is cont
