@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, temporal, ret):
+def _worker(rank, world, port, name, temporal, layout, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,7 +38,7 @@ def _worker(rank, world, port, name, temporal, ret):
         q, f, kw = S.make_inputs(name, seed=0, temporal=temporal, device=dev)
         with torch.no_grad():
             want = enc(q, f, f, **kw)
-            bev_tiling.enable_bev_tiling(enc)
+            bev_tiling.enable_bev_tiling(enc, layout=layout)
             got = enc(q, f, f, **kw)
             bev_tiling.disable_bev_tiling(enc)
         err = (got - want).abs().max().item()
@@ -50,13 +50,14 @@ def _worker(rank, world, port, name, temporal, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,temporal", [("tiny", True), ("tiny", False), ("micro4", True)])
-def test_tiled_encoder_over_rccl_matches_single_gpu(name, temporal):
+@pytest.mark.parametrize("name,temporal,layout", [("tiny", True, "rows"), ("tiny", False, "rows"), ("micro4", True, "rows"),
+                                                  ("tiny", True, "sectors"), ("tiny", False, "sectors")])
+def test_tiled_encoder_over_rccl_matches_single_gpu(name, temporal, layout):
     world = min(torch.cuda.device_count(), 8)
     if world < 2:
         pytest.skip("needs at least two GPUs (RCCL all-gather between processes)")
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), name, temporal, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, temporal, layout, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         err, same, _ = ret[rank]
