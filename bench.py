@@ -736,7 +736,8 @@ def main():
                        "sca_row_order": row_order_used,
                        "value_storage": args.value_storage,
                        "gemm": gemm_desc,
-                       "global_batch": 1, "parallelism": f"bev-row-tiles x{world}" if world > 1 else "single GPU",
+                       "global_batch": 1, "parallelism": (f"bev-{cfg.enc.bev_tiling.layout if getattr(cfg.enc, 'bev_tiling', None) is not None else 'row'}-tiles x{world}"
+                                       if world > 1 else "single GPU"),
                        "sca_rows_per_frame": rows_per_frame},
             "windows": {"ms_per_step": [round(p, 4) for p in per], "min": min(per), "median": statistics.median(per),
                         "n": len(per), "note": "ms_per_step / value = the median window"},
