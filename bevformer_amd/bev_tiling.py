@@ -225,6 +225,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     hybrid = hybrid[:, q0:q1].contiguous()
 
     x = take(full_query).contiguous()
+    history_local = take(prev_bev.permute(1, 0, 2)).contiguous() if (prev_bev is not None and bs == 1) else None
     inter = []
     # replicated, layer-invariant value projections: one grouped GEMM each (encoder.py docstring)
     # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
@@ -232,6 +233,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                                                             spatial_shapes=spatial_shapes)
     for li, layer in enumerate(encoder.layers):
         hoisted = {}
+        if history_local is not None:
+            hoisted["tsa_history"] = history_local       # (the K source of TSA's projection: gathered once, not per layer)
         if sca_vals is not None:
             hoisted["projected_value"] = sca_vals[li]
             if li == 0 and getattr(encoder, "_sca_ready", None) is not None:

@@ -165,14 +165,18 @@ class TemporalSelfAttention(BaseModule):
         else:
             first = value[:bs]
             hist = kwargs.get("tsa_history")
-            if hist is not None and bs == 1 and hist.shape == first.shape:
+            tiled = kwargs.get("bev_rows") is not None or bev_slice is not None
+            if hist is not None and bs == 1 and tiled and tuple(hist.shape) == (bs, Q, first.shape[-1]):
+                # BEV tiling: the history rows of MY queries, gathered once per frame by the schedule
+                first, tiled = hist, False
+            elif hist is not None and bs == 1 and not tiled and hist.shape == first.shape:
                 # value[:1] IS the history BEV (stack([prev_bev, bev_query], 1)[0]); taken from the tensor it was stacked
                 # from, it needs no gradient when the history is detached (the reference computes it under no_grad,
                 # bevformer.py:158-177) — through the stacked tensor autograd computes one, pads it and adds it, per layer
                 first = hist
-            if kwargs.get("bev_rows") is not None:                      # (BEV tiling, sector layout: my queries' cells)
+            if tiled and kwargs.get("bev_rows") is not None:              # (BEV tiling, sector layout: my queries' cells)
                 first = first.index_select(1, kwargs["bev_rows"])
-            elif bev_slice is not None:
+            elif tiled and bev_slice is not None:
                 first = first[:, bev_slice[0]:bev_slice[1]]
         src = query_in if shared_value else value
         num_value = src.shape[1]
