@@ -107,13 +107,22 @@ def query_blocks(num_queries, world):
 _PERMS = {}
 
 
-def sector_order(bev_h, bev_w, pc_range, device):
-    """(name, perm, inverse) of the sector layout on ``device``: ``perm[q'] = cell``, ``inverse[cell] = q'``."""
-    key = (bev_h, bev_w, tuple(float(v) for v in pc_range), str(device))
+def sector_order(bev_h, bev_w, pc_range, device, group=None, collective=False):
+    """(name, perm, inverse, perm on the CPU) of the sector layout on ``device``: ``perm[q'] = cell``,
+    ``inverse[cell] = q'``.  ``collective`` (a real process group, not a simulated rank): every rank takes RANK 0's
+    permutation (one broadcast, once per grid) — the order comes out of float ``arctan2`` / ``hypot`` and a sort, and
+    ranks whose libm or numpy round a tie differently would otherwise slice their tiles from different orders and
+    reassemble a silently scrambled grid."""
+    key = (bev_h, bev_w, tuple(float(v) for v in pc_range), str(device), id(group) if collective else None)
     hit = _PERMS.get(key)
     if hit is None:
         from .modules.geometry import sector_permutation
         perm = sector_permutation(bev_h, bev_w, [float(v) for v in pc_range])
+        if collective and dist.is_initialized() and dist.get_world_size(group) > 1:
+            shared = perm.to(device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(shared, src=src, group=group)
+            perm = shared.cpu()
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(perm.numel())
         hit = _PERMS[key] = (f"sectors{bev_h}x{bev_w}", perm.to(device), inv.to(device), perm)
@@ -185,7 +194,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     cell_perm = rows_idx = inverse = None
     if sectors:
         # queries in sector order: tile = a contiguous range of that order; blocks in units of ONE query
-        pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, bev_query.device)
+        pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, bev_query.device, group=group,
+                                                      collective=tiling.simulate is None)
         cell_perm = (pname, perm_cpu)
         blocks, unit = query_blocks(bev_h * bev_w, world), 1
         q0, q1 = blocks[rank]

@@ -54,6 +54,8 @@ class MultiScaleDeformableAttnFunction_bf16(Function):
                 sampling_locations, attention_weights, im2col_step=64):
         ctx.im2col_step = im2col_step
         ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        from . import modes as _modes
+        ctx.lanes8 = bool(_modes.current().bf16_lanes8)    # (snapshot: backward runs on the autograd thread)
         value = value.to(torch.bfloat16).contiguous()
         sampling_locations = sampling_locations.float().contiguous()
         attention_weights = attention_weights.float().contiguous()
@@ -71,9 +73,14 @@ class MultiScaleDeformableAttnFunction_bf16(Function):
         grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         grad_loc = torch.empty_like(loc)
         grad_attn = torch.empty_like(attn)
+        tuning = None
+        if ctx.lanes8:                     # benchmark knob (modes.bf16_lanes8): the 8-byte-lane gather kernel
+            from . import _lib
+            tuning = _lib.Tuning()
+            tuning.reserved[3] = 1
         ext_module.ms_deform_attn_backward(
             value, shapes, start, loc, attn, grad_output.to(torch.bfloat16).contiguous(),
-            grad_value, grad_loc, grad_attn, im2col_step=ctx.im2col_step)
+            grad_value, grad_loc, grad_attn, im2col_step=ctx.im2col_step, tuning=tuning)
         dv, dl, da = ctx.in_dtypes
         return grad_value.to(dv), None, None, grad_loc.to(dl), grad_attn.to(da), None
 

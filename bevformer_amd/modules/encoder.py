@@ -132,8 +132,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         the cache holds the source's storage, so its address cannot be recycled for other values behind its back."""
         if pos.is_contiguous():
             return pos
-        if torch.is_grad_enabled() and pos.requires_grad:
-            return pos.contiguous()
+        if (torch.is_grad_enabled() and pos.requires_grad) or pos.is_inference():
+            return pos.contiguous()         # (inference tensors track no version counter: nothing to key a cache on)
         storage = pos.untyped_storage()
         key = (storage.data_ptr(), pos.storage_offset(), pos._version, tuple(pos.shape), tuple(pos.stride()), pos.dtype)
         hit = self.__dict__.get("_pos_cache")
@@ -201,6 +201,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
         if y is not None:
             M = scas[0].num_heads
             sca_vals = [y[i].view(bs * Nc, S, M, -1) for i in range(L)]
+            if seg is not None:
+                # segments of cameras this rank cannot see were left UNWRITTEN (torch.empty): only the fused D = 32
+                # sampling kernel, which touches at most max W + 1 rows past a used camera, may read these tensors —
+                # any other consumer (SpatialCrossAttention's fallback paths) projects the features itself
+                for v in sca_vals:
+                    v._bevmsda_partial = True
         if tsa_value is not None:
             w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
             y = ops.linear(tsa_value, w, b, groups=L, out_dtype=store, tag="tsa_value_proj")

@@ -292,6 +292,12 @@ class SpatialCrossAttention(BaseModule):
                 else:
                     slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
         if slots is None:
+            if getattr(projected_value, "_bevmsda_partial", False):
+                # a hoisted projection that skipped the cameras this rank's queries cannot see (uninitialised rows)
+                # is only good for the fused kernel above: project the features here for every other path
+                Nc, S, _, _ = value.shape
+                feats = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, S, self.embed_dims)
+                projected_value = self.deformable_attention.project_value(feats)
             if frame_plan is not None and frame_plan.dynamic:
                 # the unfused statements need the row count on the host: one read of the plan's counters
                 fp = frame_plan.materialize()

@@ -29,6 +29,8 @@ def _rows_layout(reference_points, bs, nq, Q, L):
     """(bs*nq, Q, L, 2) -> (bs*Q, nq, L, 2) contiguous, the layout the fused kernel reads.  The encoder hands every
     layer the same reference tensor: the permuted copy is made once per tensor (keyed on the object and its
     version) instead of once per layer."""
+    if reference_points.is_inference():     # (torch.inference_mode: no version counter to key the cache on)
+        return reference_points.reshape(bs, nq, Q, L, 2).permute(0, 2, 1, 3, 4).reshape(bs * Q, nq, L, 2).contiguous()
     hit = getattr(reference_points, "_bevmsda_rows", None)
     if hit is not None and hit[0] == (reference_points._version, bs, nq, Q, L):
         return hit[1]

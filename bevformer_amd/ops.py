@@ -32,6 +32,12 @@ def _forward_modes(backward):
     return wrapped
 
 
+def _ver(t):
+    """Version counter of a tensor for cache keys; inference tensors (``torch.inference_mode``) track none — and cannot
+    be written to outside inference mode — so their address alone keys the cache."""
+    return 0 if t.is_inference() else t._version
+
+
 def _m():
     """The modes of this call (bevformer_amd/modes.py): the calling thread's ``using`` block or the process defaults."""
     return _modes.current()
@@ -197,9 +203,12 @@ def fused_wanted(*tensors):
                                       and any(t is not None and t.requires_grad for t in tensors))
 
 
+_RETIRED_FUSED_KWARGS = frozenset(("cam_start", "max_cam_rows", "lds_pixels"))
+
+
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", nrows=None, launch_rows=0, **_retired):
+               tag="msda_fwd", nrows=None, launch_rows=0, **retired):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -214,6 +223,9 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     rows; R above is then the capacity of the row arrays and the returned tensor has that many
     rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``);
     ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint)."""
+    unknown = set(retired) - _RETIRED_FUSED_KWARGS
+    if unknown:         # (the options of the retired LDS-staged kernels are still accepted and ignored; a typo is not)
+        raise TypeError(f"msda_fused() got unexpected keyword arguments {sorted(unknown)}")
     _req(value.is_cuda, "bevmsda: value must be a GPU tensor (there is no CPU path)")
     store = _m().value_storage
     value = value.to(store)
@@ -544,6 +556,7 @@ _GEMM_TIMER = {"cb": None}
 # test hook: outputs of launches that may leave row segments unwritten are pre-filled with NaN, so a consumer that
 # reads a skipped row cannot go unnoticed (tests/test_frame_plan_gpu.py)
 _SEGMENT_POISON = {"on": False, "launches": 0}
+_THREAD_STATS = {"inplace": 0, "out_of_place": 0}     # GradThread: how the input gradients of threaded projections were summed
 
 
 def set_gemm_mode(mode):
@@ -575,7 +588,7 @@ def set_gemm_variant(variant=None, pack=None):
 def packed_weight(weight):
     """Pre-split bf16 image of an (N, K) fp32 weight (``bevmsda_linear_pack_weight_f32``),
     cached on the tensor object until it is written to or moved."""
-    key = (weight._version, weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
     hit = getattr(weight, "_bevmsda_pack", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -601,7 +614,7 @@ def packed_weight(weight):
 def panel_weight(weight):
     """Fragment-order bf16 image of an (N, K) fp32 weight for the row-panel kernel
     (``bevmsda_linear_panel_pack_weight_f32``), cached on the tensor until it is written to or moved."""
-    key = (weight._version, weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
     hit = getattr(weight, "_bevmsda_panel", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -1075,7 +1088,7 @@ def proj_ln_proj_chain(rows, weight, bias, res, norm0, w1, b1, *, tag="proj_ln_p
 def transposed_weight(weight):
     """Contiguous ``weight.t()`` cached on the tensor until it is written to: the operand of the
     input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""
-    key = (weight._version, weight.data_ptr(), tuple(weight.shape))
+    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape))
     hit = getattr(weight, "_bevmsda_wt", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -1206,12 +1219,22 @@ class _LinearFunction(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             acc = None
+            # In-place add into the INCOMING gradient of the alias.  Autograd does not promise that an incoming
+            # gradient is exclusively ours.  It is when the alias had exactly one consumer — the next projection of the
+            # thread, whose backward allocated the buffer, tagged it (`_bevmsda_thread_buffer`) and returned it as its
+            # `gx`: the very tensor object arrives here, unsummed and no view of anything.  A second consumer of the
+            # alias makes autograd hand over the SUM (a new, untagged tensor), a gradient from anywhere else is
+            # untagged too: both take the out-of-place `gx + g_alias` below.  (The alias never leaves GradThread, so
+            # no user hook / retain_grad can hold a reference to this buffer.)
             if g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous() \
+                    and g_alias._base is None and getattr(g_alias, "_bevmsda_thread_buffer", False) \
                     and g_alias.numel() == g2.shape[0] * K:
                 acc = g_alias.view(-1, K)   # the sum of the later projections' gradients: add mine in the epilogue
                 if linear(g2, transposed_weight(weight), None, tag=ctx.tag + "_dx", _inside_autograd=True,
                           accumulate_into=acc) is None:
                     acc = None
+            if g_alias is not None:
+                _THREAD_STATS["inplace" if acc is not None else "out_of_place"] += 1
             if acc is not None:
                 gx = g_alias
             else:
@@ -1221,6 +1244,11 @@ class _LinearFunction(Function):
                 gx = gx.view(x.shape)
                 if g_alias is not None:
                     gx = gx + g_alias
+            if ctx.thread:
+                try:
+                    gx._bevmsda_thread_buffer = True      # (a fresh buffer of this thread: the previous projection may add into it)
+                except AttributeError:
+                    pass
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw, gb_k = linear_wgrad(g2, x.reshape(-1, K), want_b, tag=ctx.tag + "_dw")
@@ -1265,7 +1293,7 @@ def merged_linear_params(owner, *linears, slot="_merged_linear"):
     been written to."""
     if torch.is_grad_enabled() and any(p.requires_grad for m in linears for p in (m.weight, m.bias)):
         return (torch.cat([m.weight for m in linears], 0), torch.cat([m.bias for m in linears], 0))
-    key = tuple((m.weight._version, m.bias._version, m.weight.data_ptr(), m.bias.data_ptr())
+    key = tuple((_ver(m.weight), _ver(m.bias), m.weight.data_ptr(), m.bias.data_ptr())
                 for m in linears)
     hit = owner.__dict__.get(slot)
     if hit is not None and hit[0] == key:

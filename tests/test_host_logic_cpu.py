@@ -141,3 +141,38 @@ def test_positional_encoding_copy_is_cached_only_for_unmodified_memory():
         assert torch.equal(d, other.permute(0, 2, 1))
         cont = torch.randn(1, 12, 8)
         assert enc._contiguous_pos(cont) is cont
+
+
+def test_encoder_runs_under_inference_mode():
+    """``torch.inference_mode()``: inference tensors track no version counter, so every cache keyed on ``_version``
+    (the contiguous positional encoding, TemporalSelfAttention's reference rows, the merged / packed weights) must
+    key on something else there (``_contiguous_pos`` raised on the transposed ``bev_pos`` view)."""
+    from helpers import oracle_ops
+    enc, sd = build_pair("micro")
+    q, f, kw = S.make_inputs("micro", seed=0, temporal=True)
+    with oracle_ops(), torch.no_grad():
+        want = enc(q, f, f, **kw)
+    with oracle_ops(), torch.inference_mode():
+        q2, f2, kw2 = S.make_inputs("micro", seed=0, temporal=True)         # inference tensors
+        kw2["bev_pos"] = kw2["bev_pos"].permute(1, 2, 0).contiguous().permute(2, 0, 1)   # a transposed view, as through get_bev_features
+        assert kw2["bev_pos"].is_inference() and not kw2["bev_pos"].is_contiguous()
+        got = enc(q2, f2, f2, **kw2)
+        again = enc(q2, f2, f2, **kw2)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got, again)
+    w = torch.nn.Linear(4, 4)
+    with torch.inference_mode():
+        t = w.weight * 1.0
+        assert ops._ver(t) == 0 and ops._ver(w.weight) == w.weight._version
+
+
+def test_fused_sampling_rejects_unknown_options():
+    """``msda_fused`` swallowed every unknown keyword: only the options of the retired LDS-staged kernels
+    are still accepted (and ignored); a misspelt one raises before anything is launched."""
+    import pytest
+    v = torch.zeros(1, 4, 8, 32)
+    common = dict(M=8, L=1, P=4, K=1, off_head=8, off_k=0, lg_head=4, lg_k=0, ref_mode=0, vmul=1, vadd=0)
+    with pytest.raises(TypeError, match="launch_row"):
+        ops.msda_fused(v, None, None, torch.zeros(2, 96), 64, torch.zeros(2, 1, 4, 2), None, launch_row=3, **common)
+    with pytest.raises(RuntimeError, match="no CPU path"):      # retired names pass the keyword check (and then: CPU tensor)
+        ops.msda_fused(v, None, None, torch.zeros(2, 96), 64, torch.zeros(2, 1, 4, 2), None, cam_start=None, **common)
