@@ -170,8 +170,16 @@ def all_gather_rows(local, blocks, bev_w, group=None, simulate=None, inverse=Non
         local = torch.cat([local, local.new_zeros(bs, mx - n, C)], 1)
     # output is the dim-0 concatenation of the shards (the layout both RCCL and
     # gloo accept for all_gather_into_tensor), viewed back as (world, bs, mx, C)
-    flat = local.new_empty(world * bs, mx, C)
-    dist.all_gather_into_tensor(flat, local.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # FUNCTIONAL path only (several ranks sharing one GPU in the tests and in `bench.py --dist-backend gloo`, where
+        # RCCL refuses duplicate devices): gloo has no all-gather of device tensors, so the shards travel through host
+        # memory.  Never a measured configuration — the product collective is the RCCL call below.
+        host = torch.empty(world * bs, mx, C, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+        flat = host.to(local.device)
+    else:
+        flat = local.new_empty(world * bs, mx, C)
+        dist.all_gather_into_tensor(flat, local.contiguous(), group=group)
     buf = flat.view(world, bs, mx, C)
     if all(s == mx for s in sizes):
         return buf.permute(1, 0, 2, 3).reshape(bs, world * mx, C)

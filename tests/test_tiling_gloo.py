@@ -50,6 +50,64 @@ def _worker(rank, world, port, name, temporal, bs, layout, ret):
         dist.destroy_process_group()
 
 
+def _queue_worker(rank, world, port, name, layout, ret):
+    """BASELINE configs[4] as one thing: the test-time history queue (``BevHistory.step`` = detectors/bevformer.py:236-269)
+    driving ``PerceptionTransformer.get_bev_features`` (modules/transformer.py:104-200) over the BEV-TILED encoder."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import build_transformer_pair, oracle_ops
+        from test_history_cpu import _video
+        from bevformer_amd import bev_tiling, history
+        t, _ = build_transformer_pair(name)
+        frames = _video(name, 4, scene_break=2)
+
+        def run():
+            hist = history.BevHistory()
+            outs, seen_prev = [], []
+            for mlvl, metas, bq, kw in frames:
+                def fn(f, m, p, bq=bq, kw=kw):
+                    seen_prev.append(p is not None)
+                    return t.get_bev_features(f, bq, kw["bev_h"], kw["bev_w"], grid_length=kw["grid_length"],
+                                              bev_pos=kw["bev_pos"], prev_bev=p, img_metas=m)
+                outs.append(hist.step(fn, mlvl, metas).clone())
+            return outs, seen_prev
+        with oracle_ops(), torch.no_grad():
+            want, seen_w = run()
+            bev_tiling.enable_bev_tiling(t.encoder, layout=layout)
+            got, seen_g = run()
+            bev_tiling.disable_bev_tiling(t.encoder)
+        assert seen_w == seen_g == [False, True, False, True]       # frames 0 and 2 open a scene: no history
+        errs = [(g - w).abs().max().item() for g, w in zip(got, want)]
+        last = got[-1].contiguous()
+        gathered = [torch.empty_like(last) for _ in range(world)]
+        dist.all_gather(gathered, last)
+        ret[rank] = (errs, all(torch.equal(g, gathered[0]) for g in gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,layout", [(2, "rows"), (2, "sectors"), (3, "sectors")])
+def test_history_queue_over_the_tiled_encoder_matches_the_untiled_queue(world, layout):
+    """configs[4]: four frames with a scene break through ``BevHistory`` -> ``get_bev_features`` -> the tiled encoder on
+    ``world`` gloo ranks == the same queue over the untiled encoder; every frame's BEV (the next frame's history, after
+    the caller's rotation / shift) is the all-gathered full grid on every rank, and frames without history take the
+    per-layer exchange."""
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_queue_worker, args=(world, port, "micro", layout, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        errs, same = ret[r]
+        assert same, "ranks disagree on the last frame's BEV"
+        assert max(errs) < 5e-5, (r, errs)
+
+
 @pytest.mark.parametrize("name,temporal,bs,world,layout", [("micro", True, 1, 2, "rows"), ("micro", False, 1, 2, "rows"),
                                                            ("micro4", True, 2, 2, "rows"), ("micro", True, 1, 5, "rows"),
                                                            ("micro", True, 1, 2, "sectors"), ("micro", False, 1, 3, "sectors"),
