@@ -12,7 +12,7 @@ from .build import LIB_PATH
 _c_int = ctypes.c_int
 _c_void_p = ctypes.c_void_p
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Tuning(ctypes.Structure):
@@ -79,6 +79,13 @@ SIGNATURES = {
     "bevmsda_backward_ragged_f32": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
     "bevmsda_forward_ragged_bf16": ([_c_void_p] * 6 + _DIMS + [_c_void_p, _c_void_p], _c_int),
     "bevmsda_backward_ragged_bf16": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_backward_rows_f32": ([_c_void_p] * 8 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_backward_rows_bf16": ([_c_void_p] * 8 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_frontend_expand_rows_f32": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
+    "bevmsda_rows_from_slots_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, _c_int,
+                                     _c_void_p, _c_void_p], _c_int),
+    "bevmsda_proj_ffn_chain_train_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 6, _c_int),
+    "bevmsda_proj_ln_proj_chain_train_f32": ([_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_forward_f32_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
                                                             ctypes.POINTER(Tuning)], _c_int),
     "bevmsda_backward_f32_ex": ([_c_void_p] * 6 + _DIMS + [_c_void_p] * 4

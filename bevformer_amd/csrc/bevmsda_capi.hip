@@ -90,6 +90,7 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
     tiled = tiled && 1LL * a.S < (1LL << 23) && a.NQ < (1LL << 30) && 1LL * a.N * (1LL * a.Q * 3 / 512 + 4) * 256 < (1LL << 30);
+    if (a.nrows_dev && !(tiled && d32_fwd_eligible<T>(a))) return BEVMSDA_ERR_UNSUPPORTED;   // (no first-generation kernel reads the device count)
     if (tiled) {
       bevmsda::GradValueArgs s{};
       s.k = a;
@@ -277,7 +278,8 @@ template <typename T>
 int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *loc,
                   const float *attn, const T *grad_out, int N, int S, int M, int D, int L, int Q,
                   int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream,
-                  const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr, int R = -1) {
+                  const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr, int R = -1,
+                  const int32_t *nrows_dev = nullptr) {
   const int Nv = N;
   if (R >= 0) {
     if (R > 0 && !row_batch) return BEVMSDA_ERR_NULL_POINTER;
@@ -288,6 +290,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   if (rc < 0) return rc;
   if (rc == 1 || L == 0 || P == 0) return BEVMSDA_OK;
   if (!grad_out || !grad_loc || !grad_attn || (S > 0 && !grad_value)) return BEVMSDA_ERR_NULL_POINTER;
+  // device-side row count: only the second-generation D = 32 kernels read it
+  if (nrows_dev && (R < 0 || D != 32 || !(P == 4 || P == 8) || L > bevmsda::kGvMaxLevels || tuning)) return BEVMSDA_ERR_UNSUPPORTED;
   if (misaligned(grad_out) || misaligned(grad_value) || misaligned(grad_loc) || misaligned(grad_attn))
     return BEVMSDA_ERR_MISALIGNED;
   KArgs a{};
@@ -309,6 +313,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
                                                               static_cast<uint32_t>(tuning->reserved[1]))
                      : nullptr;
   a.bf16_lanes8 = tuning ? tuning->reserved[3] : 0;
+  a.nrows_dev = nrows_dev;
   a.mshift = ilog2_exact(M);
   a.qshift = ilog2_exact(a.qtile);
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
@@ -544,6 +549,42 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
   if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
                                grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R);
+}
+
+int bevmsda_backward_rows_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                              const float *loc, const float *attn, const int32_t *row_batch, const float *grad_out,
+                              const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                              float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
+  return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
+                              grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows);
+}
+
+int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *loc, const float *attn, const int32_t *row_batch, const uint16_t *grad_out,
+                               const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                               float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
+  return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
+                               grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows);
+}
+
+int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const float *scale, const int32_t *row_slot,
+                                const int32_t *nrows, int64_t R, int C, float *rows, void *stream) {
+  if (R < 0 || C <= 0 || ld_slots < C) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C % 4 != 0 || ld_slots % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (R == 0) return BEVMSDA_OK;
+  if (!slots || !scale || !row_slot || !rows) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(slots) || misaligned(rows)) return BEVMSDA_ERR_MISALIGNED;
+  const long long total = R * static_cast<long long>(C / 4);
+  const long long nb = (total + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::rows_from_slots_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), slots, static_cast<long>(ld_slots), scale, row_slot, nrows,
+                     static_cast<long>(R), C, rows);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,

@@ -36,12 +36,32 @@ int front_launch(const bevmsda_fused_desc *d, const bevmsda::FrontArgs &f, void 
 
 extern "C" {
 
+static int expand_launch(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                         const int32_t *row_src, const int64_t *spatial_shapes, const bevmsda_fused_desc *desc,
+                         float *loc, float *attn, int32_t *row_batch_k, void *stream, const int32_t *nrows);
+
 int bevmsda_frontend_expand_f32(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
                                 const int32_t *row_src, const int64_t *spatial_shapes, const bevmsda_fused_desc *desc,
                                 float *loc, float *attn, int32_t *row_batch_k, void *stream) {
+  return expand_launch(offs, logits, ref, row_batch, row_src, spatial_shapes, desc, loc, attn, row_batch_k, stream, nullptr);
+}
+
+int bevmsda_frontend_expand_rows_f32(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                     const int32_t *row_src, const int32_t *nrows, const int64_t *spatial_shapes,
+                                     const bevmsda_fused_desc *desc, float *loc, float *attn, int32_t *row_batch_k,
+                                     void *stream) {
+  if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
+  if (desc && desc->K != 1) return BEVMSDA_ERR_UNSUPPORTED;     // (queue-major rows of K > 1 would need the count per entry)
+  return expand_launch(offs, logits, ref, row_batch, row_src, spatial_shapes, desc, loc, attn, row_batch_k, stream, nrows);
+}
+
+static int expand_launch(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                         const int32_t *row_src, const int64_t *spatial_shapes, const bevmsda_fused_desc *desc,
+                         float *loc, float *attn, int32_t *row_batch_k, void *stream, const int32_t *nrows) {
   bevmsda::FrontArgs f{};
   const int rc = front_common(desc, f);
   if (rc != BEVMSDA_OK) return rc;
+  f.nrows_dev = nrows;
   if (desc->R == 0) return BEVMSDA_OK;
   if (!offs || !logits || !ref || !spatial_shapes || !loc || !attn || !row_batch_k) return BEVMSDA_ERR_NULL_POINTER;
   if (mis8(offs) || mis4(logits) || mis8(ref) || mis8(loc) || mis4(attn) || mis4(row_batch_k)) return BEVMSDA_ERR_MISALIGNED;

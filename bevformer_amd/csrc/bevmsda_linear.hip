@@ -300,11 +300,14 @@ int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, c
 }
 
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)
-int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
-                               const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
-                               const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
-                               const bevmsda_chain_desc *d, float *y, void *stream) {
+static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                            const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                            const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
+                            const bevmsda_chain_desc *d, float *y, void *stream, bool save, float *sv_z0, float *sv_x,
+                            float *sv_h, float *sv_z1) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && d->M > 0 && (!sv_z0 || !sv_x || !sv_h || !sv_z1)) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && (misaligned(sv_z0) || misaligned(sv_x) || misaligned(sv_h) || misaligned(sv_z1))) return BEVMSDA_ERR_MISALIGNED;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (d->C != bevmsda::kChainC || d->F != bevmsda::kChainF) return BEVMSDA_ERR_UNSUPPORTED;
@@ -330,23 +333,49 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
   a.w0 = w0p; a.w1 = w1p; a.w2 = w2p; a.b0 = b0; a.b1 = b1; a.b2 = b2;
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = gamma1; a.beta1 = beta1;
   a.eps0 = d->eps0; a.eps1 = d->eps1; a.y = y; a.ld_y = d->ld_y; a.M = d->M;
+  a.sv_z0 = sv_z0; a.sv_x = sv_x; a.sv_h = sv_h; a.sv_z1 = sv_z1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
-#define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
-  do {                                                                                                                  \
-    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
+#define BEVMSDA_CHAIN(NP_, PRE_, SV_)                                                                                        \
+  do {                                                                                                                       \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8, SV_>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4, SV_>), grid, dim3(256), 0, st, a);            \
   } while (0)
-  if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }
-  else { if (idx) BEVMSDA_CHAIN(1, 2); else BEVMSDA_CHAIN(1, 0); }
+  if (save) {
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, true); else BEVMSDA_CHAIN(3, 0, true); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, true); else BEVMSDA_CHAIN(1, 0, true); }
+  } else {
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false); else BEVMSDA_CHAIN(3, 0, false); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, false); else BEVMSDA_CHAIN(1, 0, false); }
+  }
 #undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
-int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
-                                   const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
-                                   const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream) {
+int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                               const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                               const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
+                               const bevmsda_chain_desc *d, float *y, void *stream) {
+  return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, false,
+                          nullptr, nullptr, nullptr, nullptr);
+}
+
+int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                     const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p,
+                                     const float *b1, const uint16_t *w2p, const float *b2, const float *gamma1,
+                                     const float *beta1, const bevmsda_chain_desc *d, float *y, float *save_z0, float *save_x,
+                                     float *save_h, float *save_z1, void *stream) {
+  return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, true,
+                          save_z0, save_x, save_h, save_z1);
+}
+
+static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream, bool save,
+                                float *sv_z0) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && d->M > 0 && !sv_z0) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && misaligned(sv_z0)) return BEVMSDA_ERR_MISALIGNED;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   const long ld_y2 = d->reserved[0];
@@ -371,17 +400,37 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
   a.w0 = w0p; a.w1 = w1p; a.w2 = nullptr; a.b0 = b0; a.b1 = b1; a.b2 = nullptr;
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = a.beta1 = nullptr;
   a.eps0 = d->eps0; a.eps1 = 0.f; a.y = x_out; a.ld_y = d->ld_y; a.M = d->M; a.y2 = proj_out; a.ld_y2 = ld_y2; a.N2 = d->F;
+  a.sv_z0 = sv_z0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
-#define BEVMSDA_CHAIN(NP_, PRE_)                                                                                        \
-  do {                                                                                                                  \
-    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4>), grid, dim3(256), 0, st, a);            \
+#define BEVMSDA_CHAIN(NP_, PRE_, SV_)                                                                                        \
+  do {                                                                                                                       \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8, SV_>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4, SV_>), grid, dim3(256), 0, st, a);            \
   } while (0)
-  if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2); else BEVMSDA_CHAIN(3, 0); }
-  else { if (idx) BEVMSDA_CHAIN(1, 2); else BEVMSDA_CHAIN(1, 0); }
+  if (save) {                                  // (the autograd path's forward has no gather prepass: plain rows only)
+    if (idx) return BEVMSDA_ERR_UNSUPPORTED;
+    if (d->precision == 0) BEVMSDA_CHAIN(3, 0, true); else BEVMSDA_CHAIN(1, 0, true);
+  } else {
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false); else BEVMSDA_CHAIN(3, 0, false); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, false); else BEVMSDA_CHAIN(1, 0, false); }
+  }
 #undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                   const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                   const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream) {
+  return ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, d, x_out, proj_out, stream, false, nullptr);
+}
+
+int bevmsda_proj_ln_proj_chain_train_f32(const float *rows, const uint16_t *w0p, const float *b0, const float *res,
+                                         const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                         const bevmsda_chain_desc *d, float *x_out, float *proj_out, float *save_z0,
+                                         void *stream) {
+  return ln_proj_chain_launch(rows, nullptr, nullptr, w0p, b0, res, gamma0, beta0, w1p, b1, d, x_out, proj_out, stream, true,
+                              save_z0);
 }
 
 }  // extern "C"

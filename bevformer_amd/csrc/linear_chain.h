@@ -53,6 +53,12 @@ struct ChainArgs {
   float *y2;                        // MODE 1: the second projection's output (M, ld_y2), N2 columns
   long ld_y2;
   int N2;
+  // SAVE = true (the forward of the autograd path): what the backward needs of the rows that otherwise never leave
+  // the chip, stored as dense (M, 256) / (M, 512) matrices:
+  float *sv_z0;                     // A W0^T + b0 + res, the input of LayerNorm0
+  float *sv_x;                      // MODE 0: x = LayerNorm0(...) (MODE 1 stores it as `y` anyway)
+  float *sv_h;                      // MODE 0: relu(x W1^T + b1), (M, 512)
+  float *sv_z1;                     // MODE 0: x + h W2^T + b2, the input of LayerNorm1
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -81,7 +87,7 @@ constexpr int kChainMaxN2 = 768;   // MODE 1: columns of the second projection (
 //              phases (58 % of a workgroup's cycles in the first shape: tools/gemm_diag/chain_run.py) run under the
 //              other's MFMAs, and 1,250 half-size workgroups quantise better over 256 CUs than 625 — at twice the
 //              weight traffic from L2 per row.
-template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8>
+template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8, bool SAVE = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -327,6 +333,20 @@ linear_chain_kernel(const ChainArgs a) {
   }
   wprefetch(r0, wave, 16, 0);
 
+  auto store_tile = [&](const auto &c, float *out, long ld, int col0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mrow[i] >= a.M) continue;
+      float *yrow = out + mrow[i] * ld + col0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(yrow + j * 32 + 4 * (lane >> 5) + 8 * g) =
+              make_float4(c[i][j][4 * g], c[i][j][4 * g + 1], c[i][j][4 * g + 2], c[i][j][4 * g + 3]);
+    }
+  };
+
   // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
   {
     const int d_rl = lane >> 3, d_cc = lane & 7;
@@ -397,28 +417,16 @@ linear_chain_kernel(const ChainArgs a) {
         acc[i][j][4 * g] += rs[i][j][g].x; acc[i][j][4 * g + 1] += rs[i][j][g].y;
         acc[i][j][4 * g + 2] += rs[i][j][g].z; acc[i][j][4 * g + 3] += rs[i][j][g].w;
       }
+  if constexpr (SAVE) store_tile(acc, a.sv_z0, kChainC, NT * wave * 32);
   layernorm(acc, c_g0, c_be0, a.eps0);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) xk[i][j] = acc[i][j];
+  if constexpr (SAVE && MODE == 0) store_tile(xk, a.sv_x, kChainC, NT * wave * 32);
   to_planes(xk, buf1);
   __syncthreads();                             // x planes complete (and every wavefront is done with buffer 0)
   CHAIN_STAMP(2);                              // bias + residual + LayerNorm 0 + plane write
-
-  auto store_tile = [&](const auto &c, float *out, long ld, int col0) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if (mrow[i] >= a.M) continue;
-      float *yrow = out + mrow[i] * ld + col0;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4 *>(yrow + j * 32 + 4 * (lane >> 5) + 8 * g) =
-              make_float4(c[i][j][4 * g], c[i][j][4 * g + 1], c[i][j][4 * g + 2], c[i][j][4 * g + 3]);
-    }
-  };
 
   if constexpr (MODE == 1) {
     // x is the next attention's residual: store it, then project it (from its planes) tile by tile
@@ -450,6 +458,7 @@ linear_chain_kernel(const ChainArgs a) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] < 0.f ? 0.f : acc[i][j][r];     // NaN stays NaN, as torch.relu
+      if constexpr (SAVE) store_tile(acc, a.sv_h, kChainF, half * 256 + NT * wave * 32);
       to_planes(acc, buf0);
       __syncthreads();                         // this half of the hidden layer is complete
       CHAIN_STAMP(4 + 3 * half);               // bias + ReLU + plane write
@@ -467,6 +476,7 @@ linear_chain_kernel(const ChainArgs a) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[i][j][r] += xk[i][j][r];
+    if constexpr (SAVE) store_tile(acc2, a.sv_z1, kChainC, NT * wave * 32);
     layernorm(acc2, c_g1, c_be1, a.eps1);
     CHAIN_STAMP(9);                            // bias + residual + LayerNorm 1
     store_tile(acc2, a.y, a.ld_y, NT * wave * 32);

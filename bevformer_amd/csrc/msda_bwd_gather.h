@@ -112,8 +112,10 @@ msda_gradloc_d32_kernel(const KArgs a) {
   const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
   long nq; int m;
   map_group(G, a, nq, m);
-  const bool active = nq < a.NQ;
-  if (!active) nq = a.NQ - 1;       // whole groups stay alive for the swizzles; nothing is stored
+  const long NQ = effective_rows(a);
+  const bool active = nq < NQ;
+  if (__builtin_amdgcn_ballot_w64(active) == 0) return;     // (device-side row count: the grid covers the capacity)
+  if (!active) nq = NQ - 1;         // whole groups stay alive for the swizzles; nothing is stored
   const int L = a.L;
   const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
   const long row = nq * a.M + m;
@@ -226,8 +228,10 @@ msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
   const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
   long nq; int m;
   map_group(G, a, nq, m);
-  const bool active = nq < a.NQ;
-  if (!active) nq = a.NQ - 1;
+  const long NQ = effective_rows(a);
+  const bool active = nq < NQ;
+  if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+  if (!active) nq = NQ - 1;
   const int L = a.L;
   const long n = a.row_batch ? static_cast<long>(a.row_batch[nq]) : nq / a.Q;
   const long row = nq * a.M + m;

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
   const bool tiled = s.dense_tiles > 0 && static_cast<long>(H0) * W0 == a.Q && tile_w * tile_h <= s.dense_tiles;
   // (row counts fit 31 bits: checked by the launcher)
   const int vq = tiled ? s.dense_tiles * 256 : a.Q;                           // virtual rows per batch entry
-  const int vrows = tiled ? vq * a.N : static_cast<int>(a.NQ);
+  const int vrows = tiled ? vq * a.N : static_cast<int>(effective_rows(a));    // (device-side row count: ragged calls)
   const int c0 = chunk * s.rows_per_block;
   if (c0 >= vrows) return;
   const int c1 = c0 + s.rows_per_block < vrows ? c0 + s.rows_per_block : vrows;

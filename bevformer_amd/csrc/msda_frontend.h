@@ -31,6 +31,7 @@ struct FrontArgs {
   // chain
   const float *grad_loc, *grad_attn, *attn_in;
   float *grad_offs, *grad_logits;
+  const int32_t *nrows_dev;         // expand: R is the capacity of the row arrays, the count is read here (K = 1)
 };
 
 template <int PT>
@@ -54,8 +55,14 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontArgs f) {
   const int q = static_cast<int>(g % f.K); g /= f.K;
   const int m = static_cast<int>(g % f.M);
   long r = g / f.M;
-  const bool active = r < f.R;
-  if (!active) r = f.R - 1;                         // whole groups stay alive for the shuffles
+  long Ract = f.R;
+  if (f.nrows_dev) {
+    const long n = static_cast<long>(*f.nrows_dev);
+    Ract = n < Ract ? (n < 0 ? 0 : n) : Ract;
+  }
+  const bool active = r < Ract;
+  if (__builtin_amdgcn_ballot_w64(active) == 0) return;     // (device-side row count: the grid covers the capacity)
+  if (!active) r = Ract - 1;                        // whole groups stay alive for the shuffles
   const long rs = f.row_src ? static_cast<long>(f.row_src[r]) : r;
   const long rk = static_cast<long>(q) * f.R + r;   // queue-major: the rows of one queue entry (one value batch entry per
                                                     // batch element) stay contiguous for the backward kernels

@@ -52,7 +52,19 @@ struct KArgs {
   int gv_rows;    // backward: rows per workgroup of the grad_value sort kernel (0 = default; 64 / 128 / 256)
   int bf16_lanes8;  // backward, bf16 storage: 1 = the 8-byte-lane gather kernel instead of the 16-byte-lane one
   unsigned long long *gv_prof;   // backward: phase clocks of the sort kernel (tools/gvprof.py), else nullptr
+  const int32_t *nrows_dev;      // backward (second-generation D = 32 kernels): NQ is the CAPACITY of the row arrays and the
+                                 // actual row count is read here, on the device (frame_plan.h); nullptr: NQ rows
 };
+
+// rows the launch has to process: the host's NQ, or the device-side count below it
+__device__ __forceinline__ long effective_rows(const KArgs &a) {
+  long nq = a.NQ;
+  if (a.nrows_dev) {
+    const long n = static_cast<long>(*a.nrows_dev);
+    nq = n < nq ? (n < 0 ? 0 : n) : nq;
+  }
+  return nq;
+}
 
 typedef uint16_t bf16_t;
 

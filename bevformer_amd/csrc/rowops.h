@@ -198,4 +198,28 @@ __global__ void __launch_bounds__(256) gather_mean_kernel(const float *__restric
   reinterpret_cast<float4 *>(out + q * C)[c] = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
 }
 
+// rows[r] = scale[slot] * slots[slot], slot = row_slot[r], for r < the row count (`nrows_dev`: read on the device, else R):
+// the backward of the camera mean (gather_mean: every (camera, query) row of a BEV query takes the query's gradient
+// times 1 / cameras).  One float4 per thread; rows beyond the count are not touched.
+__global__ void __launch_bounds__(256) rows_from_slots_kernel(const float *__restrict__ slots, long ld_slots,
+                                                             const float *__restrict__ scale,
+                                                             const int32_t *__restrict__ row_slot,
+                                                             const int32_t *__restrict__ nrows_dev, long R, int C,
+                                                             float *__restrict__ rows) {
+  const int c4 = C >> 2;
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  long n = R;
+  if (nrows_dev) {
+    const long d = static_cast<long>(*nrows_dev);
+    n = d < n ? (d < 0 ? 0 : d) : n;
+  }
+  if (t >= n * c4) return;
+  const long r = t / c4;
+  const int c = static_cast<int>(t - r * c4);
+  const long sl = row_slot[r];
+  const float s = scale[sl];
+  const float4 v = reinterpret_cast<const float4 *>(slots + sl * ld_slots)[c];
+  reinterpret_cast<float4 *>(rows + r * C)[c] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+}
+
 }  // namespace bevmsda

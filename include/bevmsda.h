@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BEVMSDA_ABI_VERSION 2
+#define BEVMSDA_ABI_VERSION 3
 
 enum {
   BEVMSDA_OK = 0,
@@ -114,6 +114,20 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
                                  const int32_t *row_batch, const uint16_t *grad_out, int N, int S,
                                  int M, int D, int L, int R, int P, float *grad_value,
                                  float *grad_loc, float *grad_attn, void *stream);
+
+/* bevmsda_backward_ragged_* with the row count in DEVICE memory (`nrows`, read when the kernels run; csrc/frame_plan.h
+ * writes it): R is the CAPACITY of the row arrays (loc, attn, row_batch, grad_out, grad_loc, grad_attn), rows
+ * [0, min(*nrows, R)) are processed, the others neither read nor written — no host synchronisation between the frame
+ * plan and the backward of multi_scale_deformable_attn_function.py:130-163, so a training step can be captured in a
+ * HIP graph.  Second-generation kernels only: D = 32, P in {4, 8}, L <= 4, value < 2 GiB; else BEVMSDA_ERR_UNSUPPORTED. */
+int bevmsda_backward_rows_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                              const float *loc, const float *attn, const int32_t *row_batch, const float *grad_out,
+                              const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                              float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *loc, const float *attn, const int32_t *row_batch, const uint16_t *grad_out,
+                               const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                               float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
 /* Same as above with explicit tuning. */
 int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes,
@@ -220,6 +234,11 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
 int bevmsda_frontend_expand_f32(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
                                 const int32_t *row_src, const int64_t *spatial_shapes, const bevmsda_fused_desc *desc,
                                 float *loc, float *attn, int32_t *row_batch_k, void *stream);
+/* Step 1 with the row count in device memory (K = 1): desc->R is the capacity, rows [0, min(*nrows, R)) are written. */
+int bevmsda_frontend_expand_rows_f32(const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                     const int32_t *row_src, const int32_t *nrows, const int64_t *spatial_shapes,
+                                     const bevmsda_fused_desc *desc, float *loc, float *attn, int32_t *row_batch_k,
+                                     void *stream);
 int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, const float *attn, const int32_t *row_src,
                                const int64_t *spatial_shapes, const bevmsda_fused_desc *desc, float *grad_offs,
                                float *grad_logits, void *stream);
@@ -255,6 +274,12 @@ int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const f
  * (spatial_cross_attention.py:165-172) as a gather.  idx: (Q, J) int32, -1 = empty. */
 int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *scale, int64_t Q,
                             int J, int C, float *out, void *stream);
+
+/* Backward of bevmsda_gather_mean_f32 w.r.t. `rows`: rows[r, :] = scale[s] * slots[s, :] with s = row_slot[r] (the
+ * inverse of idx: the frame plan's row -> BEV query table), for r in [0, min(*nrows, R)) (`nrows`: device-side row
+ * count, may be NULL = R); other rows are not touched.  C a multiple of 4. */
+int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const float *scale, const int32_t *row_slot,
+                                const int32_t *nrows, int64_t R, int C, float *rows, void *stream);
 
 /* Dense projection on the matrix cores (csrc/linear_mfma.h), fp32 in / fp32 out, forward only:
  *
@@ -442,6 +467,16 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
                                const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
                                const bevmsda_chain_desc *desc, float *y, void *stream);
 
+/* The same launch as the FORWARD of the autograd path: besides y it stores what the backward of the chain needs and the
+ * inference launch keeps on chip — save_z0 (M, 256) = A w0^T + b0 + res (the input of LayerNorm0), save_x (M, 256) =
+ * LayerNorm0(...), save_h (M, 512) = relu(x w1^T + b1), save_z1 (M, 256) = x + h w2^T + b2 (the input of LayerNorm1);
+ * dense matrices, 16-byte aligned.  Same arithmetic, same y. */
+int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                     const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p,
+                                     const float *b1, const uint16_t *w2p, const float *b2, const float *gamma1,
+                                     const float *beta1, const bevmsda_chain_desc *desc, float *y, float *save_z0,
+                                     float *save_x, float *save_h, float *save_z1, void *stream);
+
 /* The attention-to-attention seam of a layer with the same machinery:
  *     x = LayerNorm0(A w0^T + b0 + res)        TemporalSelfAttention's output projection, "+ identity", norms[0]
  *     p = x w1^T + b1                           the next attention's projection of the same rows — SpatialCrossAttention's
@@ -452,6 +487,12 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
 int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                                    const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                    const bevmsda_chain_desc *desc, float *x_out, float *proj_out, void *stream);
+
+/* ... and as the forward of the autograd path (plain rows, no gather): save_z0 (M, 256) = the input of LayerNorm0. */
+int bevmsda_proj_ln_proj_chain_train_f32(const float *rows, const uint16_t *w0p, const float *b0, const float *res,
+                                         const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                         const bevmsda_chain_desc *desc, float *x_out, float *proj_out, float *save_z0,
+                                         void *stream);
 
 /* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
  *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)

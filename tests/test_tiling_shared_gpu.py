@@ -121,8 +121,8 @@ def test_graphed_history_queue_over_a_simulated_rank(layout, world):
     """``GraphedBevHistory`` over rank r of a ``world``-rank tiled job simulated in this process (``BevTiling.simulate``:
     the all-gather is the copy of the rank's own shard).  The history a frame reads is the FULL previous BEV, which a
     lone simulated rank cannot produce — the test writes the untiled queue's BEV into the graphed queue's history
-    buffer between frames; then the rank's own rows of every frame (replayed from its HIP graphs, tile plan and camera
-    skipping included) must equal the untiled queue's rows."""
+    buffer between frames; then the rank's own rows of every frame WITH history (replayed from its HIP graphs, tile plan
+    and camera skipping included) must equal the untiled queue's rows."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import build_transformer_pair
     from test_history_cpu import _video
@@ -154,6 +154,9 @@ def test_graphed_history_queue_over_a_simulated_rank(layout, world):
             mine = bev_tiling.sector_order(w["bev_h"], w["bev_w"], S.PC_RANGE, dev)[1][q0:q1]
         for i, (mlvl, metas, _, _) in enumerate(frames):
             got = graphed.step(None, [x.to(dev) for x in mlvl], metas).clone()
-            torch.testing.assert_close(got[:, mine], want[i][:, mine], rtol=1e-4, atol=1e-4)
+            if i not in (0, 3):
+                # (a frame that opens a scene exchanges the CURRENT grid after every layer — a lone simulated rank sees only
+                # its own shard there, so only frames with a history BEV are comparable; the first-frame graph still runs)
+                torch.testing.assert_close(got[:, mine], want[i][:, mine], rtol=1e-4, atol=1e-4)
             graphed.prev.copy_(want[i])         # the all-gathered BEV the next frame's history would be
         bev_tiling.disable_bev_tiling(t.encoder)
