@@ -62,8 +62,8 @@ def parse():
                          "(ego-motion shift, prev-BEV rotation, can-bus MLP, flatten + embeddings, encoder), each "
                          "frame's BEV being the next frame's history (BASELINE configs[4] style; eager launches)")
     ap.add_argument("--backward", action="store_true",
-                    help="time forward + backward of the encoder (autograd path; eager launches; "
-                         "BASELINE configs[2] style)")
+                    help="time forward + backward of the encoder (autograd path; one captured HIP graph of the whole "
+                         "step unless --graph off; BASELINE configs[2] style)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--static-rig", action="store_true",
                     help="same camera matrices every step (the frame plan is then built once)")
@@ -455,12 +455,14 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
         step()
     fence()
     graph, note, g_out = None, "eager", None
-    if not backward and not queue and args.graph != "off":
+    if not queue and args.graph != "off":
+        # forward + backward too (round 4): the autograd path keeps the ragged row count on the device, so the whole
+        # step — frame plan, forward, backward, gradient accumulation into fresh buffers — is one captured graph
         try:
             graph, g_out = capture(step, fence)
-            note = "hip graph replay"
+            note = "hip graph replay" + (" (forward + backward in one graph)" if backward else "")
         except Exception as e:      # noqa: BLE001
-            graph, note = None, f"eager (capture failed: {type(e).__name__})"
+            graph, note = None, f"eager (capture failed: {type(e).__name__}: {str(e)[:100]})"
             torch.cuda.synchronize()
     ts = timed_windows(cfg, step, fence, steps, windows, graph)
     per = [t / steps * 1e3 for t in ts]
@@ -686,7 +688,7 @@ def main():
     # a failed capture) eager launches with the events recorded inside the timed region.
     graph = None
     # (gloo smoke: the host-staged all-gather cannot be captured)
-    use_graph = args.graph in ("on", "auto") and not args.backward and args.queue == 0 and not smoke
+    use_graph = args.graph in ("on", "auto") and args.queue == 0 and not smoke
     graph_note = "eager" if not smoke else "eager (gloo smoke: the all-gather is staged through host memory)"
     if use_graph:
         timer.enabled = True            # kernel durations from an eager pass (events cannot

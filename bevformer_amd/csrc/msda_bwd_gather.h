@@ -109,10 +109,12 @@ msda_gradloc_d32_kernel(const KArgs a) {
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG;
   static_assert(PT == 4 || PT == 8, "PT");
   const int lig = threadIdx.x & 7;
-  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  const long NQ = effective_rows(a);
+  const int lb = logical_block_rows(a, NQ);
+  if (lb < 0) return;                                        // (device-side row count: a block beyond the actual rows)
+  const long G = static_cast<long>(lb) * GPB + (threadIdx.x >> 3);
   long nq; int m;
   map_group(G, a, nq, m);
-  const long NQ = effective_rows(a);
   const bool active = nq < NQ;
   if (__builtin_amdgcn_ballot_w64(active) == 0) return;     // (device-side row count: the grid covers the capacity)
   if (!active) nq = NQ - 1;         // whole groups stay alive for the swizzles; nothing is stored
@@ -225,10 +227,12 @@ msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
   static_assert(PT == 4 || PT == 8, "PT");
   const int lig = threadIdx.x & 7;
   const bool upper = lig >= 4;
-  const long G = static_cast<long>(logical_block(a)) * GPB + (threadIdx.x >> 3);
+  const long NQ = effective_rows(a);
+  const int lb = logical_block_rows(a, NQ);
+  if (lb < 0) return;                                        // (device-side row count: a block beyond the actual rows)
+  const long G = static_cast<long>(lb) * GPB + (threadIdx.x >> 3);
   long nq; int m;
   map_group(G, a, nq, m);
-  const long NQ = effective_rows(a);
   const bool active = nq < NQ;
   if (__builtin_amdgcn_ballot_w64(active) == 0) return;
   if (!active) nq = NQ - 1;

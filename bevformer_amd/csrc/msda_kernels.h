@@ -135,6 +135,22 @@ __device__ __forceinline__ int logical_block(const KArgs &a) {
   return b;
 }
 
+// The same with a device-side row count (launches sized by the CAPACITY of the row arrays): the XCD ranges are cut over
+// the blocks that hold actual rows — cut over the capacity, all work would land on the first XCDs — and the surplus
+// blocks report -1 (the caller returns).  32 lane groups (row, head) per block.
+__device__ __forceinline__ int logical_block_rows(const KArgs &a, long rows) {
+  if (!a.nrows_dev) return logical_block(a);
+  const long tiles = (rows + a.qtile - 1) / a.qtile;
+  const int nb = static_cast<int>((tiles * a.qtile * a.M + 31) >> 5);
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int per = (nb + 7) >> 3;
+    if ((b >> 3) >= per) return -1;
+    b = (b & 7) * per + (b >> 3);
+  }
+  return b < nb ? b : -1;
+}
+
 // lane-group index -> (n*Q+q, m)
 __device__ __forceinline__ void map_group(long G, const KArgs &a, long &nq, int &m) {
   if (a.mshift >= 0 && a.qshift >= 0) {  // shifts instead of 64-bit divisions

@@ -19,7 +19,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain")
 
     def __init__(self):
         env = os.environ.get
@@ -39,6 +39,9 @@ class Modes:
         self.fused_lds_pad_kb = int(env("BEVMSDA_FUSED_LDS_PAD", "0"))                                    # co-scheduling probe: occupancy cap of the sampling kernel
         self.chain_shape = int(env("BEVMSDA_CHAIN_SHAPE", "0"))     # benchmark knob: workgroup shape of the row-chain kernels
         self.grad_thread = env("BEVMSDA_GRAD_THREAD", "1") == "1"   # training: value-projection input gradients summed in the GEMMs
+        # autograd path of the encoder layer on the inference kernels (train_ops.py): chain kernels that save what their
+        # backward needs, hoisted value projections, device-side row count through forward and backward
+        self.train_chain = env("BEVMSDA_TRAIN_CHAIN", "1") == "1"
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 
     def snapshot(self):

@@ -111,7 +111,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar, num_cams, device,
                     row_order=order, tile=tile, cell_perm=perm)
             plan = planner.plan(img_metas)
-            return plan.materialize() if torch.is_grad_enabled() else plan
+            if not torch.is_grad_enabled():
+                return plan
+            # autograd: the fast path (train_ops.py) keeps the row count on the device and works on a private copy of
+            # the row arrays; the per-op path needs sizes on the host (one read of the counters)
+            return plan.snapshot() if self._train_fast_path(device) else plan.materialize()
         assert tile is None, "tiles of a host-built plan come from bev_tiling.slice_plan"
         assert order in geometry.ROW_ORDERS, f"host-built plans know the row orders {geometry.ROW_ORDERS}"
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
@@ -125,6 +129,15 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 self._plan_cache.pop(next(iter(self._plan_cache)))
             self._plan_cache[key] = plan
         return plan
+
+    def _train_fast_path(self, device=None):
+        """Gradients are recorded and every layer can run its row-local parts on the chain kernels (train_ops.py):
+        the reference's operation order, dropout inactive, the MFMA kernels in use."""
+        from .. import train_ops
+        if not (torch.is_grad_enabled() and ops.modes().train_chain and not torch.is_autocast_enabled()
+                and ops.gemm_mode() != "native" and (device is None or torch.device(device).type == "cuda")):
+            return False
+        return all(getattr(layer, "chain_trainable", lambda: False)() for layer in self.layers)
 
     def _contiguous_pos(self, pos):
         """``pos`` (bs, Q, C) with unit stride along C.  The positional encoding of the BEV grid does not change from
@@ -215,6 +228,37 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 tsa_vals = [y[i].view(tsa_value.shape[0], tsa_value.shape[1], M, -1) for i in range(L)]
         return sca_vals, tsa_vals
 
+    def hoisted_value_projections_autograd(self, value, tsa_value):
+        """``hoisted_value_projections`` with gradients (train_ops.grouped_linear): camera features (Nc, S, bs, C) ->
+        per-layer (bs * Nc, S, M, D) values; ``tsa_value``: None, the stacked (bs * 2, Q, C) tensor, or (bs = 1) the
+        pair (history (1, Q, C), current (1, Q, C)) -> per-layer (bs * 2, Q, M, D) values."""
+        from .. import train_ops
+        scas = [layer.attentions[1].deformable_attention for layer in self.layers]
+        tsas = [layer.attentions[0] for layer in self.layers]
+        L = len(self.layers)
+        Nc, S, bs, C = value.shape
+        if C != 256 or any(m.value_proj.weight.shape != (256, 256) for m in scas + tsas):
+            return None, None
+        feats = value.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
+        w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
+        ys = train_ops.grouped_linear(feats, w, b, L, "sca_value_proj")
+        M = scas[0].num_heads
+        sca_vals = [y.view(bs * Nc, S, M, -1) for y in ys]
+        tsa_vals = None
+        if tsa_value is not None:
+            w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
+            if isinstance(tsa_value, tuple):
+                Q = tsa_value[0].shape[1]
+                ys = train_ops.grouped_linear([t.reshape(-1, C) for t in tsa_value], w, b, L, "tsa_value_proj")
+                nb = 2
+            else:
+                Q = tsa_value.shape[1]
+                nb = tsa_value.shape[0]
+                ys = train_ops.grouped_linear(tsa_value, w, b, L, "tsa_value_proj")
+            M = tsas[0].num_heads
+            tsa_vals = [y.view(nb, Q, M, -1) for y in ys]
+        return sca_vals, tsa_vals
+
     @auto_fp16()
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
@@ -252,7 +296,15 @@ class BEVFormerEncoder(TransformerLayerSequence):
         intermediate = []
         sca_vals, tsa_vals = self.hoisted_value_projections(value, prev_bev)
         share = None
-        if torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda and ops.modes().grad_thread:
+        fast_train = False
+        if sca_vals is None and tsa_vals is None and value.is_cuda and self._train_fast_path(value.device):
+            # autograd fast path: the same two grouped GEMMs as autograd Functions (their backward sums the six input
+            # gradients in the GEMM epilogues); with bs = 1 the history BEV and the current queries stay two tensors
+            # (no gradient is formed for a detached history)
+            sca_vals, tsa_vals = self.hoisted_value_projections_autograd(
+                value, None if history is None else (history, bev_query) if bs == 1 else prev_bev)
+            fast_train = sca_vals is not None
+        if not fast_train and torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda and ops.modes().grad_thread:
             # training: the camera features and [prev_bev, bev_query] feed every layer's value projection — their six
             # input gradients are summed inside the GEMMs instead of by autograd's adds (ops.GradThread)
             share = {"sca": ops.GradThread(), "tsa": ops.GradThread()}
@@ -260,8 +312,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
             hoisted = {}
             if share is not None:
                 hoisted["value_grad_share"] = share
-                if history is not None:
-                    hoisted["tsa_history"] = history
+            if (share is not None or fast_train) and history is not None:
+                hoisted["tsa_history"] = history
             if sca_vals is not None:
                 hoisted["projected_value"] = sca_vals[li]
                 if li == 0 and getattr(self, "_sca_ready", None) is not None:
@@ -300,6 +352,30 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         assert len(operation_order) == 6
         assert set(operation_order) == set(["self_attn", "norm", "cross_attn", "ffn"])
 
+    def chain_trainable(self):
+        """The autograd path of this layer can run on the row-chain kernels (train_ops.py): the reference's operation
+        order (post-norm), TemporalSelfAttention / SpatialCrossAttention over 256 channels, the 256 -> 512 -> 256 FFN,
+        LayerNorms — and no active dropout (eval mode, or every p = 0): the chain kernels have no dropout stage."""
+        from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
+        from .temporal_self_attention import TemporalSelfAttention
+        if tuple(self.operation_order) != ("self_attn", "norm", "cross_attn", "norm", "ffn", "norm") or self.pre_norm:
+            return False
+        att = getattr(self, "attentions", None)
+        if att is None or len(att) != 2 or len(self.ffns) != 1 or len(self.norms) != 3:
+            return False
+        t, s_, ffn = att[0], att[1], self.ffns[0]
+        if not (isinstance(t, TemporalSelfAttention) and isinstance(s_, SpatialCrossAttention)
+                and isinstance(s_.deformable_attention, MSDeformableAttention3D) and isinstance(ffn, FFN)):
+            return False
+        if t.embed_dims != 256 or s_.embed_dims != 256 or not t.batch_first or ffn.num_fcs != 2 or not ffn.add_identity \
+                or ffn.feedforward_channels != 512 or not all(isinstance(n, torch.nn.LayerNorm) for n in self.norms):
+            return False
+        if self.training:
+            drops = [t.dropout, s_.dropout] + [m for m in ffn.modules() if isinstance(m, torch.nn.Dropout)]
+            if any(getattr(d, "p", 0.0) > 0 for d in drops):
+                return False
+        return True
+
     def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
                 attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
                 ref_3d=None, bev_h=None, bev_w=None, reference_points_cam=None, mask=None,
@@ -329,6 +405,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         # autograd path: the same "+ identity" deferral, resolved by ops.add_layernorm_autograd (one forward pass,
         # one backward kernel instead of torch's add + LayerNorm and their four backward launches)
         fuse_norm_grad = torch.is_grad_enabled() and query.is_cuda and not self.pre_norm
+        # ... and the row-chain kernels as the forward of autograd Functions that save what their backward needs
+        fuse_chain_grad = fuse_norm_grad and ops.modes().train_chain and not torch.is_autocast_enabled() \
+            and ops.gemm_mode() != "native" and self.chain_trainable()
         pending = None                          # (branch output, identity) awaiting its norm
 
         def _defer(i):
@@ -337,26 +416,40 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
 
         def _post_norm(i):
             """The LayerNorm the step at ``i`` may fold into its last projection (inference fast path)."""
-            return self.norms[norm_i] if (fuse_norm and _defer(i)) else None
+            return self.norms[norm_i] if ((fuse_norm or fuse_chain_grad) and _defer(i)) else None
 
         def _chain(i):
             """cross_attn at ``i`` followed by norm, ffn, norm (the reference's order): a callable that runs the rest
             of the layer — output projection, "+ identity", norm, FFN, "+ identity", norm — in one kernel."""
-            if not fuse_norm or tuple(order[i + 1:i + 4]) != ("norm", "ffn", "norm") or ffn_i >= len(self.ffns):
+            if not (fuse_norm or fuse_chain_grad) or tuple(order[i + 1:i + 4]) != ("norm", "ffn", "norm") \
+                    or ffn_i >= len(self.ffns):
                 return None
             ffn, n0, n1 = self.ffns[ffn_i], self.norms[norm_i], self.norms[norm_i + 1]
             if not isinstance(ffn, FFN) or ffn.num_fcs != 2 or not ffn.add_identity \
                     or not isinstance(n0, torch.nn.LayerNorm) or not isinstance(n1, torch.nn.LayerNorm):
                 return None
             fc1, fc2 = ffn.layers[0][0], ffn.layers[-2]
-            return lambda rows, w, b, res, post_norm, gather: ops.proj_ffn_chain(
-                rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain") if post_norm is n0 else None
+
+            def run_s(rows, w, b, res, post_norm, gather, plan=None):
+                if post_norm is not n0:
+                    return None
+                if torch.is_grad_enabled():         # the same kernel as an autograd Function (train_ops.py)
+                    if plan is None or plan.row_query32 is None:
+                        return None
+                    from .. import train_ops
+                    dyn = plan.dynamic
+                    fold = (plan.q_rows_all, plan.n_extra_dev) if (dyn and plan.q_rows_all is not None
+                                                                   and plan.q_rows_all.shape[1] > 2) else None
+                    return train_ops.seam_s(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, row_slot=plan.row_query32,
+                                            nrows=plan.nrows_dev if dyn else None, fold=fold, tag="sca_out_ffn_chain")
+                return ops.proj_ffn_chain(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain")
+            return run_s
 
         def _chain_t(i):
             """self_attn at ``i`` followed by norm, cross_attn: a callable that runs the output projection,
             "+ identity", the norm AND the cross-attention's merged offset / weight projection in one kernel."""
-            if not fuse_norm or tuple(order[i + 1:i + 3]) != ("norm", "cross_attn") or query_pos is not None \
-                    or attn_i + 1 >= len(self.attentions):
+            if not (fuse_norm or fuse_chain_grad) or tuple(order[i + 1:i + 3]) != ("norm", "cross_attn") \
+                    or query_pos is not None or attn_i + 1 >= len(self.attentions):
                 return None
             da = getattr(self.attentions[attn_i + 1], "deformable_attention", None)
             n0 = self.norms[norm_i]
@@ -367,6 +460,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 if post_norm is not n0:
                     return None
                 wm, bm = ops.merged_linear_params(da, da.sampling_offsets, da.attention_weights)
+                if torch.is_grad_enabled():         # the same kernel as an autograd Function (train_ops.py)
+                    from .. import train_ops
+                    return train_ops.seam_t(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain")
                 return ops.proj_ln_proj_chain(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain")
             return run
 

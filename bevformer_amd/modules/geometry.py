@@ -111,6 +111,20 @@ class FramePlan:
     def dynamic(self):
         return self.nrows_dev is not None
 
+    def snapshot(self):
+        """A private copy of a device-side plan that STAYS device-side: the planner's buffers are rewritten in place by
+        its next ``plan()`` (raw pointers, no version counter moves) and the autograd Functions of the training path
+        keep these arrays for their backward — so a differentiable frame works on clones (device-to-device copies,
+        ~10 MB, no host synchronisation: capturable in a HIP graph), the row count still a device tensor."""
+        if not self.dynamic:
+            return self
+        from dataclasses import replace
+        counters = self.counters.clone()
+        return replace(self, counters=counters, nrows_dev=counters[0:1], n_extra_dev=counters[2:3], cam_start=counters[4:],
+                       row_query32=self.row_query32.clone(), row_batch=self.row_batch.clone(), row_ref=self.row_ref.clone(),
+                       q_rows=self.q_rows.clone(), q_rows_all=self.q_rows_all.clone() if self.q_rows_all is not None else None,
+                       inv_count=self.inv_count.clone())
+
     def materialize(self):
         """Host-sized views of a device-side plan (ONE device -> host read of the counters):
         the row arrays narrowed to the actual row count, ``row_query`` as int64, ``hits`` and the

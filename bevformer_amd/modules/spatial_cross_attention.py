@@ -273,7 +273,7 @@ class SpatialCrossAttention(BaseModule):
                 if post_norm is not None and chain is not None and not (self.training and self.dropout.p > 0):
                     # ... and the FFN and its norm behind them: the whole row-local tail of the layer in one kernel
                     done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
-                                 (frame_plan.q_rows, inv_count))
+                                 (frame_plan.q_rows, inv_count), frame_plan)
                     if done is not None:
                         return ops.Chained(done.view(bs, Q, C))
                 if post_norm is not None and not (self.training and self.dropout.p > 0):
@@ -291,6 +291,36 @@ class SpatialCrossAttention(BaseModule):
                     slots, projected = proj.view(bs, Q, C), True
                 else:
                     slots = ops.gather_mean(out_rows, frame_plan.q_rows, inv_count).view(bs, Q, C)
+        if slots is None and chain is not None and post_norm is not None and torch.is_grad_enabled() \
+                and frame_plan is not None and frame_plan.q_rows is not None and frame_plan.q_rows.shape[1] == 2 \
+                and frame_plan.row_query32 is not None and query_pos is None and bs * Q == frame_plan.q_rows.shape[0] \
+                and not (self.training and self.dropout.p > 0) and ops.fused_training_wanted(query, projected_value) \
+                and not getattr(projected_value, "_bevmsda_partial", False):
+            # autograd fast path (train_ops.py): fused sampling (every query projected once; the projection rows may come
+            # out of the previous seam's kernel) -> the whole row-local tail of the layer in one kernel that saves
+            # what its backward needs; the ragged row count never leaves the device
+            dyn = frame_plan.dynamic
+            da_ok = projected_value.shape[-1] == 32 and da.num_levels <= 4 and da.num_points in (4, 8) \
+                and projected_value.dtype == torch.float32 and da.num_points % row_ref.shape[-2] == 0
+            q_tab = frame_plan.q_rows_all if (dyn and frame_plan.q_rows_all is not None) else frame_plan.q_rows
+            if da_ok and (dyn or frame_plan.row_query32.numel() > 0):
+                proj_rows = query_proj
+                if proj_rows is None:
+                    wm, bm = ops.merged_linear_params(da, da.sampling_offsets, da.attention_weights)
+                    proj_rows = ops.linear_or_torch(query.reshape(bs * Q, C), wm, bm, tag="sca_offs_attn")
+                M_, L_, P_ = da.num_heads, da.num_levels, da.num_points
+                Dz = row_ref.shape[-2]
+                out_rows = ops.msda_fused_autograd(
+                    projected_value, spatial_shapes, level_start_index, proj_rows, da.sampling_offsets.out_features,
+                    row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M_, L=L_, P=P_, K=1, off_head=L_ * P_ * 2, off_k=0,
+                    lg_head=L_ * P_, lg_k=0, ref_mode=0, vmul=1, vadd=0, row_src=frame_plan.row_query32, q_rows=q_tab,
+                    tag="sca_fwd", nrows=frame_plan.nrows_dev if dyn else None,
+                    launch_rows=frame_plan.launch_rows if dyn else 0)
+                done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
+                             (frame_plan.q_rows, inv_count), frame_plan)
+                if done is not None:
+                    return ops.Chained(done.view(bs, Q, C))
+                # (declined: the per-op statements below redo the sampling — correct, slower)
         if slots is None:
             if getattr(projected_value, "_bevmsda_partial", False):
                 # a hoisted projection that skipped the cameras this rank's queries cannot see (uninitialised rows)

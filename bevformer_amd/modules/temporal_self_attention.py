@@ -199,6 +199,12 @@ class TemporalSelfAttention(BaseModule):
         proj = None
         if self.batch_first:
             proj = ops.linear(first, w, b, x2=query_in, x2_add=query_pos, tag="tsa_offs_attn")
+            if proj is None and chain is not None and torch.is_grad_enabled() and first.shape == query_in.shape \
+                    and first.shape[-1] == 256 and (query_pos is None or query_pos.shape == query_in.shape):
+                # autograd fast path (the layer offered its chain kernel): the two-source GEMM as an autograd Function
+                from .. import train_ops
+                if train_ops.wanted(first, query_in, query_pos, w, b):
+                    proj = train_ops.two_source_linear(first, query_in, query_pos, w, b, tag="tsa_offs_attn")
         if proj is None:
             if self.batch_first and query_pos is not None:
                 query = query + query_pos

@@ -310,12 +310,14 @@ class _FusedSampleFunction(Function):
     1 / (W, H) back onto the projection rows, accumulated over the rows that share one."""
 
     @staticmethod
-    def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None):
+    def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None, nrows=None,
+                launch_rows=0):
         ctx.modes = _m().snapshot()
         # bf16 storage: ONE rounded copy of the value serves the forward kernel and, saved, the backward kernels
         vs = value.detach().to(_m().value_storage).contiguous()
+        dyn = {} if nrows is None else dict(nrows=nrows, launch_rows=launch_rows)
         out = msda_fused(vs, shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
-                         tag=tag, **meta)
+                         tag=tag, **meta, **dyn)
         if out is None:
             raise RuntimeError("bevmsda: fused sampling kernel does not cover this call")
         ctx.value_dtype = value.dtype
@@ -325,6 +327,7 @@ class _FusedSampleFunction(Function):
         ctx.n_off, ctx.meta, ctx.tag = n_off, meta, tag
         ctx.store = _m().value_storage     # the value storage the forward sampled (bf16: rounded copy of `value`)
         ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
+        ctx.nrows = nrows                 # (1,) int32 device tensor: the row arrays above have CAPACITY rows
         return out
 
     @staticmethod
@@ -353,11 +356,19 @@ class _FusedSampleFunction(Function):
         value = value.detach().to(ctx.store).contiguous()      # bf16 storage: the rounded values the forward saw
         proj = proj.detach()
         logits = proj[:, ctx.n_off:]
+        nrows = ctx.nrows
+        if nrows is not None and (K != 1 or row_batch is None or row_src is None or ctx.q_rows is None):
+            raise RuntimeError("bevmsda: a device-side row count needs the ragged single-entry form with a q_rows table")
         with torch.cuda.device(dev):
-            _lib.check(lib.bevmsda_frontend_expand_f32(
-                proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
-                _ptr(row_src) if row_src is not None else None, _ptr(shapes), ctypes.byref(desc), _ptr(loc),
-                _ptr(attn), _ptr(rbk), st), "fused backward: expand")
+            if nrows is not None:
+                _lib.check(lib.bevmsda_frontend_expand_rows_f32(
+                    proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch), _ptr(row_src), nrows.data_ptr(),
+                    _ptr(shapes), ctypes.byref(desc), _ptr(loc), _ptr(attn), _ptr(rbk), st), "fused backward: expand (rows)")
+            else:
+                _lib.check(lib.bevmsda_frontend_expand_f32(
+                    proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
+                    _ptr(row_src) if row_src is not None else None, _ptr(shapes), ctypes.byref(desc), _ptr(loc),
+                    _ptr(attn), _ptr(rbk), st), "fused backward: expand")
             g = grad_out.float()
             if K > 1:       # out = mean over the queue entries; rows are queue-major
                 g = (g * (1.0 / K)).repeat(K, 1)
@@ -370,8 +381,15 @@ class _FusedSampleFunction(Function):
             cb = _TIMER["cb"]
             alg = value.numel() * value.element_size() + RK * M * L * P * 12 + RK * M * D * g.element_size() \
                 + value.numel() * 4 + RK * M * L * P * 12
+            if nrows is not None:       # (fixed bytes, bytes per row): resolved by the hook's owner from the frame's row count
+                alg = ("per_row", value.numel() * value.element_size() + value.numel() * 4,
+                       M * L * P * 24 + M * D * g.element_size())
             with (cb(ctx.tag.replace("_fwd", "") + "_bwd", alg) if cb is not None else _NoTimer()):
-                if row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
+                if nrows is not None:
+                    _lib.check((lib.bevmsda_backward_rows_bf16 if bf else lib.bevmsda_backward_rows_f32)(
+                        _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), nrows.data_ptr(),
+                        N, S, M, D, L, RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator (rows)")
+                elif row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
                     # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
                     # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
                     _lib.check((lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
@@ -395,11 +413,11 @@ class _FusedSampleFunction(Function):
                 _lib.check(lib.bevmsda_frontend_chain_f32(
                     _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")
-        return gv.to(ctx.value_dtype), gproj, None, None, None, None, None, None, None, None, None
+        return gv.to(ctx.value_dtype), gproj, None, None, None, None, None, None, None, None, None, None, None
 
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
-                        q_rows=None, tag="msda_fwd", **meta):
+                        q_rows=None, tag="msda_fwd", nrows=None, launch_rows=0, **meta):
     """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (D = 32; fp32 or bf16 value storage — with bf16
     the forward's rounded copy of ``value`` is what the backward kernels read; the caller checks
     ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
@@ -410,7 +428,7 @@ def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, r
         _req(q_rows.dtype == torch.int32 and q_rows.dim() == 2 and q_rows.is_contiguous() and q_rows.device == proj.device,
              "bevmsda: q_rows must be a contiguous int32 (slots, J) device tensor")
     return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
-                                      meta, tag, q_rows)
+                                      meta, tag, q_rows, nrows, launch_rows)
 
 
 def fold_extra_rows(rows, q_rows_all, n_extra):
@@ -585,12 +603,19 @@ def set_gemm_variant(variant=None, pack=None):
         _modes.process_defaults().gemm_pack = variant >= 4
 
 
+def _cache_ok(weight):
+    """Derived images of a weight (packed / transposed copies) are cached per version — except while a HIP graph is being
+    captured over a TRAINABLE weight: the replayed graph must rebuild them from the weight's current values (an optimizer
+    step between replays changes them without the capture noticing), so the conversion kernels are captured too."""
+    return not (weight.requires_grad and weight.is_cuda and torch.cuda.is_current_stream_capturing())
+
+
 def packed_weight(weight):
     """Pre-split bf16 image of an (N, K) fp32 weight (``bevmsda_linear_pack_weight_f32``),
     cached on the tensor object until it is written to or moved."""
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
     hit = getattr(weight, "_bevmsda_pack", None)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and _cache_ok(weight):
         return hit[1]
     lib = _lib.load()
     N, K = weight.shape
@@ -616,7 +641,7 @@ def panel_weight(weight):
     (``bevmsda_linear_panel_pack_weight_f32``), cached on the tensor until it is written to or moved."""
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
     hit = getattr(weight, "_bevmsda_panel", None)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and _cache_ok(weight):
         return hit[1]
     lib = _lib.load()
     N, K = weight.shape
@@ -1090,7 +1115,7 @@ def transposed_weight(weight):
     input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape))
     hit = getattr(weight, "_bevmsda_wt", None)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and _cache_ok(weight):
         return hit[1]
     with torch.no_grad():
         wt = weight.detach().t().contiguous()

@@ -1,0 +1,258 @@
+"""GPU: the autograd path of the encoder layer on the inference kernels (bevformer_amd/train_ops.py).
+
+Each autograd Function against autograd through the float64 torch statement of the same math (the statements are the
+reference's: temporal_self_attention.py:186-211, 267-272; spatial_cross_attention.py:165-175; encoder.py:376-404);
+then the whole encoder: fast path == per-op autograd path (``train_chain`` off) on outputs and every gradient, the
+device-side row count through forward and backward, and a HIP graph of a complete forward + backward step."""
+import pytest
+import torch
+import torch.nn as nn
+
+from bevformer_amd import ops, train_ops
+from bevformer_amd import synthetic as S
+
+from helpers import build_pair
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item(), ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _check(got, want, what, l2=2e-4, mx=5e-4):
+    e2, em = _rel(got, want)
+    assert e2 < l2 and em < mx, f"{what}: relative L2 {e2:.2e} (< {l2}), max error / max {em:.2e} (< {mx})"
+
+
+def _leaf(t):
+    return t.clone().detach().to(DEV).requires_grad_(True)
+
+
+def _ln(x, g, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+@pytest.mark.parametrize("M,N2", [(200, 768), (9001, 768), (3000, 192)])
+def test_seam_t_function_matches_the_torch_statement(M, N2):
+    g = torch.Generator().manual_seed(M)
+    rows, res = torch.randn(M, 256, generator=g), torch.randn(1, M, 256, generator=g)
+    w0, b0 = torch.randn(256, 256, generator=g) * 0.06, torch.randn(256, generator=g) * 0.1
+    w1, b1 = torch.randn(N2, 256, generator=g) * 0.06, torch.randn(N2, generator=g) * 0.1
+    norm = nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        norm.bias.copy_(0.1 * torch.randn(256, generator=g))
+    gx, gp = torch.randn(1, M, 256, generator=g), torch.randn(M, N2, generator=g)
+    leaves = [_leaf(t) for t in (rows, w0, b0, res, w1, b1)]
+    out = train_ops.seam_t(leaves[0], leaves[1], leaves[2], leaves[3], norm, leaves[4], leaves[5])
+    assert out is not None
+    x, p = out
+    torch.autograd.backward([x, p], [gx.to(DEV), gp.to(DEV)])
+    # float64 statement
+    d = [t.double().clone().requires_grad_(True) for t in (rows, w0, b0, res, w1, b1)]
+    gam, bet = norm.weight.detach().double().cpu().requires_grad_(True), norm.bias.detach().double().cpu().requires_grad_(True)
+    xw = _ln(d[0] @ d[1].t() + d[2] + d[3], gam, bet, norm.eps)
+    pw = xw.reshape(M, 256) @ d[4].t() + d[5]
+    torch.autograd.backward([xw, pw], [gx.double(), gp.double()])
+    _check(x, xw, "x", 1e-5, 1e-4)
+    _check(p, pw, "p", 1e-5, 1e-4)
+    for name, a, b_ in zip(("rows", "w0", "b0", "res", "w1", "b1"), leaves, d):
+        _check(a.grad, b_.grad, "grad " + name)
+    _check(norm.weight.grad, gam.grad, "grad gamma")
+    _check(norm.bias.grad, bet.grad, "grad beta")
+
+
+def _seam_s_case(M, R, seed, nan_tail=0):
+    """rows (R + nan_tail, 256) of which R are real; every query has 0..2 rows (idx), scale = 1 / count."""
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.randn(R, 256, generator=g)
+    row_slot = torch.randint(0, M, (R,), generator=g)
+    # at most two rows per slot: drop surplus rows by re-assigning them to empty slots
+    idx = torch.full((M, 2), -1, dtype=torch.int32)
+    fill = torch.zeros(M, dtype=torch.long)
+    free = [m for m in range(M)]
+    for r in range(R):
+        s = int(row_slot[r])
+        while fill[s] >= 2:
+            s = (s + 1) % M
+        row_slot[r] = s
+        idx[s, fill[s]] = r
+        fill[s] += 1
+    scale = 1.0 / fill.clamp(min=1).float()
+    if nan_tail:
+        rows = torch.cat([rows, torch.full((nan_tail, 256), float("nan"))], 0)
+        row_slot = torch.cat([row_slot, torch.full((nan_tail,), 2 ** 30, dtype=row_slot.dtype)])     # garbage beyond the count
+    return rows, idx, scale, row_slot.to(torch.int32), g
+
+
+@pytest.mark.parametrize("M,R,dynamic", [(300, 410, False), (9000, 11000, False), (700, 900, True)])
+def test_seam_s_function_matches_the_torch_statement(M, R, dynamic):
+    torch.manual_seed(M)                    # (nn.Linear's default init below)
+    rows, idx, scale, row_slot, g = _seam_s_case(M, R, seed=M + R, nan_tail=333 if dynamic else 0)
+    res = torch.randn(1, M, 256, generator=g)
+    w0, b0 = torch.randn(256, 256, generator=g) * 0.06, torch.randn(256, generator=g) * 0.1
+    fc1, fc2 = nn.Linear(256, 512).to(DEV), nn.Linear(512, 256).to(DEV)
+    n0, n1 = nn.LayerNorm(256).to(DEV), nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        for n in (n0, n1):
+            n.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+            n.bias.copy_(0.1 * torch.randn(256, generator=g))
+    gy = torch.randn(1, M, 256, generator=g)
+    L = [_leaf(t) for t in (rows, w0, b0, res)]
+    nrows = torch.tensor([R], dtype=torch.int32, device=DEV) if dynamic else None
+    y = train_ops.seam_s(L[0], L[1], L[2], L[3], n0, fc1, fc2, n1, gather=(idx.to(DEV), scale.to(DEV)),
+                         row_slot=row_slot.to(DEV), nrows=nrows)
+    assert y is not None
+    y.backward(gy.to(DEV))
+    # float64 statement (camera mean as the gather it is)
+    d = [t.double().clone().requires_grad_(True) for t in (rows[:R], w0, b0, res)]
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in
+         dict(w1=fc1.weight, b1=fc1.bias, w2=fc2.weight, b2=fc2.bias, g0=n0.weight, be0=n0.bias, g1=n1.weight, be1=n1.bias).items()}
+    ii = idx.long()
+    pad = torch.cat([d[0], d[0].new_zeros(1, 256)], 0)
+    a = (pad[ii[:, 0]] + pad[ii[:, 1]]) * scale.double()[:, None]          # (-1 -> the zero row)
+    x = _ln(a @ d[1].t() + d[2] + d[3], P["g0"], P["be0"], n0.eps)
+    h = torch.relu(x @ P["w1"].t() + P["b1"])
+    yw = _ln(x + h @ P["w2"].t() + P["b2"], P["g1"], P["be1"], n1.eps)
+    yw.backward(gy.double())
+    _check(y, yw, "y", 1e-5, 1e-4)
+    # (the ReLU mask of a hidden unit within fp32 round-off of zero may differ from the float64 statement's: a handful of
+    # isolated entries among M x 512 — bounded in L2, loosely in max)
+    _check(L[0].grad[:R], d[0].grad, "grad rows", 1e-3, 3e-2)
+    for name, a_, b_ in zip(("w0", "b0", "res"), L[1:], d[1:]):
+        _check(a_.grad, b_.grad, "grad " + name, 1e-3, 3e-2)
+    for name, mod_p in (("w1", fc1.weight), ("b1", fc1.bias), ("w2", fc2.weight), ("b2", fc2.bias), ("g0", n0.weight),
+                        ("be0", n0.bias), ("g1", n1.weight), ("be1", n1.bias)):
+        _check(mod_p.grad, P[name].grad, "grad " + name, 1e-3, 3e-2)
+
+
+def test_two_source_linear_function_matches_the_torch_statement():
+    g = torch.Generator().manual_seed(5)
+    Q, N = 2500, 192
+    first, query, pos = (torch.randn(1, Q, 256, generator=g) for _ in range(3))
+    w, b = torch.randn(N, 512, generator=g) * 0.05, torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(1, Q, N, generator=g)
+    L = [_leaf(t) for t in (first, query, pos, w, b)]
+    y = train_ops.two_source_linear(*L)
+    y.backward(gy.to(DEV))
+    d = [t.double().clone().requires_grad_(True) for t in (first, query, pos, w, b)]
+    yw = torch.cat([d[0], d[1] + d[2]], -1) @ d[3].t() + d[4]
+    yw.backward(gy.double())
+    _check(y, yw, "y", 1e-5, 1e-4)
+    for name, a, b_ in zip(("first", "query", "pos", "w", "b"), L, d):
+        _check(a.grad, b_.grad, "grad " + name)
+    # a detached history gets no gradient and costs none
+    L2 = [_leaf(t) for t in (first, query, pos, w, b)]
+    L2[0] = L2[0].detach()
+    train_ops.two_source_linear(*L2).backward(gy.to(DEV))
+    _check(L2[1].grad, d[1].grad, "grad query (detached history)")
+
+
+def test_grouped_linear_function_matches_the_torch_statement():
+    g = torch.Generator().manual_seed(6)
+    Lyr, Q = 3, 3000
+    hist, cur = torch.randn(1, Q, 256, generator=g), torch.randn(1, Q, 256, generator=g)
+    w, b = torch.randn(Lyr * 256, 256, generator=g) * 0.06, torch.randn(Lyr * 256, generator=g) * 0.1
+    gys = [torch.randn(2 * Q, 256, generator=g) for _ in range(Lyr)]
+    cur_d, w_d, b_d = _leaf(cur), _leaf(w), _leaf(b)
+    ys = train_ops.grouped_linear([hist.to(DEV).reshape(-1, 256), cur_d.reshape(-1, 256)], w_d, b_d, Lyr, "tsa_value_proj")
+    torch.autograd.backward(list(ys[:2]), [t.to(DEV) for t in gys[:2]])           # (the third output takes no part in the loss)
+    c64, w64, b64 = (t.double().clone().requires_grad_(True) for t in (cur, w, b))
+    x = torch.cat([hist.double().reshape(-1, 256), c64.reshape(-1, 256)], 0)
+    yw = (x @ w64.t() + b64).view(2 * Q, Lyr, 256).unbind(1)
+    torch.autograd.backward(list(yw[:2]), [t.double() for t in gys[:2]])
+    for i in range(Lyr):
+        _check(ys[i], yw[i], f"y{i}", 1e-5, 1e-4)
+    _check(cur_d.grad, c64.grad, "grad current rows")
+    _check(w_d.grad, w64.grad, "grad w")
+    _check(b_d.grad, b64.grad, "grad b")
+
+
+def _grads(enc, q, f, kw, gout):
+    enc.zero_grad(set_to_none=True)
+    qd, fd = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    out = enc(qd, fd, fd, **kw)
+    out.backward(gout)
+    return out.detach(), {"bev_query": qd.grad, "feats": fd.grad, **{k: p.grad for k, p in enc.named_parameters()}}
+
+
+@pytest.mark.parametrize("name,temporal,storage", [("micro4", True, torch.float32), ("micro4", False, torch.float32),
+                                                   ("tiny", True, torch.float32), ("micro4", True, torch.bfloat16)])
+def test_fast_training_path_equals_the_per_op_path(name, temporal, storage):
+    """Same encoder, same frame: the chain-kernel autograd path (device-side plan, row count on the device through
+    forward and backward) against the per-op autograd path of rounds 2-3 (``train_chain=False``: host-sized plan, one
+    Function per Linear / LayerNorm).  Both were / are checked against the oracle elsewhere; here they must agree to
+    GEMM-association round-off on the output and on every gradient."""
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=4, temporal=temporal, device=DEV)
+    gout = torch.randn(1, q.shape[0], 256, generator=torch.Generator().manual_seed(9)).to(DEV)
+    before = train_ops.stats()
+    with ops.using(value_storage=storage, gemm="bf16" if storage == torch.bfloat16 else "split"):
+        out_f, g_f = _grads(enc, q, f, kw, gout)
+        after = train_ops.stats()
+        with ops.using(train_chain=False):
+            out_s, g_s = _grads(enc, q, f, kw, gout)
+    L = len(enc.layers)
+    assert after["seam_s"] - before["seam_s"] == L and after["seam_t"] - before["seam_t"] == L, (before, after)
+    assert after["inplace"] > before["inplace"], "the owned gradient buffers were never added into in place"
+    assert train_ops.stats()["seam_s"] == after["seam_s"], "train_chain=False still took the chain kernels"
+    bf = storage == torch.bfloat16
+    _check(out_f, out_s, "output", 2e-2 if bf else 2e-5, 5e-2 if bf else 2e-4)
+    for k in g_s:
+        assert g_f[k] is not None and g_s[k] is not None, k
+        # (bilinear sampling is piecewise linear: a tap may flip sides between two forward round-offs — L2, not max)
+        e2, _ = _rel(g_f[k], g_s[k])
+        assert e2 < (8e-2 if bf else 3e-2), f"grad {k}: relative L2 {e2:.2e}"
+
+
+def test_training_step_replays_from_a_hip_graph():
+    """A complete forward + backward of the encoder captured in ONE HIP graph (no host read anywhere: device-side plan,
+    row count read by the kernels) and replayed with NEW camera matrices: output and gradients equal the eager step on
+    the same matrices."""
+    name = "micro4"
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=7, temporal=True, device=DEV)
+    import numpy as np
+    base = torch.tensor(np.asarray(kw["img_metas"][0]["lidar2img"]), dtype=torch.float32, device=DEV)
+    l2i = base.clone()
+    kw = dict(kw, img_metas=[dict(lidar2img=l2i, img_shape=kw["img_metas"][0]["img_shape"])])
+    gout = torch.randn(1, q.shape[0], 256, generator=torch.Generator().manual_seed(2)).to(DEV)
+    qd, fd = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
+
+    def step():
+        enc.zero_grad(set_to_none=True)
+        qd.grad = fd.grad = None
+        out = enc(qd, fd, fd, **kw)
+        out.backward(gout)
+        return out.detach()
+
+    for _ in range(2):
+        step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = step()
+    captured = {"q": qd.grad, "f": fd.grad, **{k: p.grad for k, p in enc.named_parameters()}}
+    # new camera matrices: a small yaw of the rig changes the visible rows (and their count)
+    yaw = 0.03
+    T = torch.eye(4, device=DEV)
+    T[0, 0], T[0, 1], T[1, 0], T[1, 1] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw)
+    l2i.copy_(base @ T)
+    graph.replay()
+    torch.cuda.synchronize()
+    got_out = out_g.clone()
+    got = {k: v.clone() for k, v in captured.items()}
+    want_out = step().clone()                       # eager, same (new) matrices
+    want = {"q": qd.grad, "f": fd.grad, **{k: p.grad for k, p in enc.named_parameters()}}
+    _check(got_out, want_out, "output", 1e-6, 1e-5)
+    for k in want:
+        e2, _ = _rel(got[k], want[k])
+        assert e2 < 1e-3, f"grad {k}: graph replay vs eager relative L2 {e2:.2e}"     # (atomics: summation order)
