@@ -56,6 +56,13 @@ class ChainDesc(ctypes.Structure):
                 ("eps1", ctypes.c_float), ("reserved", ctypes.c_int32 * 5)]
 
 
+class WgradProblem(ctypes.Structure):
+    """Mirror of ``struct bevmsda_wgrad_problem``."""
+    _fields_ = [("g", ctypes.c_void_p), ("ldg", ctypes.c_int64), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("grad_w", ctypes.c_void_p), ("ldgw", ctypes.c_int64),
+                ("grad_b", ctypes.c_void_p)]
+
+
 class PlanDesc(ctypes.Structure):
     """Mirror of ``struct bevmsda_plan_desc``."""
     _fields_ = [("B", ctypes.c_int32), ("Nc", ctypes.c_int32), ("Q", ctypes.c_int32),
@@ -117,6 +124,8 @@ SIGNATURES = {
     "bevmsda_linear_f32": ([_c_void_p] * 6 + [ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_packed_f32": ([_c_void_p] * 6 + [ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p],
                                   _c_int),
+    "bevmsda_linear_relu_backward_packed_f32": ([_c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, ctypes.POINTER(LinearDesc),
+                                                 _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_gather_packed_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_panel_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
@@ -130,6 +139,9 @@ SIGNATURES = {
     "bevmsda_proj_ln_proj_chain_f32": ([_c_void_p] * 10 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,
                                   _c_void_p, ctypes.c_int64, _c_void_p, _c_int, _c_void_p], _c_int),
+    "bevmsda_linear_wgrad_multi_f32": ([ctypes.POINTER(WgradProblem), _c_int, ctypes.c_int64, _c_int, _c_void_p], _c_int),
+    "bevmsda_add_layernorm_backward2_f32": ([_c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, _c_int] + [_c_void_p] * 4,
+                                            _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                        _c_int),

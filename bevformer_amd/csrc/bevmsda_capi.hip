@@ -645,9 +645,26 @@ int64_t bevmsda_add_layernorm_backward_partials(int64_t rows) {
   return nb > 2048 ? 2048 : nb;           // 8 workgroups per CU; every wavefront walks rows / 8192 rows
 }
 
+static int ln_backward_launch(const float *x, const float *res, const float *gamma, const float *grad_out,
+                              const float *grad_out2, float eps, int64_t rows, int C, float *grad_x, float *scratch,
+                              float *grad_gamma_beta, void *stream);
+
 int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
                                        float eps, int64_t rows, int C, float *grad_x, float *scratch,
                                        float *grad_gamma_beta, void *stream) {
+  return ln_backward_launch(x, res, gamma, grad_out, nullptr, eps, rows, C, grad_x, scratch, grad_gamma_beta, stream);
+}
+
+int bevmsda_add_layernorm_backward2_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
+                                        const float *grad_out2, float eps, int64_t rows, int C, float *grad_x,
+                                        float *scratch, float *grad_gamma_beta, void *stream) {
+  if (grad_out2 && misaligned(grad_out2)) return BEVMSDA_ERR_MISALIGNED;
+  return ln_backward_launch(x, res, gamma, grad_out, grad_out2, eps, rows, C, grad_x, scratch, grad_gamma_beta, stream);
+}
+
+static int ln_backward_launch(const float *x, const float *res, const float *gamma, const float *grad_out,
+                              const float *grad_out2, float eps, int64_t rows, int C, float *grad_x, float *scratch,
+                              float *grad_gamma_beta, void *stream) {
   if (rows < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (C != 256 && C != 512) return BEVMSDA_ERR_UNSUPPORTED;
   if (!grad_gamma_beta) return BEVMSDA_ERR_NULL_POINTER;
@@ -659,8 +676,8 @@ int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const f
     return BEVMSDA_ERR_MISALIGNED;
   const long long nb = bevmsda_add_layernorm_backward_partials(rows);
   const dim3 grid(static_cast<unsigned>(nb));
-  if (C == 256) hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<1>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr));
-  else hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<2>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr));
+  if (C == 256) hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<1>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr), grad_out2);
+  else hipLaunchKernelGGL((bevmsda::add_layernorm_bwd_kernel<2>), grid, dim3(256), 0, st, x, res, gamma, grad_out, eps, static_cast<long>(rows), grad_x, scratch, static_cast<float *>(nullptr), grad_out2);
   if (hipMemsetAsync(grad_gamma_beta, 0, 2 * static_cast<size_t>(C) * sizeof(float), st) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
   hipLaunchKernelGGL(bevmsda::colsum_partials_kernel, dim3(static_cast<unsigned>((2 * C + 63) / 64), 16), dim3(256), 0, st,
                      scratch, static_cast<long>(nb), 2 * C, grad_gamma_beta);

@@ -21,7 +21,8 @@ extern "C" {
 
 static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
                          const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
-                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr) {
+                         void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr,
+                         const float *mask = nullptr, long ldmask = 0) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -52,6 +53,10 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   // desc->reserved[0] = 1: y += result (first kernel, float4 epilogue: fp32 y, N and ldy multiples of 4, aligned y / bias)
   a.accum = d->reserved[0] == 1 ? 1 : 0;
   if (d->reserved[0] != 0 && d->reserved[0] != 1) return BEVMSDA_ERR_BAD_OPTION;
+  a.mask = mask; a.ldmask = ldmask;
+  if (mask && (gcols != 0 || d->out_bf16 || d->N % 4 != 0 || d->ldy % 4 != 0 || ldmask % 4 != 0 || ldmask < d->N ||
+               misaligned(y) || misaligned(mask) || (bias && misaligned(bias)) || d->variant == 131))
+    return BEVMSDA_ERR_UNSUPPORTED;
   if (a.accum && (d->out_bf16 || d->N % 4 != 0 || d->ldy % 4 != 0 || gcols % 4 != 0 || misaligned(y) || (bias && misaligned(bias)) ||
                   d->variant == 131))
     return BEVMSDA_ERR_UNSUPPORTED;
@@ -64,7 +69,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   // software-pipelined kernel (linear_pipe.h)
   {
     const int nch = (d->K0 + d->K1) / 32;
-    const bool covered = wpack && !add && !a.accum && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
+    const bool covered = wpack && !add && !a.accum && !mask && (d->N % 4) == 0 && (d->ldy % 4) == 0 && (gcols % 4) == 0 && !misaligned(y) &&
                          (!bias || !misaligned(bias)) && (!d->out_bf16 || (reinterpret_cast<uintptr_t>(y) & 7u) == 0) &&
                          (nch == 8 || nch == 16);
     if (d->variant == 131 && !covered) return BEVMSDA_ERR_UNSUPPORTED;
@@ -126,6 +131,14 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
   return linear_launch(x0, a0, x1, a1, nullptr, wpack, bias, d, y, stream);
 }
 
+int bevmsda_linear_relu_backward_packed_f32(const float *g, const uint16_t *wpack, const float *act, int64_t ld_act,
+                                            const bevmsda_linear_desc *d, float *y, void *stream) {
+  if (!wpack || !act) return BEVMSDA_ERR_NULL_POINTER;
+  if (d && (d->K1 != 0 || d->relu)) return BEVMSDA_ERR_BAD_SHAPE;
+  return linear_launch(g, nullptr, nullptr, nullptr, nullptr, wpack, nullptr, d, y, stream, nullptr, nullptr, act,
+                       static_cast<long>(ld_act));
+}
+
 int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx, const float *scale,
                                      const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d,
                                      float *y, void *stream) {
@@ -166,6 +179,46 @@ int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<3>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((bevmsda::wgrad_splitbf16_kernel<1>), grid, block, 0, st, a);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, void *stream) {
+  if (nprob < 0 || nprob > bevmsda::kWgMaxProblems || M < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (precision != 0 && precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (nprob == 0 || M == 0) return BEVMSDA_OK;
+  if (!probs) return BEVMSDA_ERR_NULL_POINTER;
+  bevmsda::WgradMultiArgs a{};
+  long long tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const bevmsda_wgrad_problem &q = probs[i];
+    if (q.N <= 0 || q.K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+    if (q.N % 4 != 0 || q.K % 4 != 0 || q.ldg % 4 != 0 || q.ldx % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+    if (q.ldg < q.N || q.ldx < q.K || q.ldgw < q.K) return BEVMSDA_ERR_BAD_SHAPE;
+    if (!q.g || !q.x || !q.grad_w) return BEVMSDA_ERR_NULL_POINTER;
+    if (misaligned(q.g) || misaligned(q.x) || (reinterpret_cast<uintptr_t>(q.grad_w) & 3u) != 0) return BEVMSDA_ERR_MISALIGNED;
+    bevmsda::WgradArgs &w = a.p[i];
+    w.g = q.g; w.x = q.x; w.ldg = q.ldg; w.ldx = q.ldx; w.gw = q.grad_w; w.ldgw = q.ldgw; w.gb = q.grad_b; w.M = M;
+    w.N = q.N; w.K = q.K; w.tiles_n = (q.N + 127) / 128; w.tiles_k = (q.K + 127) / 128;
+    a.tile0[i] = static_cast<int>(tiles);
+    tiles += 1LL * w.tiles_n * w.tiles_k;
+  }
+  if (tiles >= (1LL << 20)) return BEVMSDA_ERR_TOO_LARGE;
+  a.tile0[nprob] = static_cast<int>(tiles);
+  a.nprob = nprob;
+  // one round of workgroups (2 per CU) over all tiles; 1.5 rounds from 12 tiles on (the single-problem policy)
+  long long slices = tiles >= 12 ? (768 + tiles - 1) / tiles : 512 / tiles;
+  if (slices < 1) slices = 1;
+  long long rows = (M + slices - 1) / slices;
+  rows = ((rows + 31) / 32) * 32;
+  if (rows < 128) rows = 128;
+  slices = (M + rows - 1) / rows;
+  for (int i = 0; i < nprob; ++i) a.p[i].rows_per_block = static_cast<int>(rows);
+  const long long slices8 = ((slices + 7) / 8) * 8;
+  if (tiles * slices8 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  const dim3 grid(static_cast<unsigned>(tiles * slices8)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<3>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<1>), grid, block, 0, st, a);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -61,6 +61,8 @@ struct LinArgs {
   int group_cols;                  // > 0: output column n goes to matrix n / group_cols (each (M, ldy))
   int out_bf16;                    // 1: y holds bf16 (round-to-nearest-even of the fp32 result), ldy in elements
   int accum;                       // 1: y += result (fp32 y, float4 epilogue): gradients of a tensor with several consumers
+  const float *mask;               // (M, ldmask) or nullptr: y = mask > 0 ? result : 0 (float4 epilogue) — the backward of a
+  long ldmask;                     //   ReLU folded into the input-gradient GEMM of the Linear behind it (mask = the ReLU's output)
   int nblk_m, nblk_n;
 #ifdef BEVMSDA_LIN_DIAG
   int diag;                        // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 A loads of chunk 0 only,
@@ -461,6 +463,13 @@ linear_splitbf16_kernel(const LinArgs a) {
                 v.y = v.y < 0.f ? 0.f : v.y;
                 v.z = v.z < 0.f ? 0.f : v.z;
                 v.w = v.w < 0.f ? 0.f : v.w;
+              }
+              if (a.mask) {                   // ReLU backward: pass where the forward's activation was positive
+                const float4 mk = *reinterpret_cast<const float4 *>(a.mask + m * a.ldmask + n);
+                v.x = mk.x > 0.f ? v.x : 0.f;
+                v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f;
+                v.w = mk.w > 0.f ? v.w : 0.f;
               }
               if (a.out_bf16) {             // same element offsets, 2-byte elements
                 uint2 pk;

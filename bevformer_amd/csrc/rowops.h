@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__r
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ gout, float eps, long rows,
                                                                float *__restrict__ gx, float *__restrict__ ggamma,
-                                                               float *__restrict__ gbeta) {
+                                                               float *__restrict__ gbeta,
+                                                               const float *__restrict__ gout2 = nullptr) {
   constexpr int C = 256 * VPL;
   __shared__ float part[2][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,12 +101,17 @@ __global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__r
     const float4 *xp = reinterpret_cast<const float4 *>(x + row * C);
     const float4 *rp = res ? reinterpret_cast<const float4 *>(res + row * C) : nullptr;
     const float4 *yp = reinterpret_cast<const float4 *>(gout + row * C);
+    const float4 *yp2 = gout2 ? reinterpret_cast<const float4 *>(gout2 + row * C) : nullptr;
     float4 v[VPL], gy[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       v[i] = xp[lane + 64 * i];
       gy[i] = yp[lane + 64 * i];
+      if (yp2) {                      // the gradient arrives as two addends (a residual branch and a projection's)
+        const float4 t = yp2[lane + 64 * i];
+        gy[i].x += t.x; gy[i].y += t.y; gy[i].z += t.z; gy[i].w += t.w;
+      }
       if (rp) {
         const float4 t = rp[lane + 64 * i];
         v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;

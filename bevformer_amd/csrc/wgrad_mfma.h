@@ -35,21 +35,12 @@ struct WgradArgs {
 
 constexpr int kWgStage = 32 * 128 * 4;       // bytes of one operand tile of a chunk
 
+// One 128 x 128 output tile (tile index `tile` of the problem) over row slice `slice`.
 template <int NPROD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-wgrad_splitbf16_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_tile(const WgradArgs &a, int tile, int slice, unsigned char *lds) {
   constexpr bool LO = NPROD == 3;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWgStage];     // [stage][G | X]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  // XCD-aware map: workgroup b runs on XCD b % 8 with its private L2.  All output tiles of one row slice read the
-  // same rows of g and x, so they go to ONE XCD, back to back (tile fastest inside an XCD's sequence): the slice
-  // is fetched from HBM once and re-read from that L2 — with tiles dealt round-robin over the XCDs every tile
-  // fetched its operands from HBM again (L2 hit rate 3 %, 346 MB per launch instead of 123 MB: r2n_backward_pmc.json)
-  const int ntile = a.tiles_n * a.tiles_k;
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int tile = seq % ntile;
-  const int slice = (seq / ntile) * 8 + xcd;
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   const long m_begin = static_cast<long>(slice) * a.rows_per_block;
@@ -158,6 +149,53 @@ wgrad_splitbf16_kernel(const WgradArgs a) {
       if (lane < 32 && n < a.N) unsafeAtomicAdd(a.gb + n, s);
     }
   }
+}
+
+template <int NPROD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_splitbf16_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWgStage];     // [stage][G | X]
+  // XCD-aware map: workgroup b runs on XCD b % 8 with its private L2.  All output tiles of one row slice read the
+  // same rows of g and x, so they go to ONE XCD, back to back (tile fastest inside an XCD's sequence): the slice
+  // is fetched from HBM once and re-read from that L2 — with tiles dealt round-robin over the XCDs every tile
+  // fetched its operands from HBM again (L2 hit rate 3 %, 346 MB per launch instead of 123 MB: r2n_backward_pmc.json)
+  const int ntile = a.tiles_n * a.tiles_k;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  wgrad_tile<NPROD>(a, seq % ntile, (seq / ntile) * 8 + xcd, lds);
+}
+
+// Several weight gradients over the SAME rows in one launch (round 4): the backward of a layer seam needs the
+// gradients of two or three Linear layers at once (FFN fc1 / fc2 and the output projection; the output projection and
+// the next attention's projection; ...).  One launch each costs every one of them a full round of workgroups' worth
+// of epilogue atomics (workgroups x 16,384 element atomics: 26 us of a 65 us launch at 512 workgroups) and its own
+// ramp; together their tiles share ONE round: the row slices get longer (fewer partial tiles per output element) and
+// the atomics are paid once.  Tiles of all problems are numbered consecutively (tile0[i] = first tile of problem i).
+constexpr int kWgMaxProblems = 8;
+struct WgradMultiArgs {
+  WgradArgs p[kWgMaxProblems];       // (M, rows_per_block identical in all of them)
+  int tile0[kWgMaxProblems + 1];
+  int nprob;
+};
+
+template <int NPROD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_multi_kernel(const WgradMultiArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWgStage];
+  const int ntile = a.tile0[a.nprob];
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int tile = seq % ntile;
+  const int slice = (seq / ntile) * 8 + xcd;
+  // (uniform selects over constant indices instead of a dynamically indexed kernel-argument array: no scratch copy,
+  // one copy of the tile body)
+  WgradArgs w = a.p[0];
+  int t0 = 0;
+#pragma unroll
+  for (int i = 1; i < kWgMaxProblems; ++i)
+    if (i < a.nprob && tile >= a.tile0[i]) {
+      w = a.p[i];
+      t0 = a.tile0[i];
+    }
+  wgrad_tile<NPROD>(w, tile - t0, slice, lds);
 }
 
 }  // namespace bevmsda

@@ -22,10 +22,10 @@ inference launch keeps on chip) and runs a hand-ordered backward out of the libr
 Nothing here reads a device value on the host: with a device-side frame plan the ragged row count stays on the device
 through forward AND backward (``nrows``), so a whole training step can be captured in a HIP graph.
 
-Gradient buffers are reused deliberately: a Function adds its own contribution into the gradient tensor it was handed
-(GEMM epilogue ``y += result``) when — and only when — that tensor carries the ``_bevmsda_owned`` tag, which the
-Functions of this module put on tensors they allocate and hand out exactly once.  A gradient that autograd had to sum
-(a second consumer) is a new, untagged tensor and is added out of place.
+No Function here writes into a gradient tensor it was handed: where two gradient addends meet in front of a LayerNorm
+(a residual branch's and a projection's input gradient) the LayerNorm-backward kernel forms their sum itself
+(``bevmsda_add_layernorm_backward2_f32``), and the weight gradients of a seam go out in one multi-problem launch
+(``bevmsda_linear_wgrad_multi_f32``) over buffers the Function zeroed itself.
 """
 import ctypes
 
@@ -37,11 +37,11 @@ from . import ops
 from .ext import _ptr
 from .ops import _forward_modes, _m
 
-_STATS = {"seam_s": 0, "seam_t": 0, "two_source": 0, "grouped": 0, "inplace": 0, "out_of_place": 0}
+_STATS = {"seam_s": 0, "seam_t": 0, "two_source": 0, "grouped": 0}
 
 
 def stats():
-    """Counters of this module's Functions (tests: which path ran; how gradients were summed)."""
+    """Counters of this module's Functions (tests: which path ran)."""
     return dict(_STATS)
 
 
@@ -54,21 +54,6 @@ def wanted(*tensors):
         and torch.is_grad_enabled() and not torch.is_autocast_enabled() \
         and all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors) \
         and any(t is not None and t.requires_grad for t in tensors)
-
-
-def _own(t):
-    """Tag a gradient tensor this module allocated and hands out ONCE: its consumer may add into it in place."""
-    if t is not None:
-        try:
-            t._bevmsda_owned = True
-        except AttributeError:
-            pass
-    return t
-
-
-def _owned(t):
-    return t is not None and getattr(t, "_bevmsda_owned", False) and t._base is None and t.is_contiguous() \
-        and t.dtype == torch.float32
 
 
 def _prec():
@@ -86,10 +71,11 @@ def _panel_blob(w):
     return blob
 
 
-def _ln_backward(z, gamma, g, eps, out_shape=None):
+def _ln_backward(z, gamma, g, eps, out_shape=None, g2=None):
     """(grad of the LayerNorm input, grad_gamma, grad_beta) for ``y = LayerNorm(z)``: rowops.h's backward kernel with
-    its residual operand absent.  ``out_shape``: shape of the returned input gradient (a fresh, un-viewed tensor: it
-    can carry the ownership tag)."""
+    its residual operand absent.  ``g2``: a second addend of the incoming gradient (``g + g2`` is formed in the kernel:
+    a residual branch's gradient and a projection's input gradient meet here without an add pass).  ``out_shape``:
+    shape of the returned input gradient."""
     C = z.shape[-1]
     rows = z.numel() // C
     lib = _lib.load()
@@ -98,9 +84,9 @@ def _ln_backward(z, gamma, g, eps, out_shape=None):
     scratch = torch.empty(max(parts, 1) * 2 * C, dtype=torch.float32, device=z.device)
     gwb = torch.empty(2, C, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
-        _lib.check(lib.bevmsda_add_layernorm_backward_f32(
-            _ptr(z), None, _ptr(gamma), _ptr(g), float(eps), rows, C, _ptr(gz), _ptr(scratch), _ptr(gwb),
-            torch.cuda.current_stream().cuda_stream), "LayerNorm backward")
+        _lib.check(lib.bevmsda_add_layernorm_backward2_f32(
+            _ptr(z), None, _ptr(gamma), _ptr(g), _ptr(g2) if g2 is not None else None, float(eps), rows, C, _ptr(gz),
+            _ptr(scratch), _ptr(gwb), torch.cuda.current_stream().cuda_stream), "LayerNorm backward")
     return gz, gwb[0], gwb[1]
 
 
@@ -115,6 +101,30 @@ def _dgrad(g2, weight, tag, acc=None):
             acc.add_(y)
             y = acc
     return y
+
+
+def _dgrad_relu(g2, weight, act, tag):
+    """``(g2 @ weight) * (act > 0)``: the input gradient of the Linear behind a ReLU with the ReLU's backward in the
+    GEMM's epilogue (``bevmsda_linear_relu_backward_packed_f32``); ``act`` = the ReLU's output."""
+    wt = ops.transposed_weight(weight)                      # (in_features, out_features)
+    blob = ops.packed_weight(wt) if _m().gemm_pack else None
+    M, K = g2.shape
+    N = wt.shape[0]
+    if blob is not None and act.is_contiguous() and tuple(act.shape) == (M, N) and N % 4 == 0 and K % 32 == 0:
+        g2c, ldg = ops._rows2d(g2, K)
+        y = torch.empty((M, N), dtype=torch.float32, device=g2.device)
+        desc = _lib.LinearDesc(M=M, ldx0=ldg, ldw=K, ldy=N, N=N, K0=K, K1=0, relu=0, precision=_prec())
+        desc.reserved[1] = 1                                # (the first kernel: its epilogue carries the mask)
+        lib = _lib.load()
+        cb = ops._GEMM_TIMER["cb"]
+        ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * K + N * K + 2 * M * N)) if cb is not None else ops._NoTimer()
+        with torch.cuda.device(g2.device), ctx:
+            rc = lib.bevmsda_linear_relu_backward_packed_f32(_ptr(g2c), _ptr(blob), _ptr(act), N, ctypes.byref(desc), _ptr(y),
+                                                             torch.cuda.current_stream().cuda_stream)
+        if rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+            _lib.check(rc, "linear_relu_backward")
+            return y
+    return torch.ops.aten.threshold_backward(_dgrad(g2, weight, tag), act, 0.0)
 
 
 def _wgrad_into(g2, x2, gw, gb, tag):
@@ -132,6 +142,35 @@ def _wgrad_into(g2, x2, gw, gb, tag):
                                           gb.data_ptr() if gb is not None else None, _prec(),
                                           torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "linear_wgrad")
+
+
+def _wgrad_multi(problems, tag):
+    """Several weight gradients over the same rows in ONE launch (``bevmsda_linear_wgrad_multi_f32``): ``problems`` =
+    [(g2 (M, N), x2 (M, K), gw (N, K view), gb (N) or None), ...], accumulating into zeroed gw / gb."""
+    if not problems:
+        return
+    M = problems[0][0].shape[0]
+    arr = (_lib.WgradProblem * len(problems))()
+    keep = []
+    flops = nbytes = 0.0
+    for i, (g2, x2, gw, gb) in enumerate(problems):
+        N, K = g2.shape[1], x2.shape[1]
+        g2, ldg = ops._rows2d(g2, N)
+        x2, ldx = ops._rows2d(x2, K)
+        keep += [g2, x2]
+        assert g2.shape[0] == M and x2.shape[0] == M
+        arr[i].g, arr[i].ldg, arr[i].x, arr[i].ldx = g2.data_ptr(), ldg, x2.data_ptr(), ldx
+        arr[i].N, arr[i].K, arr[i].grad_w, arr[i].ldgw = N, K, gw.data_ptr(), gw.stride(0)
+        arr[i].grad_b = gb.data_ptr() if gb is not None else None
+        flops += 2.0 * M * N * K
+        nbytes += 4.0 * (M * (N + K) + N * K)
+    lib = _lib.load()
+    cb = ops._GEMM_TIMER["cb"]
+    ctx = cb(tag, flops, nbytes) if cb is not None else ops._NoTimer()
+    dev = problems[0][0].device
+    with torch.cuda.device(dev), ctx:
+        rc = lib.bevmsda_linear_wgrad_multi_f32(arr, len(problems), M, _prec(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "linear_wgrad_multi")
 
 
 def _zeros(device, *shapes):
@@ -191,14 +230,17 @@ class _GroupedLinearFunction(Function):
         wt = None
         if lo is not None:
             wt = wcat.detach().view(L, ncol, K)
+        probs = []
         for i, g in enumerate(gys):
             if g is None:
                 continue
             g2 = g.reshape(M, ncol).float()
             if dW is not None:
-                _wgrad_into(g2, x2, dW[i * ncol:(i + 1) * ncol], db[i * ncol:(i + 1) * ncol], ctx.tag + "_dw")
+                probs.append((g2, x2, dW[i * ncol:(i + 1) * ncol], db[i * ncol:(i + 1) * ncol]))
             if lo is not None:
                 dx = _dgrad(g2[lo:hi], wt[i], ctx.tag + "_dx", acc=dx)
+        for j in range(0, len(probs), 8):           # the weight gradients of all layers share the rows: one launch
+            _wgrad_multi(probs[j:j + 8], ctx.tag + "_dw")
         grads = []
         for (a, b), s, nd in zip(offs, ctx.x_shapes, need_x):
             grads.append(dx[a - lo:b - lo].view(*s) if (nd and dx is not None) else None)
@@ -246,13 +288,13 @@ class _TwoSourceLinearFunction(Function):
             d_first = (g2 @ w[:, :K0] if d_first is None else d_first).view(first.shape)
         if ni[1] or (ctx.has_pos and ni[2]):
             d_q = ops.linear(g2, wt[K0:], None, tag=ctx.tag + "_dx", _inside_autograd=True)
-            d_q = _own((g2 @ w[:, K0:] if d_q is None else d_q).view(query.shape))
+            d_q = (g2 @ w[:, K0:] if d_q is None else d_q).view(query.shape)
         dW = db = None
         if ni[3] or (ctx.has_b and ni[4]):
             dW, db = _zeros(w.device, (N, K0 + K1), (N,))
-            _wgrad_into(g2, first.reshape(-1, K0), dW[:, :K0], db, ctx.tag + "_dw")
             qp = query if not ctx.has_pos else query + pos
-            _wgrad_into(g2, qp.reshape(-1, K1), dW[:, K0:], None, ctx.tag + "_dw")
+            _wgrad_multi([(g2, first.reshape(-1, K0), dW[:, :K0], db), (g2, qp.reshape(-1, K1), dW[:, K0:], None)],
+                         ctx.tag + "_dw")
         d_pos = None
         if ctx.has_pos and ni[2]:
             d_pos = d_q if not ni[1] else d_q.clone()      # (one buffer per consumer: either may be added into)
@@ -316,33 +358,28 @@ class _SeamTFunction(Function):
         dev = x.device
         ni = ctx.needs_input_grad
         dW0, db0, dW1, db1 = _zeros(dev, (256, 256), (256,), (N2, 256), (N2,))
-        mine = _owned(gx)                       # (asked of the tensor autograd handed over, before any view of it)
         if gx is not None:
             gx = gx.reshape(M, 256)
             if gx.dtype != torch.float32 or not gx.is_contiguous():
-                gx, mine = gx.float().contiguous(), True
+                gx = gx.float().contiguous()
+        probs = []
+        gp2 = dxp = None
         if gp is not None:
             gp2 = gp.reshape(M, N2).float()
             if ni[6] or ni[7]:
-                _wgrad_into(gp2, x, dW1, db1, ctx.tag + "_dw1")
-            if mine:
-                _STATS["inplace"] += 1
-                dx = _dgrad(gp2, w1, ctx.tag + "_dx1", acc=gx)
-            else:
-                dx = _dgrad(gp2, w1, ctx.tag + "_dx1")
-                if gx is not None:
-                    _STATS["out_of_place"] += 1
-                    dx.add_(gx)
-        else:
-            dx = gx
-        if dx is None:
+                probs.append((gp2, x, dW1, db1))
+            dxp = _dgrad(gp2, w1, ctx.tag + "_dx1")          # the projection's share of the gradient of x
+        if gx is None and dxp is None:
             return (None,) * 10
-        dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dx, ctx.eps0, out_shape=ctx.res_shape)
+        # the two addends of d/dx (the residual branch's gradient, the projection's) meet inside the LayerNorm backward
+        ga, gb_ = (gx, dxp) if gx is not None else (dxp, None)
+        dzr, dg0, dbe0 = _ln_backward(z0, gamma0, ga, ctx.eps0, out_shape=ctx.res_shape, g2=gb_)
         dz0 = dzr.view(M, 256)
         if ni[1] or ni[2]:
-            _wgrad_into(dz0, rows2, dW0, db0, ctx.tag + "_dw0")
+            probs.append((dz0, rows2, dW0, db0))
+        _wgrad_multi(probs, ctx.tag + "_dw")
         d_rows = _dgrad(dz0, w0, ctx.tag + "_dx0").view(ctx.rows_shape) if ni[0] else None
-        d_res = _own(dzr) if ni[3] else None
+        d_res = dzr if ni[3] else None
         return (d_rows, dW0 if ni[1] else None, db0 if (ctx.has_b0 and ni[2]) else None, d_res, dg0 if ni[4] else None,
                 dbe0 if ni[5] else None, dW1 if ni[6] else None, db1 if (ctx.has_b1 and ni[7]) else None, None, None)
 
@@ -430,18 +467,17 @@ class _SeamSFunction(Function):
         dW0, db0, dW1, db1, dW2, db2 = _zeros(dev, (256, 256), (256,), (512, 256), (512,), (256, 512), (256,))
         # LayerNorm1, FFN
         dz1, dg1, dbe1 = _ln_backward(z1, gamma1, gy, ctx.eps1)
-        _wgrad_into(dz1, h, dW2, db2, tag + "_dw2")
-        dh = _dgrad(dz1, w2, tag + "_dx2")                                     # (M, 512)
-        dh = torch.ops.aten.threshold_backward(dh, h, 0.0)                    # relu: where h > 0
-        _wgrad_into(dh, x, dW1, db1, tag + "_dw1")
-        dx = _dgrad(dh, w1, tag + "_dx1", acc=dz1)                            # dz1 (the residual branch) += dh w1
-        # LayerNorm0, output projection, camera mean
-        dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dx, ctx.eps0, out_shape=ctx.res_shape)
+        dh = _dgrad_relu(dz1, w2, h, tag + "_dx2")                             # (M, 512): (dz1 w2) where h > 0
+        dxf = _dgrad(dh, w1, tag + "_dx1")                                    # the FFN's share of the gradient of x
+        # LayerNorm0 (d/dx = the residual branch's dz1 + the FFN's share: added inside the kernel), output projection
+        dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dz1, ctx.eps0, out_shape=ctx.res_shape, g2=dxf)
         dz0 = dzr.view(M, 256)
+        probs = [(dz1, h, dW2, db2), (dh, x, dW1, db1)]
         d_rows = None
         if ni[0] or ni[1] or ni[2]:
             g = ops.gather_mean(rows2 if rows2.is_contiguous() else rows2.contiguous(), idx, scale)   # recomputed: (M, 256)
-            _wgrad_into(dz0, g, dW0, db0, tag + "_dw0")
+            probs.append((dz0, g, dW0, db0))
+        _wgrad_multi(probs, tag + "_dw")            # the three weight gradients of the seam: one launch
         if ni[0]:
             dg = _dgrad(dz0, w0, tag + "_dx0")
             R = rows2.shape[0]
@@ -451,8 +487,7 @@ class _SeamSFunction(Function):
                 _lib.check(lib.bevmsda_rows_from_slots_f32(
                     _ptr(dg), 256, _ptr(scale), _ptr(row_slot), nrows.data_ptr() if ctx.has_nrows else None, R, 256,
                     _ptr(d_rows), torch.cuda.current_stream().cuda_stream), "rows_from_slots")
-            d_rows = _own(d_rows)
-        d_res = _own(dzr) if ni[3] else None
+        d_res = dzr if ni[3] else None
         hb = ctx.has_b
         return (d_rows, dW0 if ni[1] else None, db0 if (hb[0] and ni[2]) else None, d_res, dg0 if ni[4] else None,
                 dbe0 if ni[5] else None, dW1 if ni[6] else None, db1 if (hb[1] and ni[7]) else None,

@@ -269,6 +269,11 @@ int64_t bevmsda_add_layernorm_backward_partials(int64_t rows);
 int bevmsda_add_layernorm_backward_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
                                        float eps, int64_t rows, int C, float *grad_x, float *scratch,
                                        float *grad_gamma_beta, void *stream);
+/* The same with the incoming gradient given as TWO addends, grad_out + grad_out2 (grad_out2 may be NULL): a residual
+ * branch's gradient and a projection's input gradient meet in front of a LayerNorm without a separate add pass. */
+int bevmsda_add_layernorm_backward2_f32(const float *x, const float *res, const float *gamma, const float *grad_out,
+                                        const float *grad_out2, float eps, int64_t rows, int C, float *grad_x,
+                                        float *scratch, float *grad_gamma_beta, void *stream);
 /* out[q, :] = scale[q] * sum_{j<J, idx[q,j]>=0} rows[idx[q,j], :] — the per-camera
  * scatter-add and division by the camera count of SpatialCrossAttention
  * (spatial_cross_attention.py:165-172) as a gather.  idx: (Q, J) int32, -1 = empty. */
@@ -341,6 +346,15 @@ int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, ui
 int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
                               const uint16_t *wpack, const float *bias,
                               const bevmsda_linear_desc *desc, float *y, void *stream);
+/* Input gradient of a Linear that sits behind a ReLU, with the ReLU's backward in the epilogue:
+ *     y[m, n] = act[m, n] > 0 ? sum_k g[m, k] * w[n, k] : 0
+ * g (M, desc->ldx0) = the gradient w.r.t. the Linear's output (desc->K0 columns), wpack = the packed image of the
+ * TRANSPOSED weight (N = the Linear's in_features rows, K0 = out_features columns), act (M, ld_act) = the ReLU's output
+ * saved by the forward (mmcv FFN: Linear -> ReLU -> Linear, custom_base_transformer_layer.py:157-158).  fp32 y with N,
+ * ldy, ld_act multiples of 4 and 16-byte aligned pointers; no bias, no second source. */
+int bevmsda_linear_relu_backward_packed_f32(const float *g, const uint16_t *wpack, const float *act, int64_t ld_act,
+                                            const bevmsda_linear_desc *desc, float *y, void *stream);
+
 /* The packed projection with bevmsda_gather_mean_f32 folded into its A-load:
  *     A[m, :] = scale[m] * sum_{j < 2, idx[m, j] >= 0} rows[idx[m, j], :]      (idx: (M, 2) int32)
  * — SpatialCrossAttention's per-camera scatter-add, camera-count division and output_proj
@@ -502,6 +516,21 @@ int bevmsda_proj_ln_proj_chain_train_f32(const float *rows, const uint16_t *w0p,
  * N, K, ldg, ldx multiples of 4, g / x 16-byte aligned; otherwise BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED. */
 int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_t ldx, int64_t M, int N, int K,
                              float *grad_w, int64_t ldgw, float *grad_b, int precision, void *stream);
+
+/* Several weight gradients over the SAME M rows in one launch (the backward of a layer seam needs two or three at
+ * once): tiles of all problems share one round of workgroups — longer row slices, the epilogue atomics paid once
+ * instead of once per Linear.  Up to 8 problems; each as bevmsda_linear_wgrad_f32 (accumulating; grad_b may be NULL). */
+typedef struct bevmsda_wgrad_problem {
+  const float *g;       /* (M, ldg): gradient w.r.t. the Linear's output, N columns */
+  int64_t ldg;
+  const float *x;       /* (M, ldx): the Linear's input, K columns */
+  int64_t ldx;
+  int32_t N, K;
+  float *grad_w;        /* (N, ldgw), accumulated into */
+  int64_t ldgw;
+  float *grad_b;        /* (N) or NULL */
+} bevmsda_wgrad_problem;
+int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, void *stream);
 
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *

@@ -197,7 +197,6 @@ def test_fast_training_path_equals_the_per_op_path(name, temporal, storage):
             out_s, g_s = _grads(enc, q, f, kw, gout)
     L = len(enc.layers)
     assert after["seam_s"] - before["seam_s"] == L and after["seam_t"] - before["seam_t"] == L, (before, after)
-    assert after["inplace"] > before["inplace"], "the owned gradient buffers were never added into in place"
     assert train_ops.stats()["seam_s"] == after["seam_s"], "train_chain=False still took the chain kernels"
     bf = storage == torch.bfloat16
     _check(out_f, out_s, "output", 2e-2 if bf else 2e-5, 5e-2 if bf else 2e-4)
