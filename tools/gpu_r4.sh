@@ -22,7 +22,7 @@ for s in $steps; do
     bwd_base) timeout 400 python bench.py --no-cpu-baseline --no-variants --backward --steps 5 --warmup 2 --windows 3 ${BWD_ARGS:-} > "$out/bench_bwd_base.json" 2> "$out/bench_bwd_base.err"; echo "rc=$?" >> "$out/bench_bwd_base.err"; cut -c1-500 "$out/bench_bwd_base.json"; tail -3 "$out/bench_bwd_base.err";;
     bwd_small4) timeout 400 python bench.py --no-cpu-baseline --no-variants --backward --workload small4 --steps 5 --warmup 2 --windows 3 ${BWD_ARGS:-} > "$out/bench_bwd_small4.json" 2> "$out/bench_bwd_small4.err"; echo "rc=$?" >> "$out/bench_bwd_small4.err"; cut -c1-500 "$out/bench_bwd_small4.json"; tail -3 "$out/bench_bwd_small4.err";;
     bwd_small4_bf16) timeout 400 python bench.py --no-cpu-baseline --no-variants --backward --workload small4 --gemm bf16 --value-storage bf16 --steps 5 --warmup 2 --windows 3 ${BWD_ARGS:-} > "$out/bench_bwd_small4_bf16.json" 2> "$out/bench_bwd_small4_bf16.err"; echo "rc=$?" >> "$out/bench_bwd_small4_bf16.err"; cut -c1-500 "$out/bench_bwd_small4_bf16.json"; tail -3 "$out/bench_bwd_small4_bf16.err";;
-    trace_bwd) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_bwd" python "$root/bench.py" --no-cpu-baseline --no-variants --backward --graph off --steps 3 --warmup 1 --windows 1 ${BWD_ARGS:-} > "$out/prof_bwd_summary.txt" 2>&1; head -45 "$out/prof_bwd_summary.txt" | cut -c1-170;;
+    trace_bwd) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_bwd${TRACE_TAG:-}" python "$root/bench.py" --no-cpu-baseline --no-variants --backward --graph off --steps 3 --warmup 1 --windows 1 ${BWD_ARGS:-} > "$out/prof_bwd_summary.txt" 2>&1; head -45 "$out/prof_bwd_summary.txt" | cut -c1-170;;
     trace_fwd) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_fwd" python "$root/bench.py" --no-cpu-baseline --no-variants --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_fwd_summary.txt" 2>&1; head -30 "$out/prof_fwd_summary.txt" | cut -c1-170;;
     traffic_fwd) timeout 900 python tools/profile_traffic.py --config base_fwd --tag "$tag" > "$out/traffic_fwd.log" 2>&1; tail -15 "$out/traffic_fwd.log";;
     traffic_bwd) timeout 900 python tools/profile_traffic.py --config base_bwd --tag "$tag" > "$out/traffic_bwd.log" 2>&1; tail -15 "$out/traffic_bwd.log";;
