@@ -587,6 +587,19 @@ int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const floa
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+int bevmsda_cast_rows_bf16(const float *in, const int32_t *nrows, int64_t R, int C, float scale, uint16_t *out, void *stream) {
+  if (R < 0 || C <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (C % 8 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (R == 0) return BEVMSDA_OK;
+  if (!in || !out) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(in) || misaligned(out)) return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = (R * static_cast<long long>(C / 8) + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::cast_rows_bf16_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, nrows, static_cast<long>(R), C, scale, out);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *offs, const float *logits, const float *ref,
                               const int32_t *row_batch, const int32_t *row_src,

@@ -376,8 +376,35 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   // workgroup shape (desc->reserved[1]): 1 = 64-row panels (8 wavefronts, one workgroup per CU), 2 = 32-row panels
   // (4 wavefronts, two workgroups per CU); 0 = default
   int shape = d->reserved[1];
-  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
-  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
+  if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
+  // default: 32-row panels up to kChainSmallRows rows, mixed from one whole round of 64-row panels on (measured at 40,000
+  // rows, interleaved runs on one box: 103.2-103.6 vs 106.6-107.2 us; profiles/r4/r4f_chain_mixed_shape_ab.txt)
+  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : (d->M >= 256LL * 64 ? 3 : 1);
+  if (shape == 3) {
+    // mixed (round 4): whole rounds of the 64-row shape (one workgroup per CU: 256 x 64 rows per round)
+    // and the remainder — a partial round that would leave most CUs idle behind a few 64-row workgroups — on the 32-row
+    // shape at two workgroups per CU, as a second launch over the tail rows
+    const long long round64 = 256LL * 64;
+    const long long head = (d->M / round64) * round64;
+    const long long tail = d->M - head;
+    if (head == 0 || tail == 0 || tail > 256LL * 2 * 32) {
+      bevmsda_chain_desc one = *d;
+      one.reserved[1] = (head == 0) ? 2 : 1;
+      return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &one, y, stream,
+                              save, sv_z0, sv_x, sv_h, sv_z1);
+    }
+    bevmsda_chain_desc dh = *d, dt = *d;
+    dh.M = head; dh.reserved[1] = 1;
+    dt.M = tail; dt.reserved[1] = 2;
+    int rc = ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dh, y, stream,
+                              save, sv_z0, sv_x, sv_h, sv_z1);
+    if (rc != BEVMSDA_OK) return rc;
+    const long long o = head;
+    return ffn_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p, b0,
+                            res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dt,
+                            y + o * d->ld_y, stream, save, save ? sv_z0 + o * 256 : nullptr, save ? sv_x + o * 256 : nullptr,
+                            save ? sv_h + o * 512 : nullptr, save ? sv_z1 + o * 256 : nullptr);
+  }
   const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
@@ -442,9 +469,27 @@ static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const flo
       (b0 && misaligned(b0)) || (b1 && misaligned(b1)) || misaligned(gamma0) || misaligned(beta0))
     return BEVMSDA_ERR_MISALIGNED;
   int shape = d->reserved[1];
-  if (shape < 0 || shape > 2) return BEVMSDA_ERR_BAD_OPTION;
-  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : 1;
+  if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : (d->M >= 256LL * 64 ? 3 : 1);     // (100.4-101.5 vs 103.8-105.7 us at 40,000 rows)
   if (d->F % 64 != 0) shape = 1;               // the 32-row shape walks 64-column tiles
+  if (shape == 3) {                            // mixed: whole rounds on the 64-row shape, the tail on the 32-row shape
+    const long long round64 = 256LL * 64;
+    const long long head = (d->M / round64) * round64;
+    const long long tail = d->M - head;
+    bevmsda_chain_desc dh = *d, dt = *d;
+    if (head == 0 || tail == 0 || tail > 256LL * 2 * 32) {
+      dh.reserved[1] = (head == 0) ? 2 : 1;
+      return ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0);
+    }
+    dh.M = head; dh.reserved[1] = 1;
+    dt.M = tail; dt.reserved[1] = 2;
+    int rc = ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0);
+    if (rc != BEVMSDA_OK) return rc;
+    const long long o = head;
+    return ln_proj_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p,
+                                b0, res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, &dt, x_out + o * d->ld_y,
+                                proj_out + o * ld_y2, stream, save, save ? sv_z0 + o * 256 : nullptr);
+  }
   const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;

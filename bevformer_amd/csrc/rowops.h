@@ -228,4 +228,30 @@ __global__ void __launch_bounds__(256) rows_from_slots_kernel(const float *__res
   reinterpret_cast<float4 *>(rows + r * C)[c] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
 }
 
+// out[r, :] = bf16(scale * in[r, :]) for r < the row count (device-side `nrows_dev`, else R): the gradient rows of the
+// sampling backward in the storage type of its kernels, touching only the rows that exist.  8 floats per thread.
+__global__ void __launch_bounds__(256) cast_rows_bf16_kernel(const float *__restrict__ in, const int32_t *__restrict__ nrows_dev,
+                                                            long R, int C, float scale, uint16_t *__restrict__ out) {
+  const int c8 = C >> 3;
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  long n = R;
+  if (nrows_dev) {
+    const long d = static_cast<long>(*nrows_dev);
+    n = d < n ? (d < 0 ? 0 : d) : n;
+  }
+  if (t >= n * c8) return;
+  const float4 a = reinterpret_cast<const float4 *>(in)[2 * t], b = reinterpret_cast<const float4 *>(in)[2 * t + 1];
+  auto rn = [](float f) -> uint32_t {      // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  uint4 o;
+  o.x = rn(a.x * scale) | (rn(a.y * scale) << 16);
+  o.y = rn(a.z * scale) | (rn(a.w * scale) << 16);
+  o.z = rn(b.x * scale) | (rn(b.y * scale) << 16);
+  o.w = rn(b.z * scale) | (rn(b.w * scale) << 16);
+  reinterpret_cast<uint4 *>(out)[t] = o;
+}
+
 }  // namespace bevmsda

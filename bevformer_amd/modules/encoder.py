@@ -241,7 +241,13 @@ class BEVFormerEncoder(TransformerLayerSequence):
             return None, None
         feats = value.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
         w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
-        ys = train_ops.grouped_linear(feats, w, b, L, "sca_value_proj")
+        # bf16 value storage: the GEMM rounds in its epilogue, the sampling Functions hand their fp32 gradients back
+        # through a sink (no conversion pass in either direction)
+        store = ops.value_storage()
+        bf = store == torch.bfloat16
+        self._value_sinks = ([None] * L, [None] * L) if bf else None
+        ys = train_ops.grouped_linear(feats, w, b, L, "sca_value_proj", out_dtype=store if bf else None,
+                                      sink=self._value_sinks[0] if bf else None)
         M = scas[0].num_heads
         sca_vals = [y.view(bs * Nc, S, M, -1) for y in ys]
         tsa_vals = None
@@ -249,12 +255,14 @@ class BEVFormerEncoder(TransformerLayerSequence):
             w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
             if isinstance(tsa_value, tuple):
                 Q = tsa_value[0].shape[1]
-                ys = train_ops.grouped_linear([t.reshape(-1, C) for t in tsa_value], w, b, L, "tsa_value_proj")
+                ys = train_ops.grouped_linear([t.reshape(-1, C) for t in tsa_value], w, b, L, "tsa_value_proj",
+                                              out_dtype=store if bf else None, sink=self._value_sinks[1] if bf else None)
                 nb = 2
             else:
                 Q = tsa_value.shape[1]
                 nb = tsa_value.shape[0]
-                ys = train_ops.grouped_linear(tsa_value, w, b, L, "tsa_value_proj")
+                ys = train_ops.grouped_linear(tsa_value, w, b, L, "tsa_value_proj", out_dtype=store if bf else None,
+                                              sink=self._value_sinks[1] if bf else None)
             M = tsas[0].num_heads
             tsa_vals = [y.view(nb, Q, M, -1) for y in ys]
         return sca_vals, tsa_vals
@@ -314,6 +322,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 hoisted["value_grad_share"] = share
             if (share is not None or fast_train) and history is not None:
                 hoisted["tsa_history"] = history
+            if fast_train and getattr(self, "_value_sinks", None) is not None:
+                hoisted["projected_value_sink"] = (self._value_sinks[0], li)
+                hoisted["tsa_projected_value_sink"] = (self._value_sinks[1], li)
             if sca_vals is not None:
                 hoisted["projected_value"] = sca_vals[li]
                 if li == 0 and getattr(self, "_sca_ready", None) is not None:

@@ -300,8 +300,11 @@ class SpatialCrossAttention(BaseModule):
             # out of the previous seam's kernel) -> the whole row-local tail of the layer in one kernel that saves
             # what its backward needs; the ragged row count never leaves the device
             dyn = frame_plan.dynamic
+            sink = kwargs.get("projected_value_sink")
             da_ok = projected_value.shape[-1] == 32 and da.num_levels <= 4 and da.num_points in (4, 8) \
-                and projected_value.dtype == torch.float32 and da.num_points % row_ref.shape[-2] == 0
+                and (projected_value.dtype == torch.float32
+                     or (projected_value.dtype == torch.bfloat16 == ops.value_storage() and sink is not None)) \
+                and da.num_points % row_ref.shape[-2] == 0
             q_tab = frame_plan.q_rows_all if (dyn and frame_plan.q_rows_all is not None) else frame_plan.q_rows
             if da_ok and (dyn or frame_plan.row_query32.numel() > 0):
                 proj_rows = query_proj
@@ -315,7 +318,8 @@ class SpatialCrossAttention(BaseModule):
                     row_ref.reshape(-1, 1, Dz, 2), row_batch, M=M_, L=L_, P=P_, K=1, off_head=L_ * P_ * 2, off_k=0,
                     lg_head=L_ * P_, lg_k=0, ref_mode=0, vmul=1, vadd=0, row_src=frame_plan.row_query32, q_rows=q_tab,
                     tag="sca_fwd", nrows=frame_plan.nrows_dev if dyn else None,
-                    launch_rows=frame_plan.launch_rows if dyn else 0)
+                    launch_rows=frame_plan.launch_rows if dyn else 0,
+                    value_sink=sink if projected_value.dtype == torch.bfloat16 else None)
                 done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
                              (frame_plan.q_rows, inv_count), frame_plan)
                 if done is not None:

@@ -221,8 +221,10 @@ class TemporalSelfAttention(BaseModule):
                                  Q=Q, tag="tsa_fwd")
             if out is not None:
                 out = out.to(query.dtype).view(bs, Q, C)
+        vsink = kwargs.get("tsa_projected_value_sink") if v is tsa_projected_value else None
+        v_ok = v.dtype == torch.float32 or (v.dtype == torch.bfloat16 == ops.value_storage() and vsink is not None)
         if out is None and reference_points.shape[-1] == 2 and self.batch_first and key_padding_mask is None \
-                and v.shape[-1] == 32 and L <= 4 and P in (4, 8) and nq * P <= 8 and v.dtype == torch.float32 \
+                and v.shape[-1] == 32 and L <= 4 and P in (4, 8) and nq * P <= 8 and v_ok \
                 and ops.fused_training_wanted(proj, v):
             # autograd path: same kernel, gradients w.r.t. the value and the projection rows
             ref = _rows_layout(reference_points, bs, nq, Q, L)
@@ -230,7 +232,8 @@ class TemporalSelfAttention(BaseModule):
                                           proj.reshape(bs * Q, -1), n_off, ref, None, M=M, L=L, P=P, K=nq,
                                           off_head=nq * L * P * 2, off_k=L * P * 2, lg_head=nq * L * P,
                                           lg_k=L * P, ref_mode=1, vmul=1 if shared_value else nq,
-                                          vadd=0 if shared_value else 1, Q=Q, tag="tsa_fwd")
+                                          vadd=0 if shared_value else 1, Q=Q, tag="tsa_fwd",
+                                          value_sink=vsink if v.dtype == torch.bfloat16 else None)
             out = out.to(query.dtype).view(bs, Q, C)
         if out is None:
             out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,

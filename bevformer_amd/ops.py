@@ -311,8 +311,12 @@ class _FusedSampleFunction(Function):
 
     @staticmethod
     def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None, nrows=None,
-                launch_rows=0):
+                launch_rows=0, value_sink=None):
         ctx.modes = _m().snapshot()
+        # (sink, i): the fp32 grad_value of this call is DEPOSITED in sink[i] and a zero-stride placeholder of the value's
+        # own (bf16) dtype goes back through autograd — the producer of a bf16-stored value (train_ops.grouped_linear)
+        # reads the sink, so the gradient is neither rounded to bf16 nor copied on its way there
+        ctx.value_sink = value_sink
         # bf16 storage: ONE rounded copy of the value serves the forward kernel and, saved, the backward kernels
         vs = value.detach().to(_m().value_storage).contiguous()
         dyn = {} if nrows is None else dict(nrows=nrows, launch_rows=launch_rows)
@@ -369,10 +373,19 @@ class _FusedSampleFunction(Function):
                     proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
                     _ptr(row_src) if row_src is not None else None, _ptr(shapes), ctypes.byref(desc), _ptr(loc),
                     _ptr(attn), _ptr(rbk), st), "fused backward: expand")
-            g = grad_out.float()
-            if K > 1:       # out = mean over the queue entries; rows are queue-major
-                g = (g * (1.0 / K)).repeat(K, 1)
-            g = g.to(ctx.store).contiguous()
+            if bf and grad_out.dtype == torch.float32 and grad_out.is_contiguous() and grad_out.dim() == 2 \
+                    and grad_out.shape[0] == R and grad_out.shape[1] % 8 == 0 and grad_out.data_ptr() % 16 == 0:
+                # bf16 storage: scale by 1 / K and round in one pass per queue entry, over the rows that exist only
+                g = torch.empty((RK, grad_out.shape[1]), dtype=torch.bfloat16, device=dev)
+                for k in range(K):
+                    _lib.check(lib.bevmsda_cast_rows_bf16(
+                        _ptr(grad_out), nrows.data_ptr() if nrows is not None else None, R, grad_out.shape[1], 1.0 / K,
+                        g.data_ptr() + k * R * grad_out.shape[1] * 2, st), "fused backward: cast rows")
+            else:
+                g = grad_out.float()
+                if K > 1:       # out = mean over the queue entries; rows are queue-major
+                    g = (g * (1.0 / K)).repeat(K, 1)
+                g = g.to(ctx.store).contiguous()
             gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
             gl = torch.empty_like(loc)
             ga = torch.empty_like(attn)
@@ -413,11 +426,17 @@ class _FusedSampleFunction(Function):
                 _lib.check(lib.bevmsda_frontend_chain_f32(
                     _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")
-        return gv.to(ctx.value_dtype), gproj, None, None, None, None, None, None, None, None, None, None, None
+        if ctx.value_sink is not None:
+            sink, slot = ctx.value_sink
+            sink[slot] = gv
+            gv_out = torch.zeros((), dtype=ctx.value_dtype, device=dev).expand(value.shape)
+        else:
+            gv_out = gv.to(ctx.value_dtype)
+        return gv_out, gproj, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
-                        q_rows=None, tag="msda_fwd", nrows=None, launch_rows=0, **meta):
+                        q_rows=None, tag="msda_fwd", nrows=None, launch_rows=0, value_sink=None, **meta):
     """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (D = 32; fp32 or bf16 value storage — with bf16
     the forward's rounded copy of ``value`` is what the backward kernels read; the caller checks
     ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
@@ -428,7 +447,7 @@ def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, r
         _req(q_rows.dtype == torch.int32 and q_rows.dim() == 2 and q_rows.is_contiguous() and q_rows.device == proj.device,
              "bevmsda: q_rows must be a contiguous int32 (slots, J) device tensor")
     return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
-                                      meta, tag, q_rows, nrows, launch_rows)
+                                      meta, tag, q_rows, nrows, launch_rows, value_sink)
 
 
 def fold_extra_rows(rows, q_rows_all, n_extra):

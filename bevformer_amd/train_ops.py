@@ -190,11 +190,12 @@ class _GroupedLinearFunction(Function):
     (``ops.linear(groups=L)``); x = the row-wise concatenation of ``xs``."""
 
     @staticmethod
-    def forward(ctx, wcat, bcat, L, tag, segments, *xs):
+    def forward(ctx, wcat, bcat, L, tag, segments, out_dtype, sink, *xs):
         ctx.modes = _m().snapshot()
         x = xs[0] if len(xs) == 1 else torch.cat([t.reshape(-1, t.shape[-1]) for t in xs], 0)
         y = ops.linear(x.detach(), wcat.detach(), bcat.detach(), groups=L, tag=tag, _inside_autograd=True,
-                       segments=segments)
+                       segments=segments, out_dtype=out_dtype or torch.float32)
+        ctx.sink = sink
         if y is None:
             raise RuntimeError("bevmsda: grouped projection not covered")
         ctx.L, ctx.tag = L, tag
@@ -214,7 +215,7 @@ class _GroupedLinearFunction(Function):
         M = x2.shape[0]
         ncol = wcat.shape[0] // L
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        need_x = [ctx.needs_input_grad[5 + i] for i in range(len(ctx.x_shapes))]
+        need_x = [ctx.needs_input_grad[7 + i] for i in range(len(ctx.x_shapes))]
         dW, db = _zeros(x.device, (L * ncol, K), (L * ncol,)) if (need_w or need_b) else (None, None)
         # row ranges of x that want a gradient (e.g. only the current BEV of [history ; current])
         offs, o = [], 0
@@ -231,7 +232,10 @@ class _GroupedLinearFunction(Function):
         if lo is not None:
             wt = wcat.detach().view(L, ncol, K)
         probs = []
+        sink = ctx.sink
         for i, g in enumerate(gys):
+            if sink is not None and sink[i] is not None:
+                g, sink[i] = sink[i], None          # the consumer's fp32 gradient (its autograd return is a placeholder)
             if g is None:
                 continue
             g2 = g.reshape(M, ncol).float()
@@ -244,15 +248,17 @@ class _GroupedLinearFunction(Function):
         grads = []
         for (a, b), s, nd in zip(offs, ctx.x_shapes, need_x):
             grads.append(dx[a - lo:b - lo].view(*s) if (nd and dx is not None) else None)
-        return (dW if need_w else None, db if need_b else None, None, None, None, *grads)
+        return (dW if need_w else None, db if need_b else None, None, None, None, None, None, *grads)
 
 
-def grouped_linear(xs, wcat, bcat, L, tag, segments=None):
+def grouped_linear(xs, wcat, bcat, L, tag, segments=None, out_dtype=None, sink=None):
     """tuple of L tensors (rows, N / L): the projections of the row-wise concatenation of ``xs`` (a tensor or a list of
-    tensors with the same last dim) by the L row blocks of ``wcat`` / ``bcat``."""
+    tensors with the same last dim) by the L row blocks of ``wcat`` / ``bcat``.  ``out_dtype=torch.bfloat16``: the
+    results are rounded in the GEMM's epilogue (bf16 value storage of the sampling kernels); ``sink``: a list of L
+    slots in which the consumers deposit their fp32 gradients (``ops.msda_fused_autograd(value_sink=(sink, i))``)."""
     if torch.is_tensor(xs):
         xs = [xs]
-    return _GroupedLinearFunction.apply(wcat, bcat, L, tag, segments, *xs)
+    return _GroupedLinearFunction.apply(wcat, bcat, L, tag, segments, out_dtype, sink, *xs)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -286,6 +286,11 @@ int bevmsda_gather_mean_f32(const float *rows, const int32_t *idx, const float *
 int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const float *scale, const int32_t *row_slot,
                                 const int32_t *nrows, int64_t R, int C, float *rows, void *stream);
 
+/* out[r, :] = bf16(scale * in[r, :]) (round to nearest even) for r in [0, min(*nrows, R)) (`nrows` device-side, may be
+ * NULL = R): the incoming gradient rows of the sampling backward converted to the bf16 storage type of its kernels
+ * without touching the unused capacity of a device-side plan.  Dense (R, C) matrices, C a multiple of 8. */
+int bevmsda_cast_rows_bf16(const float *in, const int32_t *nrows, int64_t R, int C, float scale, uint16_t *out, void *stream);
+
 /* Dense projection on the matrix cores (csrc/linear_mfma.h), fp32 in / fp32 out, forward only:
  *
  *     y[m, n] = act( sum_k A[m, k] * w[n, k] + bias[n] ),   A = [ x0 (+ a0) | x1 (+ a1) ]
@@ -473,7 +478,9 @@ typedef struct bevmsda_chain_desc {
   int32_t precision;             /* as bevmsda_linear_desc */
   float eps0, eps1;
   int32_t reserved[5];           /* [0]: bevmsda_proj_ln_proj_chain_f32: row stride of proj_out in floats; [1]: workgroup
-                                    shape, 0 = default, 1 = 64-row panels (one workgroup per CU), 2 = 32-row panels (two) */
+                                    shape, 0 = default, 1 = 64-row panels (one workgroup per CU), 2 = 32-row panels (two),
+                                    3 = mixed: whole rounds of 256 x 64 rows on shape 1, the remaining rows on shape 2 (a
+                                    second launch) */
 } bevmsda_chain_desc;
 
 int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
