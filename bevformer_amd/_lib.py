@@ -140,7 +140,8 @@ SIGNATURES = {
     "bevmsda_proj_ln_proj_chain_f32": ([_c_void_p] * 10 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,
                                   _c_void_p, ctypes.c_int64, _c_void_p, _c_int, _c_void_p], _c_int),
-    "bevmsda_linear_wgrad_multi_f32": ([ctypes.POINTER(WgradProblem), _c_int, ctypes.c_int64, _c_int, _c_void_p], _c_int),
+    "bevmsda_linear_wgrad_multi_f32": ([ctypes.POINTER(WgradProblem), _c_int, ctypes.c_int64, _c_int, _c_int, _c_int, _c_void_p],
+                                       _c_int),
     "bevmsda_add_layernorm_backward2_f32": ([_c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, _c_int] + [_c_void_p] * 4,
                                             _c_int),
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),

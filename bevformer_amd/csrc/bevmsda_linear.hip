@@ -6,6 +6,7 @@
 #include "linear_panel.h"
 #include "linear_chain.h"
 #include "wgrad_mfma.h"
+#include "wgrad_tr.h"
 
 namespace {
 constexpr bool kLinearPipeDefault = false;       // linear_pipe.h (software-pipelined) as the default where it applies
@@ -182,7 +183,9 @@ int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
-int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, void *stream) {
+int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, int workgroups,
+                                   int variant, void *stream) {
+  if (variant != 0 && variant != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (nprob < 0 || nprob > bevmsda::kWgMaxProblems || M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (precision != 0 && precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (nprob == 0 || M == 0) return BEVMSDA_OK;
@@ -205,8 +208,10 @@ int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob
   if (tiles >= (1LL << 20)) return BEVMSDA_ERR_TOO_LARGE;
   a.tile0[nprob] = static_cast<int>(tiles);
   a.nprob = nprob;
-  // one round of workgroups (2 per CU) over all tiles; 1.5 rounds from 12 tiles on (the single-problem policy)
-  long long slices = tiles >= 12 ? (768 + tiles - 1) / tiles : 512 / tiles;
+  // one round of workgroups (2 per CU) over all tiles; 1.5 rounds from 12 tiles on (the single-problem policy);
+  // `workgroups` > 0: the caller's target instead (benchmark sweeps)
+  if (workgroups < 0 || workgroups > (1 << 20)) return BEVMSDA_ERR_BAD_OPTION;
+  long long slices = workgroups > 0 ? workgroups / tiles : (tiles >= 12 ? (768 + tiles - 1) / tiles : 512 / tiles);
   if (slices < 1) slices = 1;
   long long rows = (M + slices - 1) / slices;
   rows = ((rows + 31) / 32) * 32;
@@ -217,8 +222,14 @@ int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob
   if (tiles * slices8 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   const dim3 grid(static_cast<unsigned>(tiles * slices8)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<3>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<1>), grid, block, 0, st, a);
+  // variant 0: bf16 planes + transposing LDS reads (wgrad_tr.h); 1: fp32 tiles + gathered fragments (wgrad_mfma.h)
+  if (variant == 0) {
+    if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_tr_multi_kernel<3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::wgrad_tr_multi_kernel<1>), grid, block, 0, st, a);
+  } else {
+    if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::wgrad_multi_kernel<1>), grid, block, 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -19,7 +19,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant")
 
     def __init__(self):
         env = os.environ.get
@@ -42,6 +42,8 @@ class Modes:
         # autograd path of the encoder layer on the inference kernels (train_ops.py): chain kernels that save what their
         # backward needs, hoisted value projections, device-side row count through forward and backward
         self.train_chain = env("BEVMSDA_TRAIN_CHAIN", "1") == "1"
+        self.wgrad_workgroups = int(env("BEVMSDA_WGRAD_WGS", "0"))  # benchmark knob: workgroup target of the multi-problem weight gradient
+        self.wgrad_variant = int(env("BEVMSDA_WGRAD_VARIANT", "0"))  # 0: bf16 planes + transposing LDS reads; 1: gathered fragments
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 
     def snapshot(self):

@@ -169,7 +169,8 @@ def _wgrad_multi(problems, tag):
     ctx = cb(tag, flops, nbytes) if cb is not None else ops._NoTimer()
     dev = problems[0][0].device
     with torch.cuda.device(dev), ctx:
-        rc = lib.bevmsda_linear_wgrad_multi_f32(arr, len(problems), M, _prec(), torch.cuda.current_stream().cuda_stream)
+        rc = lib.bevmsda_linear_wgrad_multi_f32(arr, len(problems), M, _prec(), _m().wgrad_workgroups, _m().wgrad_variant,
+                                                torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "linear_wgrad_multi")
 
 

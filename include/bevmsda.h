@@ -537,7 +537,10 @@ typedef struct bevmsda_wgrad_problem {
   int64_t ldgw;
   float *grad_b;        /* (N) or NULL */
 } bevmsda_wgrad_problem;
-int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, void *stream);
+int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, int workgroups,
+                                   int variant, void *stream);
+/* workgroups: 0 = the library's choice (benchmark sweeps: a target count); variant: 0 = operands split once to bf16 planes
+ * in LDS, fragments by the transposing LDS read (csrc/wgrad_tr.h), 1 = the first kernel's gathered fragments. */
 
 /* The encoder's caller, PerceptionTransformer.get_bev_features (modules/transformer.py:104-200).
  *

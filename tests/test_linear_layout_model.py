@@ -372,3 +372,80 @@ def test_chain_kernel_plane_writes_feed_the_next_stage():
                 for r in range(16):
                     got[i * 32 + (lane & 31), 32 * wave + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3)] = acc[i, lane, r]
     np.testing.assert_allclose(got, x @ w.T, rtol=1e-11, atol=1e-11)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# csrc/wgrad_tr.h: bf16 planes + ds_read_b64_tr_b16 fragments of the weight-gradient kernel (round 4)
+
+def _tr_read(addr_of_lane, lds_u16):
+    """gfx950 ``ds_read_b64_tr_b16`` as measured by tools/probes/tr_read_probe.hip (profiles/r4/r4h_*_probe.txt): in
+    every 16-lane group, lane i receives as element j the element (i & 3) of the 8-byte piece addressed by lane
+    (i >> 2) + 4 j of the same group."""
+    out = []
+    for lane in range(64):
+        base = lane & ~15
+        i = lane & 15
+        vals = []
+        for j in range(4):
+            a = addr_of_lane[base + (i >> 2) + 4 * j]
+            assert a % 8 == 0
+            vals.append(lds_u16[a // 2 + (i & 3)])
+        out.append(vals)
+    return out
+
+
+def test_transposing_read_model_reproduces_the_hardware_probe():
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r4",
+                        "r4h_ds_read_b64_tr_b16_probe.txt")
+    text = open(path).read()
+    lds = list(range(8192))
+    patterns = {0: lambda l: l * 8,
+                1: lambda l: (l & 3) * 8 + ((l >> 2) & 3) * 64 + (l >> 4) * 256,
+                2: lambda l: (l & 15) * 64 + (l >> 4) * 8,
+                3: lambda l: 0}
+    for p, fn in patterns.items():
+        block = text.split(f"pattern {p}\n")[1].split("pattern ")[0]
+        got = {int(m.group(1)): [int(v) for v in m.group(2).split()]
+               for m in re.finditer(r"lane\s+(\d+):((?:\s+\d+){4})", block)}
+        assert len(got) == 64
+        want = _tr_read([fn(l) for l in range(64)], lds)
+        for lane in range(64):
+            assert got[lane] == want[lane], (p, lane, got[lane], want[lane])
+
+
+def test_weight_gradient_planes_and_transposed_fragments():
+    """Replay of wgrad_tr.h's address arithmetic: the split-and-store pass writes element (row m, column n) of a chunk
+    tile at plane byte m * 320 + 2 n; lane L of a wavefront (wn / wk, column tile t, k-step ks) must receive rows
+    16 ks + 8 (L >> 5) + 0..7 of column 64 w + 32 t + (L & 31) — the MFMA operand layout — and the 32 pieces a half-wave
+    addresses in one transposing read must lie on 32 distinct bank pairs (row stride 80 banks = 16 mod 64)."""
+    ROWB, STRIDE = 320, 160
+    plane = [0] * (32 * STRIDE)
+    for m in range(32):                      # writer: thread (prow0 = tid >> 5, c4 = 4 (tid & 31)) rows prow0 + 8 i
+        for n in range(128):
+            plane[(m * ROWB + 2 * n) // 2] = m * 1000 + n
+    for w in range(2):
+        for t in range(2):
+            for ks in range(2):
+                for second in range(2):
+                    addr = []
+                    for lane in range(64):
+                        s, g0, g1 = lane & 15, (lane >> 4) & 1, lane >> 5
+                        frow, fcolb = 8 * g1 + (s >> 2), (16 * g0 + 4 * (s & 3)) * 2
+                        addr.append(frow * ROWB + (w * 64 + t * 32) * 2 + fcolb + ks * 16 * ROWB + second * 4 * ROWB)
+                    got = _tr_read(addr, plane)
+                    for lane in range(64):
+                        for j in range(4):
+                            m = 16 * ks + 8 * (lane >> 5) + 4 * second + j
+                            n = 64 * w + 32 * t + (lane & 31)
+                            assert got[lane][j] == m * 1000 + n, (w, t, ks, second, lane, j)
+                    for half in range(2):        # 32 lanes x 8 bytes: 32 distinct pairs of 4-byte banks (64 banks)
+                        banks = [(addr[half * 32 + l] // 4) % 64 for l in range(32)]
+                        assert len(set(banks)) == 32 and all(b % 2 == 0 for b in banks), (w, t, ks, second, half)
+    # writer: a wavefront's 64 threads store 8 bytes each: lanes 0..31 one row (256 contiguous bytes), lanes 32..63 the next
+    for wave in range(4):
+        for half in range(2):
+            tids = [wave * 64 + half * 32 + l for l in range(32)]
+            a = [((t_ >> 5) * ROWB + (t_ & 31) * 8) for t_ in tids]
+            assert len({(x // 4) % 64 for x in a}) == 32

@@ -255,3 +255,35 @@ def test_training_step_replays_from_a_hip_graph():
     for k in want:
         e2, _ = _rel(got[k], want[k])
         assert e2 < 1e-3, f"grad {k}: graph replay vs eager relative L2 {e2:.2e}"     # (atomics: summation order)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_multi_problem_weight_gradient_matches_float64(variant, mode):
+    """``bevmsda_linear_wgrad_multi_f32``: three problems over the same rows in one launch (a ragged row count, N = 192
+    with a partial tile, row views with a stride, one problem without bias) against float64; variant 0 = bf16 planes +
+    transposing LDS reads (csrc/wgrad_tr.h), 1 = the first kernel's gathered fragments."""
+    g = torch.Generator().manual_seed(17 + variant)
+    M = 4999
+    G1, X1 = torch.randn(M, 256, generator=g), torch.randn(M, 512, generator=g)
+    G2, X2 = torch.randn(M, 192, generator=g), torch.randn(M, 256, generator=g)
+    big = torch.randn(M, 768, generator=g)
+    G3, X3 = big[:, 256:512], torch.randn(M, 256, generator=g)            # a column block of a wider matrix (ld = 768)
+    probs_cpu = [(G1, X1, True), (G2, X2, True), (G3, X3, False)]
+    dev_probs, outs = [], []
+    bigd = big.to(DEV)
+    for i, (G, X, bias) in enumerate(probs_cpu):
+        Gd = bigd[:, 256:512] if i == 2 else G.to(DEV)
+        gw = torch.zeros(G.shape[1], X.shape[1], device=DEV)
+        gb = torch.zeros(G.shape[1], device=DEV) if bias else None
+        dev_probs.append((Gd, X.to(DEV), gw, gb))
+        outs.append((gw, gb))
+    with ops.using(gemm=mode, wgrad_variant=variant):
+        train_ops._wgrad_multi(dev_probs, "test_dw")
+    torch.cuda.synchronize()
+    tol = (2e-5, 1e-4) if mode == "split" else (6e-3, 3e-2)
+    for (G, X, bias), (gw, gb) in zip(probs_cpu, outs):
+        want = G.double().t() @ X.double()
+        _check(gw, want, "grad_w", *tol)
+        if bias:
+            _check(gb, G.double().sum(0), "grad_b", 1e-5, 1e-4)
