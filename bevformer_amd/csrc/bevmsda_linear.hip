@@ -23,7 +23,7 @@ extern "C" {
 static int linear_launch(const float *x0, const float *a0, const float *x1, const float *a1, const float *w,
                          const uint16_t *wpack, const float *bias, const bevmsda_linear_desc *d, float *y,
                          void *stream, const int32_t *gidx = nullptr, const float *gscale = nullptr,
-                         const float *mask = nullptr, long ldmask = 0) {
+                         const float *mask = nullptr, long ldmask = 0, float mask_scale = 1.0f) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -54,7 +54,7 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   // desc->reserved[0] = 1: y += result (first kernel, float4 epilogue: fp32 y, N and ldy multiples of 4, aligned y / bias)
   a.accum = d->reserved[0] == 1 ? 1 : 0;
   if (d->reserved[0] != 0 && d->reserved[0] != 1) return BEVMSDA_ERR_BAD_OPTION;
-  a.mask = mask; a.ldmask = ldmask;
+  a.mask = mask; a.ldmask = ldmask; a.mask_scale = mask_scale;
   if (mask && (gcols != 0 || d->out_bf16 || d->N % 4 != 0 || d->ldy % 4 != 0 || ldmask % 4 != 0 || ldmask < d->N ||
                misaligned(y) || misaligned(mask) || (bias && misaligned(bias)) || d->variant == 131))
     return BEVMSDA_ERR_UNSUPPORTED;
@@ -133,11 +133,11 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
 }
 
 int bevmsda_linear_relu_backward_packed_f32(const float *g, const uint16_t *wpack, const float *act, int64_t ld_act,
-                                            const bevmsda_linear_desc *d, float *y, void *stream) {
+                                            float scale, const bevmsda_linear_desc *d, float *y, void *stream) {
   if (!wpack || !act) return BEVMSDA_ERR_NULL_POINTER;
   if (d && (d->K1 != 0 || d->relu)) return BEVMSDA_ERR_BAD_SHAPE;
   return linear_launch(g, nullptr, nullptr, nullptr, nullptr, wpack, nullptr, d, y, stream, nullptr, nullptr, act,
-                       static_cast<long>(ld_act));
+                       static_cast<long>(ld_act), scale);
 }
 
 int bevmsda_linear_gather_packed_f32(const float *rows, int64_t ld_rows, const int32_t *idx, const float *scale,
@@ -368,8 +368,12 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
                             const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                             const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
                             const bevmsda_chain_desc *d, float *y, void *stream, bool save, float *sv_z0, float *sv_x,
-                            float *sv_h, float *sv_z1) {
+                            float *sv_h, float *sv_z1, const float *dk0 = nullptr, const float *dkh = nullptr,
+                            const float *dk1 = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  const bool drop = dk0 || dkh || dk1;
+  if (drop && !save) return BEVMSDA_ERR_BAD_OPTION;
+  if ((dk0 && misaligned(dk0)) || (dkh && misaligned(dkh)) || (dk1 && misaligned(dk1))) return BEVMSDA_ERR_MISALIGNED;
   if (save && d->M > 0 && (!sv_z0 || !sv_x || !sv_h || !sv_z1)) return BEVMSDA_ERR_NULL_POINTER;
   if (save && (misaligned(sv_z0) || misaligned(sv_x) || misaligned(sv_h) || misaligned(sv_z1))) return BEVMSDA_ERR_MISALIGNED;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
@@ -402,19 +406,20 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
       bevmsda_chain_desc one = *d;
       one.reserved[1] = (head == 0) ? 2 : 1;
       return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &one, y, stream,
-                              save, sv_z0, sv_x, sv_h, sv_z1);
+                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1);
     }
     bevmsda_chain_desc dh = *d, dt = *d;
     dh.M = head; dh.reserved[1] = 1;
     dt.M = tail; dt.reserved[1] = 2;
     int rc = ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dh, y, stream,
-                              save, sv_z0, sv_x, sv_h, sv_z1);
+                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1);
     if (rc != BEVMSDA_OK) return rc;
     const long long o = head;
     return ffn_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p, b0,
                             res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dt,
                             y + o * d->ld_y, stream, save, save ? sv_z0 + o * 256 : nullptr, save ? sv_x + o * 256 : nullptr,
-                            save ? sv_h + o * 512 : nullptr, save ? sv_z1 + o * 256 : nullptr);
+                            save ? sv_h + o * 512 : nullptr, save ? sv_z1 + o * 256 : nullptr, dk0 ? dk0 + o * 256 : nullptr,
+                            dkh ? dkh + o * 512 : nullptr, dk1 ? dk1 + o * 256 : nullptr);
   }
   const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
@@ -425,19 +430,23 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = gamma1; a.beta1 = beta1;
   a.eps0 = d->eps0; a.eps1 = d->eps1; a.y = y; a.ld_y = d->ld_y; a.M = d->M;
   a.sv_z0 = sv_z0; a.sv_x = sv_x; a.sv_h = sv_h; a.sv_z1 = sv_z1;
+  a.dk0 = dk0; a.dkh = dkh; a.dk1 = dk1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
-#define BEVMSDA_CHAIN(NP_, PRE_, SV_)                                                                                        \
-  do {                                                                                                                       \
-    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8, SV_>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4, SV_>), grid, dim3(256), 0, st, a);            \
+#define BEVMSDA_CHAIN(NP_, PRE_, SV_, DR_)                                                                                        \
+  do {                                                                                                                            \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8, SV_, DR_>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4, SV_, DR_>), grid, dim3(256), 0, st, a);            \
   } while (0)
-  if (save) {
-    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, true); else BEVMSDA_CHAIN(3, 0, true); }
-    else { if (idx) BEVMSDA_CHAIN(1, 2, true); else BEVMSDA_CHAIN(1, 0, true); }
+  if (drop) {                                  // (train() mode with active dropout: the gather form only)
+    if (!idx) return BEVMSDA_ERR_UNSUPPORTED;
+    if (d->precision == 0) BEVMSDA_CHAIN(3, 2, true, true); else BEVMSDA_CHAIN(1, 2, true, true);
+  } else if (save) {
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, true, false); else BEVMSDA_CHAIN(3, 0, true, false); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, true, false); else BEVMSDA_CHAIN(1, 0, true, false); }
   } else {
-    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false); else BEVMSDA_CHAIN(3, 0, false); }
-    else { if (idx) BEVMSDA_CHAIN(1, 2, false); else BEVMSDA_CHAIN(1, 0, false); }
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false, false); else BEVMSDA_CHAIN(3, 0, false, false); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, false, false); else BEVMSDA_CHAIN(1, 0, false, false); }
   }
 #undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
@@ -455,16 +464,18 @@ int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, cons
                                      const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p,
                                      const float *b1, const uint16_t *w2p, const float *b2, const float *gamma1,
                                      const float *beta1, const bevmsda_chain_desc *d, float *y, float *save_z0, float *save_x,
-                                     float *save_h, float *save_z1, void *stream) {
+                                     float *save_h, float *save_z1, const float *drop0, const float *droph,
+                                     const float *drop1, void *stream) {
   return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, true,
-                          save_z0, save_x, save_h, save_z1);
+                          save_z0, save_x, save_h, save_z1, drop0, droph, drop1);
 }
 
 static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                                 const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                 const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream, bool save,
-                                float *sv_z0) {
+                                float *sv_z0, const float *dk0 = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (dk0 && (!save || misaligned(dk0))) return BEVMSDA_ERR_BAD_OPTION;
   if (save && d->M > 0 && !sv_z0) return BEVMSDA_ERR_NULL_POINTER;
   if (save && misaligned(sv_z0)) return BEVMSDA_ERR_MISALIGNED;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
@@ -490,16 +501,19 @@ static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const flo
     bevmsda_chain_desc dh = *d, dt = *d;
     if (head == 0 || tail == 0 || tail > 256LL * 2 * 32) {
       dh.reserved[1] = (head == 0) ? 2 : 1;
-      return ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0);
+      return ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0,
+                                  dk0);
     }
     dh.M = head; dh.reserved[1] = 1;
     dt.M = tail; dt.reserved[1] = 2;
-    int rc = ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0);
+    int rc = ln_proj_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, &dh, x_out, proj_out, stream, save, sv_z0,
+                                  dk0);
     if (rc != BEVMSDA_OK) return rc;
     const long long o = head;
     return ln_proj_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p,
                                 b0, res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, &dt, x_out + o * d->ld_y,
-                                proj_out + o * ld_y2, stream, save, save ? sv_z0 + o * 256 : nullptr);
+                                proj_out + o * ld_y2, stream, save, save ? sv_z0 + o * 256 : nullptr,
+                                dk0 ? dk0 + o * 256 : nullptr);
   }
   const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
@@ -510,19 +524,21 @@ static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const flo
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = a.beta1 = nullptr;
   a.eps0 = d->eps0; a.eps1 = 0.f; a.y = x_out; a.ld_y = d->ld_y; a.M = d->M; a.y2 = proj_out; a.ld_y2 = ld_y2; a.N2 = d->F;
   a.sv_z0 = sv_z0;
+  a.dk0 = dk0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
-#define BEVMSDA_CHAIN(NP_, PRE_, SV_)                                                                                        \
-  do {                                                                                                                       \
-    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8, SV_>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4, SV_>), grid, dim3(256), 0, st, a);            \
+#define BEVMSDA_CHAIN(NP_, PRE_, SV_, DR_)                                                                                        \
+  do {                                                                                                                            \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 2, 1, 8, SV_, DR_>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 1, 1, 2, 4, SV_, DR_>), grid, dim3(256), 0, st, a);            \
   } while (0)
   if (save) {                                  // (the autograd path's forward has no gather prepass: plain rows only)
     if (idx) return BEVMSDA_ERR_UNSUPPORTED;
-    if (d->precision == 0) BEVMSDA_CHAIN(3, 0, true); else BEVMSDA_CHAIN(1, 0, true);
+    if (dk0) { if (d->precision == 0) BEVMSDA_CHAIN(3, 0, true, true); else BEVMSDA_CHAIN(1, 0, true, true); }
+    else { if (d->precision == 0) BEVMSDA_CHAIN(3, 0, true, false); else BEVMSDA_CHAIN(1, 0, true, false); }
   } else {
-    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false); else BEVMSDA_CHAIN(3, 0, false); }
-    else { if (idx) BEVMSDA_CHAIN(1, 2, false); else BEVMSDA_CHAIN(1, 0, false); }
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN(3, 2, false, false); else BEVMSDA_CHAIN(3, 0, false, false); }
+    else { if (idx) BEVMSDA_CHAIN(1, 2, false, false); else BEVMSDA_CHAIN(1, 0, false, false); }
   }
 #undef BEVMSDA_CHAIN
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
@@ -537,9 +553,9 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
 int bevmsda_proj_ln_proj_chain_train_f32(const float *rows, const uint16_t *w0p, const float *b0, const float *res,
                                          const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                          const bevmsda_chain_desc *d, float *x_out, float *proj_out, float *save_z0,
-                                         void *stream) {
+                                         const float *drop0, void *stream) {
   return ln_proj_chain_launch(rows, nullptr, nullptr, w0p, b0, res, gamma0, beta0, w1p, b1, d, x_out, proj_out, stream, true,
-                              save_z0);
+                              save_z0, drop0);
 }
 
 }  // extern "C"

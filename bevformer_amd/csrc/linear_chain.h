@@ -59,6 +59,12 @@ struct ChainArgs {
   float *sv_x;                      // MODE 0: x = LayerNorm0(...) (MODE 1 stores it as `y` anyway)
   float *sv_h;                      // MODE 0: relu(x W1^T + b1), (M, 512)
   float *sv_z1;                     // MODE 0: x + h W2^T + b2, the input of LayerNorm1
+  // DROP = true (train() mode with active dropout): per-element scale tensors, 0 or 1 / (1 - p), dense like the saves;
+  // nullptr = that dropout is inactive.  The reference's nn.Dropout sites of the chain:
+  const float *dk0;                 // (M, 256): on A W0^T + b0, before "+ res" (spatial_cross_attention.py:175 /
+                                    //           temporal_self_attention.py:272)
+  const float *dkh;                 // MODE 0, (M, 512): on relu(x W1^T + b1) (mmcv FFN: Linear, ReLU, Dropout)
+  const float *dk1;                 // MODE 0, (M, 256): on h W2^T + b2, before "+ x"
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -87,7 +93,7 @@ constexpr int kChainMaxN2 = 768;   // MODE 1: columns of the second projection (
 //              phases (58 % of a workgroup's cycles in the first shape: tools/gemm_diag/chain_run.py) run under the
 //              other's MFMAs, and 1,250 half-size workgroups quantise better over 256 CUs than 625 — at twice the
 //              weight traffic from L2 per row.
-template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8, bool SAVE = false>
+template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8, bool SAVE = false, bool DROP = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -347,6 +353,21 @@ linear_chain_kernel(const ChainArgs a) {
     }
   };
 
+  // c *= mask[row, col0 + my columns] (a dropout scale tensor; rows past M read row M - 1 and are never stored)
+  auto scale_tile = [&](auto &c, const float *mask, long ld, int col0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float *mrowp = mask + (mrow[i] < a.M ? mrow[i] : a.M - 1) * ld + col0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 mk = *reinterpret_cast<const float4 *>(mrowp + j * 32 + 4 * (lane >> 5) + 8 * g);
+          c[i][j][4 * g] *= mk.x; c[i][j][4 * g + 1] *= mk.y; c[i][j][4 * g + 2] *= mk.z; c[i][j][4 * g + 3] *= mk.w;
+        }
+    }
+  };
+
   // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
   {
     const int d_rl = lane >> 3, d_cc = lane & 7;
@@ -408,6 +429,7 @@ linear_chain_kernel(const ChainArgs a) {
   CHAIN_STAMP(1);                              // GEMM 0
   wprefetch(r1, wave, 16, 0);
   add_cols(acc, c_b0, 0);
+  if constexpr (DROP) { if (a.dk0) scale_tile(acc, a.dk0, kChainC, NT * wave * 32); }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -458,6 +480,7 @@ linear_chain_kernel(const ChainArgs a) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] < 0.f ? 0.f : acc[i][j][r];     // NaN stays NaN, as torch.relu
+      if constexpr (DROP) { if (a.dkh) scale_tile(acc, a.dkh, kChainF, half * 256 + NT * wave * 32); }
       if constexpr (SAVE) store_tile(acc, a.sv_h, kChainF, half * 256 + NT * wave * 32);
       to_planes(acc, buf0);
       __syncthreads();                         // this half of the hidden layer is complete
@@ -470,6 +493,7 @@ linear_chain_kernel(const ChainArgs a) {
 
     // ---------------------------------------------------------------- y = LN1(x + ffn(x))
     add_cols(acc2, c_b2, 0);
+    if constexpr (DROP) { if (a.dk1) scale_tile(acc2, a.dk1, kChainC, NT * wave * 32); }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll

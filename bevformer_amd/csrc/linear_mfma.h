@@ -63,6 +63,7 @@ struct LinArgs {
   int accum;                       // 1: y += result (fp32 y, float4 epilogue): gradients of a tensor with several consumers
   const float *mask;               // (M, ldmask) or nullptr: y = mask > 0 ? result : 0 (float4 epilogue) — the backward of a
   long ldmask;                     //   ReLU folded into the input-gradient GEMM of the Linear behind it (mask = the ReLU's output)
+  float mask_scale;                // ... times this (1 / (1 - p) when a dropout sat between the ReLU and the Linear)
   int nblk_m, nblk_n;
 #ifdef BEVMSDA_LIN_DIAG
   int diag;                        // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 A loads of chunk 0 only,
@@ -466,10 +467,10 @@ linear_splitbf16_kernel(const LinArgs a) {
               }
               if (a.mask) {                   // ReLU backward: pass where the forward's activation was positive
                 const float4 mk = *reinterpret_cast<const float4 *>(a.mask + m * a.ldmask + n);
-                v.x = mk.x > 0.f ? v.x : 0.f;
-                v.y = mk.y > 0.f ? v.y : 0.f;
-                v.z = mk.z > 0.f ? v.z : 0.f;
-                v.w = mk.w > 0.f ? v.w : 0.f;
+                v.x = mk.x > 0.f ? v.x * a.mask_scale : 0.f;
+                v.y = mk.y > 0.f ? v.y * a.mask_scale : 0.f;
+                v.z = mk.z > 0.f ? v.z * a.mask_scale : 0.f;
+                v.w = mk.w > 0.f ? v.w * a.mask_scale : 0.f;
               }
               if (a.out_bf16) {             // same element offsets, 2-byte elements
                 uint2 pk;

@@ -366,7 +366,8 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
     def chain_trainable(self):
         """The autograd path of this layer can run on the row-chain kernels (train_ops.py): the reference's operation
         order (post-norm), TemporalSelfAttention / SpatialCrossAttention over 256 channels, the 256 -> 512 -> 256 FFN,
-        LayerNorms — and no active dropout (eval mode, or every p = 0): the chain kernels have no dropout stage."""
+        LayerNorms.  Active dropout (train() mode, p > 0 in the attentions / the FFN) is covered: the seam Functions draw
+        the scale tensors of the reference's nn.Dropout sites and the chain kernels apply them."""
         from .spatial_cross_attention import MSDeformableAttention3D, SpatialCrossAttention
         from .temporal_self_attention import TemporalSelfAttention
         if tuple(self.operation_order) != ("self_attn", "norm", "cross_attn", "norm", "ffn", "norm") or self.pre_norm:
@@ -381,10 +382,11 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         if t.embed_dims != 256 or s_.embed_dims != 256 or not t.batch_first or ffn.num_fcs != 2 or not ffn.add_identity \
                 or ffn.feedforward_channels != 512 or not all(isinstance(n, torch.nn.LayerNorm) for n in self.norms):
             return False
-        if self.training:
-            drops = [t.dropout, s_.dropout] + [m for m in ffn.modules() if isinstance(m, torch.nn.Dropout)]
-            if any(getattr(d, "p", 0.0) > 0 for d in drops):
-                return False
+        # the FFN as mmcv builds it: [Linear, ReLU, Dropout], Linear, Dropout (+ an identity dropout_layer)
+        lay = list(ffn.layers)
+        if len(lay) != 3 or not isinstance(lay[0][2], torch.nn.Dropout) or not isinstance(lay[2], torch.nn.Dropout) \
+                or getattr(ffn.dropout_layer, "p", 0.0) > 0:
+            return False
         return True
 
     def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
@@ -441,7 +443,7 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 return None
             fc1, fc2 = ffn.layers[0][0], ffn.layers[-2]
 
-            def run_s(rows, w, b, res, post_norm, gather, plan=None):
+            def run_s(rows, w, b, res, post_norm, gather, plan=None, drop_p=0.0):
                 if post_norm is not n0:
                     return None
                 if torch.is_grad_enabled():         # the same kernel as an autograd Function (train_ops.py)
@@ -451,8 +453,13 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     dyn = plan.dynamic
                     fold = (plan.q_rows_all, plan.n_extra_dev) if (dyn and plan.q_rows_all is not None
                                                                    and plan.q_rows_all.shape[1] > 2) else None
+                    lay = list(ffn.layers)
+                    ph, po = (lay[0][2].p, lay[2].p) if ffn.training else (0.0, 0.0)
                     return train_ops.seam_s(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, row_slot=plan.row_query32,
-                                            nrows=plan.nrows_dev if dyn else None, fold=fold, tag="sca_out_ffn_chain")
+                                            nrows=plan.nrows_dev if dyn else None, fold=fold, tag="sca_out_ffn_chain",
+                                            drop_p=(drop_p, ph, po))
+                if drop_p > 0:
+                    return None
                 return ops.proj_ffn_chain(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain")
             return run_s
 
@@ -467,13 +474,15 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             if da is None or not hasattr(da, "sampling_offsets") or not isinstance(n0, torch.nn.LayerNorm):
                 return None
 
-            def run(rows, w, b, res, post_norm):
+            def run(rows, w, b, res, post_norm, drop_p=0.0):
                 if post_norm is not n0:
                     return None
                 wm, bm = ops.merged_linear_params(da, da.sampling_offsets, da.attention_weights)
                 if torch.is_grad_enabled():         # the same kernel as an autograd Function (train_ops.py)
                     from .. import train_ops
-                    return train_ops.seam_t(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain")
+                    return train_ops.seam_t(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain", drop_p=drop_p)
+                if drop_p > 0:
+                    return None
                 return ops.proj_ln_proj_chain(rows, w, b, res, n0, wm, bm, tag="tsa_out_sca_proj_chain")
             return run
 

@@ -294,7 +294,7 @@ class SpatialCrossAttention(BaseModule):
         if slots is None and chain is not None and post_norm is not None and torch.is_grad_enabled() \
                 and frame_plan is not None and frame_plan.q_rows is not None and frame_plan.q_rows.shape[1] == 2 \
                 and frame_plan.row_query32 is not None and query_pos is None and bs * Q == frame_plan.q_rows.shape[0] \
-                and not (self.training and self.dropout.p > 0) and ops.fused_training_wanted(query, projected_value) \
+                and ops.fused_training_wanted(query, projected_value) \
                 and not getattr(projected_value, "_bevmsda_partial", False):
             # autograd fast path (train_ops.py): fused sampling (every query projected once; the projection rows may come
             # out of the previous seam's kernel) -> the whole row-local tail of the layer in one kernel that saves
@@ -321,7 +321,8 @@ class SpatialCrossAttention(BaseModule):
                     launch_rows=frame_plan.launch_rows if dyn else 0,
                     value_sink=sink if projected_value.dtype == torch.bfloat16 else None)
                 done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
-                             (frame_plan.q_rows, inv_count), frame_plan)
+                             (frame_plan.q_rows, inv_count), frame_plan,
+                             drop_p=self.dropout.p if self.training else 0.0)
                 if done is not None:
                     return ops.Chained(done.view(bs, Q, C))
                 # (declined: the per-op statements below redo the sampling — correct, slower)

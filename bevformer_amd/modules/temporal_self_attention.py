@@ -238,9 +238,11 @@ class TemporalSelfAttention(BaseModule):
         if out is None:
             out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,
                                        level_start_index, shared_value, bs, Q, C)
-        if post_norm is not None and chain is not None and self.batch_first and not (self.training and self.dropout.p > 0):
-            # ... and the next attention's projection of the normed rows behind them, in the same kernel
-            done = chain(out, self.output_proj.weight, self.output_proj.bias, identity, post_norm)
+        drop_p = self.dropout.p if self.training else 0.0
+        if post_norm is not None and chain is not None and self.batch_first and (drop_p == 0 or torch.is_grad_enabled()):
+            # ... and the next attention's projection of the normed rows behind them, in the same kernel (under autograd
+            # with the dropout of train() mode applied inside it)
+            done = chain(out, self.output_proj.weight, self.output_proj.bias, identity, post_norm, drop_p=drop_p)
             if done is not None:
                 return ops.NormedWithProj(done[0], done[1])
         if post_norm is not None and self.batch_first and not (self.training and self.dropout.p > 0):

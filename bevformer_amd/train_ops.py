@@ -103,9 +103,10 @@ def _dgrad(g2, weight, tag, acc=None):
     return y
 
 
-def _dgrad_relu(g2, weight, act, tag):
-    """``(g2 @ weight) * (act > 0)``: the input gradient of the Linear behind a ReLU with the ReLU's backward in the
-    GEMM's epilogue (``bevmsda_linear_relu_backward_packed_f32``); ``act`` = the ReLU's output."""
+def _dgrad_relu(g2, weight, act, tag, scale=1.0):
+    """``scale * (g2 @ weight) * (act > 0)``: the input gradient of the Linear behind a ReLU (and, with ``scale`` =
+    1 / (1 - p), behind the Dropout that followed it: ``act`` is then the activation after that dropout) with the
+    backward of both in the GEMM's epilogue (``bevmsda_linear_relu_backward_packed_f32``)."""
     wt = ops.transposed_weight(weight)                      # (in_features, out_features)
     blob = ops.packed_weight(wt) if _m().gemm_pack else None
     M, K = g2.shape
@@ -119,12 +120,14 @@ def _dgrad_relu(g2, weight, act, tag):
         cb = ops._GEMM_TIMER["cb"]
         ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * K + N * K + 2 * M * N)) if cb is not None else ops._NoTimer()
         with torch.cuda.device(g2.device), ctx:
-            rc = lib.bevmsda_linear_relu_backward_packed_f32(_ptr(g2c), _ptr(blob), _ptr(act), N, ctypes.byref(desc), _ptr(y),
+            rc = lib.bevmsda_linear_relu_backward_packed_f32(_ptr(g2c), _ptr(blob), _ptr(act), N, float(scale),
+                                                             ctypes.byref(desc), _ptr(y),
                                                              torch.cuda.current_stream().cuda_stream)
         if rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
             _lib.check(rc, "linear_relu_backward")
             return y
-    return torch.ops.aten.threshold_backward(_dgrad(g2, weight, tag), act, 0.0)
+    out = torch.ops.aten.threshold_backward(_dgrad(g2, weight, tag), act, 0.0)
+    return out if scale == 1.0 else out * scale
 
 
 def _wgrad_into(g2, x2, gw, gb, tag):
@@ -317,11 +320,13 @@ class _SeamTFunction(Function):
     """x = LayerNorm0(rows w0^T + b0 + res), p = x w1^T + b1 — ``bevmsda_proj_ln_proj_chain_train_f32``."""
 
     @staticmethod
-    def forward(ctx, rows, w0, b0, res, gamma0, beta0, w1, b1, eps0, tag):
+    def forward(ctx, rows, w0, b0, res, gamma0, beta0, w1, b1, eps0, tag, drop0=None):
         ctx.modes = _m().snapshot()
         m = _m()
         rows2, ldx = ops._rows2d(rows.detach(), 256)
         M = rows2.shape[0]
+        if drop0 is not None:
+            drop0 = drop0.detach().reshape(M, 256).float().contiguous()
         res2, ldres = ops._rows2d(res.detach(), 256)
         N2 = w1.shape[0]
         dev = rows.device
@@ -346,8 +351,10 @@ class _SeamTFunction(Function):
         with torch.cuda.device(dev), tctx:
             rc = lib.bevmsda_proj_ln_proj_chain_train_f32(
                 _ptr(rows2), _ptr(_panel_blob(w0)), p(b0), _ptr(res2), p(gamma0), p(beta0), _ptr(_panel_blob(w1)), p(b1),
-                ctypes.byref(desc), _ptr(x), _ptr(pr), _ptr(z0), torch.cuda.current_stream().cuda_stream)
+                ctypes.byref(desc), _ptr(x), _ptr(pr), _ptr(z0), _ptr(drop0) if drop0 is not None else None,
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "proj_ln_proj_chain (train)")
+        ctx.drop0 = drop0
         ctx.eps0, ctx.tag = float(eps0), tag
         ctx.has_b0, ctx.has_b1 = b0 is not None, b1 is not None
         ctx.res_shape = tuple(res.shape)
@@ -377,29 +384,38 @@ class _SeamTFunction(Function):
                 probs.append((gp2, x, dW1, db1))
             dxp = _dgrad(gp2, w1, ctx.tag + "_dx1")          # the projection's share of the gradient of x
         if gx is None and dxp is None:
-            return (None,) * 10
+            return (None,) * 11
         # the two addends of d/dx (the residual branch's gradient, the projection's) meet inside the LayerNorm backward
         ga, gb_ = (gx, dxp) if gx is not None else (dxp, None)
         dzr, dg0, dbe0 = _ln_backward(z0, gamma0, ga, ctx.eps0, out_shape=ctx.res_shape, g2=gb_)
         dz0 = dzr.view(M, 256)
+        dzp = dz0 if ctx.drop0 is None else dz0 * ctx.drop0      # through the dropout on the projection's output
         if ni[1] or ni[2]:
-            probs.append((dz0, rows2, dW0, db0))
+            probs.append((dzp, rows2, dW0, db0))
         _wgrad_multi(probs, ctx.tag + "_dw")
-        d_rows = _dgrad(dz0, w0, ctx.tag + "_dx0").view(ctx.rows_shape) if ni[0] else None
+        d_rows = _dgrad(dzp, w0, ctx.tag + "_dx0").view(ctx.rows_shape) if ni[0] else None
         d_res = dzr if ni[3] else None
         return (d_rows, dW0 if ni[1] else None, db0 if (ctx.has_b0 and ni[2]) else None, d_res, dg0 if ni[4] else None,
-                dbe0 if ni[5] else None, dW1 if ni[6] else None, db1 if (ctx.has_b1 and ni[7]) else None, None, None)
+                dbe0 if ni[5] else None, dW1 if ni[6] else None, db1 if (ctx.has_b1 and ni[7]) else None, None, None, None)
 
 
-def seam_t(rows, w0, b0, res, norm0, w1, b1, tag="tsa_out_sca_proj_chain"):
-    """(x, p) = (norm0(rows w0^T + b0 + res), x w1^T + b1) with gradients, or None when the call is not covered."""
+def dropout_scale(shape, p, device):
+    """The scale tensor (0 or 1 / (1 - p)) of one ``nn.Dropout`` call in train() mode, drawn by the framework's own
+    ``torch.nn.functional.dropout`` on ones (same generator stream, same call count as the module it stands for)."""
+    return torch.nn.functional.dropout(torch.ones(shape, dtype=torch.float32, device=device), p, True)
+
+
+def seam_t(rows, w0, b0, res, norm0, w1, b1, tag="tsa_out_sca_proj_chain", drop_p=0.0):
+    """(x, p) = (norm0(drop(rows w0^T + b0) + res), x w1^T + b1) with gradients, or None when the call is not covered.
+    ``drop_p`` > 0: the attention's ``nn.Dropout`` is active (train() mode)."""
     if not (isinstance(norm0, torch.nn.LayerNorm) and tuple(norm0.normalized_shape) == (256,) and norm0.weight is not None
             and norm0.bias is not None and tuple(w0.shape) == (256, 256) and w1.dim() == 2 and w1.shape[1] == 256
             and w1.shape[0] % 64 == 0 and w1.shape[0] <= 768 and rows.shape[-1] == 256 and res is not None
             and res.shape[-1] == 256 and res.numel() == rows.numel()
             and wanted(rows, w0, b0, res, norm0.weight, norm0.bias, w1, b1)):
         return None
-    return _SeamTFunction.apply(rows, w0, b0, res, norm0.weight, norm0.bias, w1, b1, norm0.eps, tag)
+    drop0 = dropout_scale(res.shape, drop_p, rows.device) if drop_p > 0 else None
+    return _SeamTFunction.apply(rows, w0, b0, res, norm0.weight, norm0.bias, w1, b1, norm0.eps, tag, drop0)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -410,10 +426,18 @@ class _SeamSFunction(Function):
 
     @staticmethod
     def forward(ctx, rows, w0, b0, res, gamma0, beta0, w1, b1, w2, b2, gamma1, beta1, idx, scale, row_slot, nrows, fold,
-                eps0, eps1, tag):
+                eps0, eps1, tag, drops=None):
         ctx.modes = _m().snapshot()
         m = _m()
         rows2, ldx = ops._rows2d(rows.detach(), 256)
+        M0 = idx.shape[0]
+        # drops = (scale tensor of the attention's dropout, of the FFN's hidden dropout, of its output dropout, p_hidden)
+        dk = [None, None, None]
+        if drops is not None:
+            for i, (t, C_) in enumerate(zip(drops[:3], (256, 512, 256))):
+                dk[i] = None if t is None else t.detach().reshape(M0, C_).float().contiguous()
+        ctx.drop0, ctx.drop1 = dk[0], dk[2]
+        ctx.hidden_scale = 1.0 / (1.0 - drops[3]) if (drops is not None and dk[1] is not None) else 1.0
         if fold is not None:
             # rows of a third.. camera folded into the first (in place, on the sampling Function's fresh output: nobody
             # else reads it, and the version saved below is the folded one — what the backward's gather recomputes from)
@@ -447,7 +471,8 @@ class _SeamSFunction(Function):
             rc = lib.bevmsda_proj_ffn_chain_train_f32(
                 _ptr(rows2), _ptr(idx), _ptr(scale), _ptr(_panel_blob(w0)), p(b0), _ptr(res2), p(gamma0), p(beta0),
                 _ptr(_panel_blob(w1)), p(b1), _ptr(_panel_blob(w2)), p(b2), p(gamma1), p(beta1), ctypes.byref(desc), _ptr(y),
-                _ptr(z0), _ptr(x), _ptr(h), _ptr(z1), torch.cuda.current_stream().cuda_stream)
+                _ptr(z0), _ptr(x), _ptr(h), _ptr(z1), *[_ptr(t) if t is not None else None for t in dk],
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "proj_ffn_chain (train)")
         ctx.eps0, ctx.eps1, ctx.tag = float(eps0), float(eps1), tag
         ctx.has_b = (b0 is not None, b1 is not None, b2 is not None)
@@ -474,19 +499,22 @@ class _SeamSFunction(Function):
         dW0, db0, dW1, db1, dW2, db2 = _zeros(dev, (256, 256), (256,), (512, 256), (512,), (256, 512), (256,))
         # LayerNorm1, FFN
         dz1, dg1, dbe1 = _ln_backward(z1, gamma1, gy, ctx.eps1)
-        dh = _dgrad_relu(dz1, w2, h, tag + "_dx2")                             # (M, 512): (dz1 w2) where h > 0
+        df = dz1 if ctx.drop1 is None else dz1 * ctx.drop1                     # through the FFN's output dropout
+        # (dz1 w2) where h > 0 (h: after its dropout — zero where dropped), times 1 / (1 - p) of that dropout
+        dh = _dgrad_relu(df, w2, h, tag + "_dx2", ctx.hidden_scale)            # (M, 512)
         dxf = _dgrad(dh, w1, tag + "_dx1")                                    # the FFN's share of the gradient of x
         # LayerNorm0 (d/dx = the residual branch's dz1 + the FFN's share: added inside the kernel), output projection
         dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dz1, ctx.eps0, out_shape=ctx.res_shape, g2=dxf)
         dz0 = dzr.view(M, 256)
-        probs = [(dz1, h, dW2, db2), (dh, x, dW1, db1)]
+        dzp = dz0 if ctx.drop0 is None else dz0 * ctx.drop0                    # through the attention's dropout
+        probs = [(df, h, dW2, db2), (dh, x, dW1, db1)]
         d_rows = None
         if ni[0] or ni[1] or ni[2]:
             g = ops.gather_mean(rows2 if rows2.is_contiguous() else rows2.contiguous(), idx, scale)   # recomputed: (M, 256)
-            probs.append((dz0, g, dW0, db0))
+            probs.append((dzp, g, dW0, db0))
         _wgrad_multi(probs, tag + "_dw")            # the three weight gradients of the seam: one launch
         if ni[0]:
-            dg = _dgrad(dz0, w0, tag + "_dx0")
+            dg = _dgrad(dzp, w0, tag + "_dx0")
             R = rows2.shape[0]
             d_rows = torch.empty((R, 256), dtype=torch.float32, device=dev)
             lib = _lib.load()
@@ -499,14 +527,16 @@ class _SeamSFunction(Function):
         return (d_rows, dW0 if ni[1] else None, db0 if (hb[0] and ni[2]) else None, d_res, dg0 if ni[4] else None,
                 dbe0 if ni[5] else None, dW1 if ni[6] else None, db1 if (hb[1] and ni[7]) else None,
                 dW2 if ni[8] else None, db2 if (hb[2] and ni[9]) else None, dg1 if ni[10] else None,
-                dbe1 if ni[11] else None, None, None, None, None, None, None, None, None)
+                dbe1 if ni[11] else None, None, None, None, None, None, None, None, None, None)
 
 
 def seam_s(rows, w0, b0, res, norm0, fc1, fc2, norm1, *, gather, row_slot, nrows=None, fold=None,
-           tag="sca_out_ffn_chain"):
+           tag="sca_out_ffn_chain", drop_p=(0.0, 0.0, 0.0)):
     """The SCA seam with gradients, or None when not covered.  ``gather = (idx (M, 2) int32, scale (M))``; ``row_slot``
     (R,) int32: the BEV query of every ragged row; ``nrows``: device-side row count of a dynamic frame plan;
-    ``fold = (q_rows_all, n_extra_dev)``: rows of a third.. camera are folded into the first before the gather."""
+    ``fold = (q_rows_all, n_extra_dev)``: rows of a third.. camera are folded into the first before the gather.
+    ``drop_p = (attention's dropout, FFN hidden dropout, FFN output dropout)``: the active probabilities of train()
+    mode (scale tensors are drawn here, in the reference's call order)."""
     idx, scale = gather
     for norm in (norm0, norm1):
         if not (isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (256,) and norm.weight is not None
@@ -520,5 +550,12 @@ def seam_s(rows, w0, b0, res, norm0, fc1, fc2, norm1, *, gather, row_slot, nrows
             and wanted(rows, w0, b0, res, norm0.weight, norm0.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
                        norm1.weight, norm1.bias)):
         return None
+    drops = None
+    if any(p > 0 for p in drop_p):
+        M = idx.shape[0]
+        lead = tuple(res.shape[:-1])
+        drops = (dropout_scale(lead + (256,), drop_p[0], rows.device) if drop_p[0] > 0 else None,
+                 dropout_scale(lead + (512,), drop_p[1], rows.device) if drop_p[1] > 0 else None,
+                 dropout_scale(lead + (256,), drop_p[2], rows.device) if drop_p[2] > 0 else None, drop_p[1])
     return _SeamSFunction.apply(rows, w0, b0, res, norm0.weight, norm0.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
-                                norm1.weight, norm1.bias, idx, scale, row_slot, nrows, fold, norm0.eps, norm1.eps, tag)
+                                norm1.weight, norm1.bias, idx, scale, row_slot, nrows, fold, norm0.eps, norm1.eps, tag, drops)

@@ -358,7 +358,9 @@ int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1,
  * saved by the forward (mmcv FFN: Linear -> ReLU -> Linear, custom_base_transformer_layer.py:157-158).  fp32 y with N,
  * ldy, ld_act multiples of 4 and 16-byte aligned pointers; no bias, no second source. */
 int bevmsda_linear_relu_backward_packed_f32(const float *g, const uint16_t *wpack, const float *act, int64_t ld_act,
-                                            const bevmsda_linear_desc *desc, float *y, void *stream);
+                                            float scale, const bevmsda_linear_desc *desc, float *y, void *stream);
+/* scale: multiplies the passed elements (1 / (1 - p) when a Dropout sat between the ReLU and the Linear and `act` is
+ * the activation AFTER that dropout: zero where dropped or not positive); 1 otherwise. */
 
 /* The packed projection with bevmsda_gather_mean_f32 folded into its A-load:
  *     A[m, :] = scale[m] * sum_{j < 2, idx[m, j] >= 0} rows[idx[m, j], :]      (idx: (M, 2) int32)
@@ -496,7 +498,12 @@ int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, cons
                                      const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p,
                                      const float *b1, const uint16_t *w2p, const float *b2, const float *gamma1,
                                      const float *beta1, const bevmsda_chain_desc *desc, float *y, float *save_z0,
-                                     float *save_x, float *save_h, float *save_z1, void *stream);
+                                     float *save_x, float *save_h, float *save_z1, const float *drop0, const float *droph,
+                                     const float *drop1, void *stream);
+/* drop0 (M, 256), droph (M, 512), drop1 (M, 256): dropout scale tensors (0 or 1 / (1 - p); NULL = inactive) of the three
+ * nn.Dropout sites of the chain in train() mode — on the attention's projected output before "+ identity"
+ * (spatial_cross_attention.py:175), on the FFN's hidden activations and on its output (mmcv FFN); save_h then holds the
+ * hidden rows AFTER their dropout.  Gather form (idx) only when any is given. */
 
 /* The attention-to-attention seam of a layer with the same machinery:
  *     x = LayerNorm0(A w0^T + b0 + res)        TemporalSelfAttention's output projection, "+ identity", norms[0]
@@ -513,7 +520,7 @@ int bevmsda_proj_ln_proj_chain_f32(const float *rows, const int32_t *idx, const 
 int bevmsda_proj_ln_proj_chain_train_f32(const float *rows, const uint16_t *w0p, const float *b0, const float *res,
                                          const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                          const bevmsda_chain_desc *desc, float *x_out, float *proj_out, float *save_z0,
-                                         void *stream);
+                                         const float *drop0, void *stream);      /* drop0: as above (temporal_self_attention.py:272) */
 
 /* Weight / bias gradient of a Linear layer (csrc/wgrad_mfma.h), the TN form of the projection:
  *     grad_w[n, k] += sum_m g[m, n] * x[m, k]          grad_b[n] += sum_m g[m, n]      (grad_b may be NULL)

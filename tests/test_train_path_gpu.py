@@ -287,3 +287,97 @@ def test_multi_problem_weight_gradient_matches_float64(variant, mode):
         _check(gw, want, "grad_w", *tol)
         if bias:
             _check(gb, G.double().sum(0), "grad_b", 1e-5, 1e-4)
+
+
+def _fixed_masks(monkeypatch, seed):
+    """``train_ops.dropout_scale`` replaced by seeded Bernoulli scale tensors (CPU generator: the float64 statement uses
+    the same ones); returns the list the draws are appended to."""
+    drawn = []
+    g = torch.Generator().manual_seed(seed)
+
+    def scale(shape, p, device):
+        t = (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
+        drawn.append(t)
+        return t.to(device)
+    monkeypatch.setattr(train_ops, "dropout_scale", scale)
+    return drawn
+
+
+def test_seam_functions_with_active_dropout(monkeypatch):
+    """train() mode: the three nn.Dropout sites of the SCA seam (attention output, FFN hidden, FFN output) and the one of
+    the TSA seam as scale tensors inside the chain kernels, forward and backward, against the float64 statements with
+    the same masks."""
+    drawn = _fixed_masks(monkeypatch, 3)
+    torch.manual_seed(5)
+    M, R = 1500, 2100
+    rows, idx, scale, row_slot, g = _seam_s_case(M, R, seed=77)
+    res = torch.randn(1, M, 256, generator=g)
+    w0, b0 = torch.randn(256, 256, generator=g) * 0.06, torch.randn(256, generator=g) * 0.1
+    fc1, fc2 = nn.Linear(256, 512).to(DEV), nn.Linear(512, 256).to(DEV)
+    n0, n1 = nn.LayerNorm(256).to(DEV), nn.LayerNorm(256).to(DEV)
+    gy = torch.randn(1, M, 256, generator=g)
+    L = [_leaf(t) for t in (rows, w0, b0, res)]
+    y = train_ops.seam_s(L[0], L[1], L[2], L[3], n0, fc1, fc2, n1, gather=(idx.to(DEV), scale.to(DEV)),
+                         row_slot=row_slot.to(DEV), drop_p=(0.1, 0.2, 0.3))
+    assert y is not None and len(drawn) == 3
+    y.backward(gy.to(DEV))
+    m0, mh, m1 = (t.double().reshape(M, -1) for t in drawn)
+    d = [t.double().clone().requires_grad_(True) for t in (rows, w0, b0, res)]
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in
+         dict(w1=fc1.weight, b1=fc1.bias, w2=fc2.weight, b2=fc2.bias, g0=n0.weight, be0=n0.bias, g1=n1.weight, be1=n1.bias).items()}
+    ii = idx.long()
+    pad = torch.cat([d[0], d[0].new_zeros(1, 256)], 0)
+    a = (pad[ii[:, 0]] + pad[ii[:, 1]]) * scale.double()[:, None]
+    x = _ln((a @ d[1].t() + d[2]) * m0 + d[3].reshape(M, 256), P["g0"], P["be0"], n0.eps)
+    h = torch.relu(x @ P["w1"].t() + P["b1"]) * mh
+    yw = _ln(x + (h @ P["w2"].t() + P["b2"]) * m1, P["g1"], P["be1"], n1.eps)
+    yw.backward(gy.double().reshape(M, 256))
+    _check(y.reshape(M, 256), yw, "y", 1e-5, 1e-4)
+    # (ReLU units within fp32 round-off of zero flip against the float64 statement: isolated entries, amplified by 1 / (1 - p))
+    _check(L[0].grad, d[0].grad, "grad rows", 3e-3, 5e-2)
+    for name, a_, b_ in zip(("w0", "b0", "res"), L[1:], d[1:]):
+        _check(a_.grad, b_.grad, "grad " + name, 3e-3, 5e-2)
+    for name, mod_p in (("w1", fc1.weight), ("b1", fc1.bias), ("w2", fc2.weight), ("b2", fc2.bias), ("g0", n0.weight),
+                        ("be0", n0.bias), ("g1", n1.weight), ("be1", n1.bias)):
+        _check(mod_p.grad, P[name].grad, "grad " + name, 3e-3, 5e-2)
+
+    # the TSA seam
+    drawn.clear()
+    rows_t = torch.randn(1, M, 256, generator=g)
+    w1, b1 = torch.randn(768, 256, generator=g) * 0.06, torch.randn(768, generator=g) * 0.1
+    gx, gp = torch.randn(1, M, 256, generator=g), torch.randn(M, 768, generator=g)
+    Lt = [_leaf(t) for t in (rows_t, w0, b0, res, w1, b1)]
+    n0.zero_grad()
+    xo, po = train_ops.seam_t(Lt[0], Lt[1], Lt[2], Lt[3], n0, Lt[4], Lt[5], drop_p=0.25)
+    assert len(drawn) == 1
+    torch.autograd.backward([xo, po], [gx.to(DEV), gp.to(DEV)])
+    mt = drawn[0].double().reshape(M, 256)
+    dt = [t.double().clone().requires_grad_(True) for t in (rows_t, w0, b0, res, w1, b1)]
+    gam, bet = n0.weight.detach().double().cpu().requires_grad_(True), n0.bias.detach().double().cpu().requires_grad_(True)
+    xw = _ln((dt[0].reshape(M, 256) @ dt[1].t() + dt[2]) * mt + dt[3].reshape(M, 256), gam, bet, n0.eps)
+    pw = xw @ dt[4].t() + dt[5]
+    torch.autograd.backward([xw, pw], [gx.double().reshape(M, 256), gp.double()])
+    _check(xo.reshape(M, 256), xw, "x", 1e-5, 1e-4)
+    for name, a_, b_ in zip(("rows", "w0", "b0", "res", "w1", "b1"), Lt, dt):
+        _check(a_.grad.reshape(b_.grad.shape), b_.grad, "TSA seam grad " + name)
+    _check(n0.weight.grad, gam.grad, "TSA seam grad gamma")
+
+
+def test_train_mode_takes_the_chain_kernels_with_dropout_active():
+    """``train()`` with p = 0.1 everywhere (the reference's training configuration): the layer still runs on the chain
+    kernels (seam counters move), the output differs from eval mode, gradients are finite.  Parity of this mode against
+    the oracle with shared deterministic masks: tests/test_encoder_gpu.py::test_train_mode_with_active_dropout_on_the_gpu."""
+    enc, _ = build_pair("micro4", device=DEV)
+    q, f, kw = S.make_inputs("micro4", seed=4, temporal=True, device=DEV)
+    with torch.no_grad():
+        ref = enc(q, f, f, **kw)
+    enc.train()
+    before = train_ops.stats()
+    qd = q.clone().requires_grad_(True)
+    torch.manual_seed(0)
+    out = enc(qd, f, f, **kw)
+    after = train_ops.stats()
+    assert after["seam_s"] - before["seam_s"] == len(enc.layers) and after["seam_t"] - before["seam_t"] == len(enc.layers)
+    assert (out - ref).abs().max() > 1e-3
+    out.sum().backward()
+    assert torch.isfinite(qd.grad).all() and all(torch.isfinite(p.grad).all() for p in enc.parameters())
