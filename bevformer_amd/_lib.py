@@ -108,7 +108,7 @@ SIGNATURES = {
                                         _c_int),
     "bevmsda_frontend_expand_f32": ([_c_void_p] * 6 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_frontend_chain_f32": ([_c_void_p] * 5 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 3, _c_int),
-    "bevmsda_frontend_chain_gather_f32": ([_c_void_p] * 4 + [ctypes.c_int64, _c_int, _c_void_p,
+    "bevmsda_frontend_chain_gather_f32": ([_c_void_p] * 4 + [ctypes.c_int64, _c_int, _c_void_p, _c_void_p,
                                            ctypes.POINTER(FusedDesc)] + [_c_void_p] * 3, _c_int),
     "bevmsda_frame_plan_counters": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_frame_plan_scratch": ([_c_int, _c_int], ctypes.c_int64),

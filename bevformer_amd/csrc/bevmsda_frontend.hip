@@ -96,9 +96,9 @@ int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, co
 }
 
 int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_attn, const float *attn,
-                                      const int32_t *q_rows, int64_t slots, int J, const int64_t *spatial_shapes,
-                                      const bevmsda_fused_desc *desc, float *grad_offs, float *grad_logits,
-                                      void *stream) {
+                                      const int32_t *q_rows, int64_t slots, int J, const int32_t *n_extra,
+                                      const int64_t *spatial_shapes, const bevmsda_fused_desc *desc, float *grad_offs,
+                                      float *grad_logits, void *stream) {
   bevmsda::FrontArgs f{};
   const int rc = front_common(desc, f);
   if (rc != BEVMSDA_OK) return rc;
@@ -114,8 +114,8 @@ int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_a
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   const dim3 grid(static_cast<unsigned>(nb)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (desc->P == 8) hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<8>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J);
-  else hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<4>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J);
+  if (desc->P == 8) hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<8>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J, n_extra);
+  else hipLaunchKernelGGL((bevmsda::frontend_chain_gather_kernel<4>), grid, block, 0, st, f, q_rows, static_cast<long>(slots), J, n_extra);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

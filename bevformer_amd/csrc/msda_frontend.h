@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(256) frontend_chain_flat_kernel(const FrontArg
 // K = 1 (SpatialCrossAttention); L * PT a power of two <= 32.
 template <int PT>
 __global__ void __launch_bounds__(256) frontend_chain_gather_kernel(const FrontArgs f, const int32_t *__restrict__ q_rows,
-                                                                   long slots, int J) {
+                                                                   long slots, int J, const int32_t *__restrict__ n_extra) {
   const int LP = f.L * PT;
+  // the plan's device-side count of slots with more than two rows: 0 (the usual frame) -> only the first two columns
+  // of the table can hold rows (they fill in order), the walk over the other J - 2 is skipped
+  const int Jw = (n_extra && J > 2 && *n_extra == 0) ? 2 : J;
   const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   const int lp = static_cast<int>(t % LP);
   long g = t / LP;
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(256) frontend_chain_gather_kernel(const FrontA
   const int l = lp / PT;
   const float W = static_cast<float>(f.shapes[2 * l + 1]), H = static_cast<float>(f.shapes[2 * l]);
   float glogit = 0.f, gx = 0.f, gy = 0.f;
-  for (int j = 0; j < J; ++j) {
+  for (int j = 0; j < Jw; ++j) {
     const int r = q_rows[sl * J + j];                // uniform over the LP lanes of a group
     if (r < 0) continue;
     const long o = (static_cast<long>(r) * f.M + m) * LP + lp;

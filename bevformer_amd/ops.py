@@ -311,7 +311,8 @@ class _FusedSampleFunction(Function):
 
     @staticmethod
     def forward(ctx, value, proj, shapes, start, ref, row_batch, row_src, n_off, meta, tag, q_rows=None, nrows=None,
-                launch_rows=0, value_sink=None):
+                launch_rows=0, value_sink=None, n_extra=None):
+        ctx.n_extra = n_extra             # (1,) int32 device tensor: the plan's count of slots with more than two rows
         ctx.modes = _m().snapshot()
         # (sink, i): the fp32 grad_value of this call is DEPOSITED in sink[i] and a zero-stride placeholder of the value's
         # own (bf16) dtype goes back through autograd — the producer of a bf16-stored value (train_ops.grouped_linear)
@@ -417,7 +418,8 @@ class _FusedSampleFunction(Function):
             if row_src is not None and qr is not None and K == 1 and qr.shape[0] == proj.shape[0]:
                 gproj = torch.empty_like(proj)
                 rc = lib.bevmsda_frontend_chain_gather_f32(
-                    _ptr(gl), _ptr(ga), _ptr(attn), _ptr(qr), qr.shape[0], qr.shape[1], _ptr(shapes),
+                    _ptr(gl), _ptr(ga), _ptr(attn), _ptr(qr), qr.shape[0], qr.shape[1],
+                    ctx.n_extra.data_ptr() if ctx.n_extra is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st)
                 if rc != _lib.ERR_UNSUPPORTED:
                     _lib.check(rc, "fused backward: chain (gather)")
@@ -432,11 +434,11 @@ class _FusedSampleFunction(Function):
             gv_out = torch.zeros((), dtype=ctx.value_dtype, device=dev).expand(value.shape)
         else:
             gv_out = gv.to(ctx.value_dtype)
-        return gv_out, gproj, None, None, None, None, None, None, None, None, None, None, None, None
+        return gv_out, gproj, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, row_src=None,
-                        q_rows=None, tag="msda_fwd", nrows=None, launch_rows=0, value_sink=None, **meta):
+                        q_rows=None, tag="msda_fwd", nrows=None, launch_rows=0, value_sink=None, n_extra=None, **meta):
     """``msda_fused`` with gradients w.r.t. ``value`` and ``proj`` (D = 32; fp32 or bf16 value storage — with bf16
     the forward's rounded copy of ``value`` is what the backward kernels read; the caller checks
     ``fused_training_wanted``).  ``proj`` must be the projection matrix itself (offsets in the first ``n_off``
@@ -447,7 +449,7 @@ def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, r
         _req(q_rows.dtype == torch.int32 and q_rows.dim() == 2 and q_rows.is_contiguous() and q_rows.device == proj.device,
              "bevmsda: q_rows must be a contiguous int32 (slots, J) device tensor")
     return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
-                                      meta, tag, q_rows, nrows, launch_rows, value_sink)
+                                      meta, tag, q_rows, nrows, launch_rows, value_sink, n_extra)
 
 
 def fold_extra_rows(rows, q_rows_all, n_extra):

@@ -244,11 +244,13 @@ int bevmsda_frontend_chain_f32(const float *grad_loc, const float *grad_attn, co
                                float *grad_logits, void *stream);
 /* Step 3 as a gather (K = 1, L in {1, 2, 4}): `q_rows` (slots, J) int32 lists the rows that read projection row
  * `slot` (-1 = none; the frame plan's table, spatial_cross_attention.py:136-153 inverted); every element of the
- * gradient matrix rows [0, slots) is STORED (no atomics, no zeroing by the caller, fixed summation order). */
+ * gradient matrix rows [0, slots) is STORED (no atomics, no zeroing by the caller, fixed summation order).
+ * `n_extra` (device, may be NULL): the frame plan's count of slots with more than two rows; when it reads 0 only the
+ * first two columns of the table are walked (rows fill the columns in order). */
 int bevmsda_frontend_chain_gather_f32(const float *grad_loc, const float *grad_attn, const float *attn,
-                                      const int32_t *q_rows, int64_t slots, int J, const int64_t *spatial_shapes,
-                                      const bevmsda_fused_desc *desc, float *grad_offs, float *grad_logits,
-                                      void *stream);
+                                      const int32_t *q_rows, int64_t slots, int J, const int32_t *n_extra,
+                                      const int64_t *spatial_shapes, const bevmsda_fused_desc *desc, float *grad_offs,
+                                      float *grad_logits, void *stream);
 
 /* Row-wise helpers of the encoder layer (csrc/rowops.h), fp32, forward only.
  *

@@ -381,3 +381,28 @@ def test_train_mode_takes_the_chain_kernels_with_dropout_active():
     assert (out - ref).abs().max() > 1e-3
     out.sum().backward()
     assert torch.isfinite(qd.grad).all() and all(torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
+@pytest.mark.parametrize("case", ["bs2", "three_cameras"])
+def test_fast_training_path_with_a_batch_and_with_three_cameras_per_query(case):
+    """Fast path == per-op path on output and gradients (i) for batch size 2 (the TSA value of [history ; current] stays
+    one stacked tensor, the literal bs > 1 quirks of the reference) and (ii) on a rig whose cameras 0, 1, 2 coincide:
+    every visible query has three rows — the fold of the third row into the first before the two-row gather, its
+    gradient (all rows of a query take the query's gradient) and the walk over the full row table in the backward."""
+    name = "micro4"
+    enc, _ = build_pair(name, device=DEV)
+    bs = 2 if case == "bs2" else 1
+    q, f, kw = S.make_inputs(name, seed=6, temporal=True, bs=bs, device=DEV)
+    if case == "three_cameras":
+        mats = kw["img_metas"][0]["lidar2img"]
+        kw["img_metas"][0]["lidar2img"] = [mats[0], mats[0].copy(), mats[0].copy(), mats[3], mats[4], mats[5]]
+    gout = torch.randn(bs, q.shape[0], 256, generator=torch.Generator().manual_seed(1)).to(DEV)
+    before = train_ops.stats()
+    out_f, g_f = _grads(enc, q, f, kw, gout)
+    assert train_ops.stats()["seam_s"] - before["seam_s"] == len(enc.layers)
+    with ops.using(train_chain=False):
+        out_s, g_s = _grads(enc, q, f, kw, gout)
+    _check(out_f, out_s, "output", 2e-5, 2e-4)
+    for k in g_s:
+        e2, _ = _rel(g_f[k], g_s[k])
+        assert e2 < 3e-2, f"grad {k}: relative L2 {e2:.2e}"
