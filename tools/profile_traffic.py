@@ -47,8 +47,10 @@ def classify(name):
         return "linear_panel:" + re.sub(r".*kernel", "", name)
     if "linear_splitbf16_kernel" in name or "linear_pipe_kernel" in name:
         return "linear_first:" + re.sub(r".*kernel", "", name)
-    if "wgrad_splitbf16_kernel" in name:
+    if "wgrad_splitbf16_kernel" in name or "wgrad_multi_kernel" in name:
         return "linear_wgrad:" + re.sub(r".*kernel", "", name)
+    if "wgrad_tr_multi_kernel" in name:
+        return "linear_wgrad_tr:" + re.sub(r".*kernel", "", name)
     return None
 
 
