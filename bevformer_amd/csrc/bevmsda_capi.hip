@@ -78,14 +78,30 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     const unsigned grid8 = b.xcd_remap ? static_cast<unsigned>(((nb8 + 7) / 8) * 8) : static_cast<unsigned>(nb8);
     // grad_value through LDS tiles (msda_bwd_lds.h) unless variant 3 asks for the first-generation kernel
     // (one memory-side atomic per tap) or the shape does not fit the tiled kernel
-    const int G = a.P % 4 == 0 ? 4 : (a.P % 2 == 0 ? 2 : 1);
+    // point groups of the sort key (points p with equal p % G get their own bucket range): SpatialCrossAttention's points
+    // cycle through 4 pillar anchors at different heights — disjoint footprints per anchor, G = 4; a single-level call
+    // (TemporalSelfAttention: all points around ONE reference point, offsets of a few pixels) has overlapping footprints,
+    // and keying them apart flushes every shared pixel once per point: G = 1 there (round 4: 1,166 -> ~680 flushes per
+    // (tile, head, queue entry) by tools/flush_sim.py's count; measured below)
+#ifndef BEVMSDA_GV_GROUPS_MULTI
+#define BEVMSDA_GV_GROUPS_MULTI 4
+#endif
+#ifndef BEVMSDA_GV_GROUPS_SINGLE
+#define BEVMSDA_GV_GROUPS_SINGLE 1
+#endif
+    int G = a.P % 4 == 0 ? 4 : (a.P % 2 == 0 ? 2 : 1);
+    const int gcap = a.L == 1 ? BEVMSDA_GV_GROUPS_SINGLE : BEVMSDA_GV_GROUPS_MULTI;
+    if (G > gcap) G = gcap;
     // (entries carry the pixel index of a level in 23 bits and the row of the block in 8)
     // 256 rows / 1024 threads per workgroup (one per CU) for single-level calls (TemporalSelfAttention: the
     // 16 x 16 grid tiles), 128 rows / 512 threads (two per CU: one sorts while the other's flushes drain) for
     // multi-level calls — measured on the padded base SCA call, image-ordered rows: 1.13 vs 1.27 ms (raster rows:
     // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  tuning->reserved[0] = 64 / 128 / 256 forces one.
     const int gv_forced = a.gv_rows;           // bevmsda_tuning.reserved[0]
-    const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? 128 : kGvRowsPerBlock);
+#ifndef BEVMSDA_GV_ROWS_MULTI
+#define BEVMSDA_GV_ROWS_MULTI 128
+#endif
+    const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? BEVMSDA_GV_ROWS_MULTI : kGvRowsPerBlock);
     const int gv_threads = gv_rows == 64 ? 256 : (gv_rows == 128 ? 512 : bevmsda::kGvThreads);
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
