@@ -136,8 +136,10 @@ msda_gradloc_d32_kernel(const KArgs a) {
   f32x4 g;
   {
     float t[4];
-    Io<T, 4>::load(static_cast<const T *>(a.grad_out) + row * D + lig * 4, t);
-    g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = t[3];
+    const long grow = a.gout_rows > 0 ? (nq % a.gout_rows) * a.M + m : row;
+    Io<T, 4>::load(static_cast<const T *>(a.grad_out) + grow * D + lig * 4, t);
+    const float gs = a.gout_rows > 0 ? a.gout_scale : 1.f;
+    g[0] = t[0] * gs; g[1] = t[1] * gs; g[2] = t[2] * gs; g[3] = t[3] * gs;
   }
   float2 xy = lp[0];
   float aw = ap[0];
@@ -253,9 +255,11 @@ msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
 
   float g[8];
   {
-    const uint4 t = *reinterpret_cast<const uint4 *>(static_cast<const bf16_t *>(a.grad_out) + row * D + (lig & 3) * 8);
-    g[0] = bf16_lo(t.x); g[1] = bf16_hi(t.x); g[2] = bf16_lo(t.y); g[3] = bf16_hi(t.y);
-    g[4] = bf16_lo(t.z); g[5] = bf16_hi(t.z); g[6] = bf16_lo(t.w); g[7] = bf16_hi(t.w);
+    const long grow = a.gout_rows > 0 ? (nq % a.gout_rows) * a.M + m : row;
+    const uint4 t = *reinterpret_cast<const uint4 *>(static_cast<const bf16_t *>(a.grad_out) + grow * D + (lig & 3) * 8);
+    const float gs = a.gout_rows > 0 ? a.gout_scale : 1.f;
+    g[0] = bf16_lo(t.x) * gs; g[1] = bf16_hi(t.x) * gs; g[2] = bf16_lo(t.y) * gs; g[3] = bf16_hi(t.y) * gs;
+    g[4] = bf16_lo(t.z) * gs; g[5] = bf16_hi(t.z) * gs; g[6] = bf16_lo(t.w) * gs; g[7] = bf16_hi(t.w) * gs;
   }
   float2 xy = lp[0];
   float aw = ap[0];

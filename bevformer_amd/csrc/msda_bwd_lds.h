@@ -175,8 +175,13 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
   for (int i = tid; i < (c1 - c0) * 8; i += THREADS) {
     const int row = i >> 3, q4 = (i & 7) * 4;
     const int pr = phys(c0 + row);
-    reinterpret_cast<float4 *>(gl)[i] = pr < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) :
-        load_gout4<T>(static_cast<const T *>(a.grad_out) + (static_cast<long>(pr) * a.M + m) * D + q4);
+    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pr >= 0) {
+      const long grow = a.gout_rows > 0 ? static_cast<long>(pr) % a.gout_rows : static_cast<long>(pr);
+      gq = load_gout4<T>(static_cast<const T *>(a.grad_out) + (grow * a.M + m) * D + q4);
+      if (a.gout_rows > 0) { gq.x *= a.gout_scale; gq.y *= a.gout_scale; gq.z *= a.gout_scale; gq.w *= a.gout_scale; }
+    }
+    reinterpret_cast<float4 *>(gl)[i] = gq;
   }
 
   // sub-ranges of rows that share a value batch entry (rows are grouped by camera: normally one)

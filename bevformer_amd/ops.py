@@ -374,14 +374,21 @@ class _FusedSampleFunction(Function):
                     proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
                     _ptr(row_src) if row_src is not None else None, _ptr(shapes), ctypes.byref(desc), _ptr(loc),
                     _ptr(attn), _ptr(rbk), st), "fused backward: expand")
+            # queue entries that share their output row (TSA's mean over K entries, one value batch entry each, one batch
+            # element): the backward kernels read scale * grad_out[r % R] themselves — no scaled, repeated copy
+            shared = row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R \
+                and nrows is None and grad_out.dim() == 2 and grad_out.shape[0] == R
             if bf and grad_out.dtype == torch.float32 and grad_out.is_contiguous() and grad_out.dim() == 2 \
                     and grad_out.shape[0] == R and grad_out.shape[1] % 8 == 0 and grad_out.data_ptr() % 16 == 0:
-                # bf16 storage: scale by 1 / K and round in one pass per queue entry, over the rows that exist only
-                g = torch.empty((RK, grad_out.shape[1]), dtype=torch.bfloat16, device=dev)
-                for k in range(K):
+                # bf16 storage: round (and, without row sharing, scale by 1 / K per queue entry) over the rows that exist
+                reps = 1 if shared else K
+                g = torch.empty((R * reps, grad_out.shape[1]), dtype=torch.bfloat16, device=dev)
+                for k in range(reps):
                     _lib.check(lib.bevmsda_cast_rows_bf16(
-                        _ptr(grad_out), nrows.data_ptr() if nrows is not None else None, R, grad_out.shape[1], 1.0 / K,
-                        g.data_ptr() + k * R * grad_out.shape[1] * 2, st), "fused backward: cast rows")
+                        _ptr(grad_out), nrows.data_ptr() if nrows is not None else None, R, grad_out.shape[1],
+                        1.0 if shared else 1.0 / K, g.data_ptr() + k * R * grad_out.shape[1] * 2, st), "fused backward: cast rows")
+            elif shared:
+                g = grad_out.to(ctx.store).contiguous()
             else:
                 g = grad_out.float()
                 if K > 1:       # out = mean over the queue entries; rows are queue-major
@@ -403,12 +410,18 @@ class _FusedSampleFunction(Function):
                     _lib.check((lib.bevmsda_backward_rows_bf16 if bf else lib.bevmsda_backward_rows_f32)(
                         _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), nrows.data_ptr(),
                         N, S, M, D, L, RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator (rows)")
-                elif row_batch is None and K > 1 and N == K and m["vmul"] == K and m["vadd"] == 1 and m.get("Q", 0) == R:
+                elif shared:
                     # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
                     # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
-                    _lib.check((lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
-                        _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
-                        _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator")
+                    rc = (lib.bevmsda_backward_shared_bf16 if bf else lib.bevmsda_backward_shared_f32)(
+                        _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), R, 1.0 / K, N, S, M, D, L, R, P,
+                        _ptr(gv), _ptr(gl), _ptr(ga), st)
+                    if rc == _lib.ERR_UNSUPPORTED:      # (a shape only the first-generation kernels take: scaled, repeated rows)
+                        g = (g.float() * (1.0 / K)).repeat(K, 1).to(ctx.store).contiguous()
+                        rc = (lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
+                            _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,
+                            _ptr(gv), _ptr(gl), _ptr(ga), st)
+                    _lib.check(rc, "fused backward: operator")
                 else:
                     _lib.check((lib.bevmsda_backward_ragged_bf16 if bf else lib.bevmsda_backward_ragged_f32)(
                         _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), N, S, M, D, L,
@@ -424,7 +437,8 @@ class _FusedSampleFunction(Function):
                 if rc != _lib.ERR_UNSUPPORTED:
                     _lib.check(rc, "fused backward: chain (gather)")
             if rc == _lib.ERR_UNSUPPORTED:
-                gproj = torch.zeros_like(proj)
+                # (with row_src the chain pass ADDS the rows of a query with atomics; without it every element is stored)
+                gproj = torch.zeros_like(proj) if row_src is not None else torch.empty_like(proj)
                 _lib.check(lib.bevmsda_frontend_chain_f32(
                     _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")

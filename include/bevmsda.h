@@ -129,6 +129,18 @@ int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
                                float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
+/* bevmsda_backward_* whose N * Q operand rows SHARE `grad_rows` rows of grad_out: row r reads grad_scale *
+ * grad_out[r % grad_rows] — TemporalSelfAttention averages its queue entries (temporal_self_attention.py:257-262), so the
+ * N = 2 entries of a query receive the same output gradient times 1 / 2; no repeated, pre-scaled copy of it is formed.
+ * Second-generation kernels only (D = 32, P in {4, 8}, L <= 4). */
+int bevmsda_backward_shared_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
+                                const float *attn, const float *grad_out, int64_t grad_rows, float grad_scale, int N, int S, int M,
+                                int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+int bevmsda_backward_shared_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
+                                 const float *attn, const uint16_t *grad_out, int64_t grad_rows, float grad_scale, int N, int S,
+                                 int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                                 void *stream);
+
 /* Same as above with explicit tuning. */
 int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes,
                            const int64_t *level_start, const float *loc, const float *attn,
