@@ -86,10 +86,12 @@ SIGNATURES = {
     "bevmsda_backward_ragged_f32": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
     "bevmsda_forward_ragged_bf16": ([_c_void_p] * 6 + _DIMS + [_c_void_p, _c_void_p], _c_int),
     "bevmsda_backward_ragged_bf16": ([_c_void_p] * 7 + _DIMS + [_c_void_p] * 4, _c_int),
-    "bevmsda_backward_shared_f32": ([_c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float] + _DIMS + [_c_void_p] * 4, _c_int),
-    "bevmsda_backward_shared_bf16": ([_c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float] + _DIMS + [_c_void_p] * 4, _c_int),
-    "bevmsda_backward_rows_f32": ([_c_void_p] * 8 + _DIMS + [_c_void_p] * 4, _c_int),
-    "bevmsda_backward_rows_bf16": ([_c_void_p] * 8 + _DIMS + [_c_void_p] * 4, _c_int),
+    "bevmsda_backward_shared_f32": ([_c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float] + _DIMS + [_c_void_p, ctypes.c_int64]
+                                    + [_c_void_p] * 3, _c_int),
+    "bevmsda_backward_shared_bf16": ([_c_void_p] * 6 + [ctypes.c_int64, ctypes.c_float] + _DIMS + [_c_void_p, ctypes.c_int64]
+                                    + [_c_void_p] * 3, _c_int),
+    "bevmsda_backward_rows_f32": ([_c_void_p] * 8 + _DIMS + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
+    "bevmsda_backward_rows_bf16": ([_c_void_p] * 8 + _DIMS + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
     "bevmsda_frontend_expand_rows_f32": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_cast_rows_bf16": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_int, ctypes.c_float, _c_void_p, _c_void_p], _c_int),
     "bevmsda_rows_from_slots_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, _c_int,

@@ -106,7 +106,7 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
     tiled = tiled && 1LL * a.S < (1LL << 23) && a.NQ < (1LL << 30) && 1LL * a.N * (1LL * a.Q * 3 / 512 + 4) * 256 < (1LL << 30);
-    if ((a.nrows_dev || a.gout_rows > 0) && !(tiled && d32_fwd_eligible<T>(a))) return BEVMSDA_ERR_UNSUPPORTED;   // (no first-generation kernel reads the device count / shares grad_out rows)
+    if ((a.nrows_dev || a.gout_rows > 0 || a.gv_stride > 0) && !(tiled && d32_fwd_eligible<T>(a))) return BEVMSDA_ERR_UNSUPPORTED;   // (no first-generation kernel reads the device count / shares grad_out rows)
     if (tiled) {
       bevmsda::GradValueArgs s{};
       s.k = a;
@@ -295,7 +295,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
                   const float *attn, const T *grad_out, int N, int S, int M, int D, int L, int Q,
                   int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream,
                   const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr, int R = -1,
-                  const int32_t *nrows_dev = nullptr, long gout_rows = 0, float gout_scale = 1.f) {
+                  const int32_t *nrows_dev = nullptr, long gout_rows = 0, float gout_scale = 1.f, long gv_stride = 0) {
   const int Nv = N;
   if (R >= 0) {
     if (R > 0 && !row_batch) return BEVMSDA_ERR_NULL_POINTER;
@@ -333,6 +333,10 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
   // shared grad_out rows (second-generation D = 32 kernels only)
   if (gout_rows < 0 || (gout_rows > 0 && (D != 32 || !(P == 4 || P == 8) || L > bevmsda::kGvMaxLevels || tuning))) return BEVMSDA_ERR_UNSUPPORTED;
   a.gout_rows = gout_rows; a.gout_scale = gout_scale;
+  // grad_value rows of a wider array: the sort kernel of the second generation only
+  if (gv_stride < 0 || (gv_stride > 0 && (gv_stride < 1L * M * D || gv_stride % 4 != 0 || D != 32 || !(P == 4 || P == 8) || L > bevmsda::kGvMaxLevels || tuning)))
+    return gv_stride < 0 ? BEVMSDA_ERR_BAD_SHAPE : BEVMSDA_ERR_UNSUPPORTED;
+  a.gv_stride = gv_stride;
   a.mshift = ilog2_exact(M);
   a.qshift = ilog2_exact(a.qtile);
   return dispatch<T, true>(a, variant, static_cast<hipStream_t>(stream));
@@ -573,38 +577,41 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
 int bevmsda_backward_rows_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *loc, const float *attn, const int32_t *row_batch, const float *grad_out,
                               const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
-                              float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+                              float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream) {
   if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
   return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
-                              grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows);
+                              grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows, 0, 1.f, static_cast<long>(grad_value_stride));
 }
 
 int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *loc, const float *attn, const int32_t *row_batch, const uint16_t *grad_out,
                                const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
-                               float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+                               float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream) {
   if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, 0, P,
-                               grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows);
+                               grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows, 0, 1.f, static_cast<long>(grad_value_stride));
 }
 
 int bevmsda_backward_shared_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
                                 const float *attn, const float *grad_out, int64_t grad_rows, float grad_scale, int N, int S, int M,
-                                int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream) {
+                                int D, int L, int Q, int P, float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn,
+                                void *stream) {
   if (grad_rows <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   return backward_impl<float>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P, grad_value, grad_loc,
-                              grad_attn, stream, nullptr, nullptr, -1, nullptr, static_cast<long>(grad_rows), grad_scale);
+                              grad_attn, stream, nullptr, nullptr, -1, nullptr, static_cast<long>(grad_rows), grad_scale,
+                              static_cast<long>(grad_value_stride));
 }
 
 int bevmsda_backward_shared_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
                                  const float *attn, const uint16_t *grad_out, int64_t grad_rows, float grad_scale, int N, int S,
-                                 int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
-                                 void *stream) {
+                                 int M, int D, int L, int Q, int P, float *grad_value, int64_t grad_value_stride, float *grad_loc,
+                                 float *grad_attn, void *stream) {
   if (grad_rows <= 0) return BEVMSDA_ERR_BAD_SHAPE;
   return backward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Q, P, grad_value, grad_loc,
-                               grad_attn, stream, nullptr, nullptr, -1, nullptr, static_cast<long>(grad_rows), grad_scale);
+                               grad_attn, stream, nullptr, nullptr, -1, nullptr, static_cast<long>(grad_rows), grad_scale,
+                              static_cast<long>(grad_value_stride));
 }
 
 int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const float *scale, const int32_t *row_slot,

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
     const int y = tile_y0 + (w >> 4), x = tile_x0 + (w & 15);
     return (y < H0 && x < W0) ? tile_n * a.Q + y * W0 + x : -1;
   };
-  const int pix_stride = a.M * D;
+  const long pix_stride = a.gv_stride > 0 ? a.gv_stride : static_cast<long>(a.M * D);
   const int half = tid >> 5;          // 32 half-waves per workgroup
   const int c = tid & 31;             // my channel
   // bucket of a tap: [point group | y mod 2^yb | x mod 2^xb], 12 bits
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
     for (int l = 0; l < kGvMaxLevels; ++l) {
       if (l >= L) break;
       const int H = Hs[l], W = Ws[l];
-      float *gv = a.grad_value + ((n0 * a.S + ls[l]) * a.M + m) * D + c;
+      float *gv = a.grad_value + (n0 * a.S + ls[l]) * pix_stride + m * D + c;
       // ---- (1) zero the counters
       for (int z = tid; z < kGvBuckets / 4; z += THREADS) reinterpret_cast<int4 *>(cnt)[z] = make_int4(0, 0, 0, 0);
       lds_barrier();
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             const int px = en[j].x & 0x7fffff;
             if (px != cur) {
               if (cur >= 0) {
-                unsafeAtomicAdd(gv + static_cast<long>(cur) * pix_stride, acc);
+                unsafeAtomicAdd(gv + cur * pix_stride, acc);
                 if constexpr (PROF) { if (c == 0) atomicAdd(&s.prof[7], 1ULL); }
               }
               cur = px;
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             acc = fmaf(__int_as_float(en[j].y), gg[j], acc);
           }
         }
-        if (cur >= 0) unsafeAtomicAdd(gv + static_cast<long>(cur) * pix_stride, acc);
+        if (cur >= 0) unsafeAtomicAdd(gv + cur * pix_stride, acc);
       }
       GV_TICK(4)
       // (the next level's placement is separated from these reads by the barriers of its steps 1-3)

@@ -54,6 +54,8 @@ struct KArgs {
   unsigned long long *gv_prof;   // backward: phase clocks of the sort kernel (tools/gvprof.py), else nullptr
   const int32_t *nrows_dev;      // backward (second-generation D = 32 kernels): NQ is the CAPACITY of the row arrays and the
                                  // actual row count is read here, on the device (frame_plan.h); nullptr: NQ rows
+  long gv_stride;                // backward (second-generation D = 32 kernels): elements between two pixels of grad_value (0 = M * D:
+                                 // dense); > M * D: the L value-projection gradients of a frame side by side in one array
   long gout_rows;                // backward (second-generation D = 32 kernels): > 0: grad_out has this many rows and row r of
   float gout_scale;              // the operands reads scale * grad_out[r % gout_rows] — the queue entries of
                                  // TemporalSelfAttention share one output row (their mean: scale = 1 / entries); 0: one

@@ -245,9 +245,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # through a sink (no conversion pass in either direction)
         store = ops.value_storage()
         bf = store == torch.bfloat16
-        self._value_sinks = ([None] * L, [None] * L) if bf else None
+        # the consumers' value gradients land side by side in one array per family (train_ops.ValueGradSink)
+        self._value_sinks = (train_ops.ValueGradSink(L), train_ops.ValueGradSink(L))
         ys = train_ops.grouped_linear(feats, w, b, L, "sca_value_proj", out_dtype=store if bf else None,
-                                      sink=self._value_sinks[0] if bf else None)
+                                      sink=self._value_sinks[0])
         M = scas[0].num_heads
         sca_vals = [y.view(bs * Nc, S, M, -1) for y in ys]
         tsa_vals = None
@@ -256,13 +257,13 @@ class BEVFormerEncoder(TransformerLayerSequence):
             if isinstance(tsa_value, tuple):
                 Q = tsa_value[0].shape[1]
                 ys = train_ops.grouped_linear([t.reshape(-1, C) for t in tsa_value], w, b, L, "tsa_value_proj",
-                                              out_dtype=store if bf else None, sink=self._value_sinks[1] if bf else None)
+                                              out_dtype=store if bf else None, sink=self._value_sinks[1])
                 nb = 2
             else:
                 Q = tsa_value.shape[1]
                 nb = tsa_value.shape[0]
                 ys = train_ops.grouped_linear(tsa_value, w, b, L, "tsa_value_proj", out_dtype=store if bf else None,
-                                              sink=self._value_sinks[1] if bf else None)
+                                              sink=self._value_sinks[1])
             M = tsas[0].num_heads
             tsa_vals = [y.view(nb, Q, M, -1) for y in ys]
         return sca_vals, tsa_vals

@@ -319,7 +319,7 @@ class SpatialCrossAttention(BaseModule):
                     lg_head=L_ * P_, lg_k=0, ref_mode=0, vmul=1, vadd=0, row_src=frame_plan.row_query32, q_rows=q_tab,
                     tag="sca_fwd", nrows=frame_plan.nrows_dev if dyn else None,
                     launch_rows=frame_plan.launch_rows if dyn else 0,
-                    value_sink=sink if projected_value.dtype == torch.bfloat16 else None,
+                    value_sink=sink,
                     n_extra=frame_plan.n_extra_dev if dyn else None)
                 done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
                              (frame_plan.q_rows, inv_count), frame_plan,

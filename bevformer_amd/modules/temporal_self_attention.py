@@ -233,7 +233,7 @@ class TemporalSelfAttention(BaseModule):
                                           off_head=nq * L * P * 2, off_k=L * P * 2, lg_head=nq * L * P,
                                           lg_k=L * P, ref_mode=1, vmul=1 if shared_value else nq,
                                           vadd=0 if shared_value else 1, Q=Q, tag="tsa_fwd",
-                                          value_sink=vsink if v.dtype == torch.bfloat16 else None)
+                                          value_sink=vsink)
             out = out.to(query.dtype).view(bs, Q, C)
         if out is None:
             out = self._sample_unfused(proj, n_off, v, reference_points, spatial_shapes,

@@ -394,7 +394,14 @@ class _FusedSampleFunction(Function):
                 if K > 1:       # out = mean over the queue entries; rows are queue-major
                     g = (g * (1.0 / K)).repeat(K, 1)
                 g = g.to(ctx.store).contiguous()
-            gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
+            # grad_value: a dense zero-filled array, or (a sink with an arena) this call's pixel rows of the frame-wide
+            # array that holds the value gradients of all layers side by side
+            gv, gvs = None, 0
+            if ctx.value_sink is not None and (nrows is not None or shared) and hasattr(ctx.value_sink[0], "buffer"):
+                gv = ctx.value_sink[0].buffer(ctx.value_sink[1], value.shape, dev)
+                gvs = 0 if gv is None else gv.stride(1)
+            if gv is None:
+                gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
             gl = torch.empty_like(loc)
             ga = torch.empty_like(attn)
             # algorithmic bytes of the operator's backward: value + locations + weights + grad_out read,
@@ -409,14 +416,16 @@ class _FusedSampleFunction(Function):
                 if nrows is not None:
                     _lib.check((lib.bevmsda_backward_rows_bf16 if bf else lib.bevmsda_backward_rows_f32)(
                         _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), nrows.data_ptr(),
-                        N, S, M, D, L, RK, P, _ptr(gv), _ptr(gl), _ptr(ga), st), "fused backward: operator (rows)")
+                        N, S, M, D, L, RK, P, _ptr(gv), gvs, _ptr(gl), _ptr(ga), st), "fused backward: operator (rows)")
                 elif shared:
                     # one batch element, one value batch entry per queue entry: queue-major rows ARE the dense
                     # (N = K, Q = R) layout of the operator (its grid-tiled grad_value path applies)
                     rc = (lib.bevmsda_backward_shared_bf16 if bf else lib.bevmsda_backward_shared_f32)(
                         _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), R, 1.0 / K, N, S, M, D, L, R, P,
-                        _ptr(gv), _ptr(gl), _ptr(ga), st)
+                        _ptr(gv), gvs, _ptr(gl), _ptr(ga), st)
                     if rc == _lib.ERR_UNSUPPORTED:      # (a shape only the first-generation kernels take: scaled, repeated rows)
+                        if gvs:
+                            gv, gvs = torch.zeros(value.shape, dtype=torch.float32, device=dev), 0
                         g = (g.float() * (1.0 / K)).repeat(K, 1).to(ctx.store).contiguous()
                         rc = (lib.bevmsda_backward_bf16 if bf else lib.bevmsda_backward_f32)(
                             _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(g), N, S, M, D, L, R, P,

@@ -237,6 +237,24 @@ class _GroupedLinearFunction(Function):
             wt = wcat.detach().view(L, ncol, K)
         probs = []
         sink = ctx.sink
+        arena = sink.take() if isinstance(sink, ValueGradSink) else None
+        if arena is not None and tuple(arena.shape) == (M, L * ncol):
+            # the consumers wrote their gradients side by side into one (rows, L * ncol) array: ONE input-gradient GEMM
+            # with K = L * ncol (the L partial products are summed in its accumulators instead of L - 1 read-modify-write
+            # passes over dx) and one weight-gradient problem with N = L * ncol
+            for i, g in enumerate(gys):
+                dep, sink[i] = sink[i], None
+                col = arena[:, i * ncol:(i + 1) * ncol]
+                if dep is not None and dep.data_ptr() == col.data_ptr():
+                    continue
+                src = dep if dep is not None else g         # (a consumer that took another path: its own array)
+                if src is not None:
+                    col.add_(src.reshape(M, ncol))
+            if dW is not None:
+                _wgrad_multi([(arena, x2, dW, db)], ctx.tag + "_dw")
+            if lo is not None:
+                dx = _dgrad(arena[lo:hi], wcat.detach(), ctx.tag + "_dx")
+            gys = ()
         for i, g in enumerate(gys):
             if sink is not None and sink[i] is not None:
                 g, sink[i] = sink[i], None          # the consumer's fp32 gradient (its autograd return is a placeholder)
@@ -263,6 +281,34 @@ def grouped_linear(xs, wcat, bcat, L, tag, segments=None, out_dtype=None, sink=N
     if torch.is_tensor(xs):
         xs = [xs]
     return _GroupedLinearFunction.apply(wcat, bcat, L, tag, segments, out_dtype, sink, *xs)
+
+
+class ValueGradSink(list):
+    """L slots in which the consumers of a grouped projection's outputs deposit their fp32 gradients (the autograd
+    return of such a consumer is a zero-stride placeholder).  ``arena=True``: the slots are the column blocks of ONE
+    zero-filled (rows, L * width) array allocated on first use in a backward pass — ``buffer(slot, shape, device)`` hands
+    out block ``slot`` as a strided (N, S, M, D) view (pixel stride L * M * D) that the grad_value kernels accumulate
+    into (``grad_value_stride`` of ``bevmsda_backward_rows_*`` / ``_shared_*``)."""
+
+    def __init__(self, L, arena=True):
+        super().__init__([None] * L)
+        self.use_arena = bool(arena)
+        self.arena = None
+
+    def buffer(self, slot, shape, device):
+        if not self.use_arena:
+            return None
+        N, S, M, D = shape
+        width = M * D
+        if self.arena is None:
+            self.arena = torch.zeros((N * S, len(self) * width), dtype=torch.float32, device=device)
+        if tuple(self.arena.shape) != (N * S, len(self) * width):
+            return None
+        return self.arena[:, slot * width:(slot + 1) * width].view(N, S, M, D)
+
+    def take(self):
+        arena, self.arena = self.arena, None
+        return arena
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -119,27 +119,31 @@ int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_s
  * writes it): R is the CAPACITY of the row arrays (loc, attn, row_batch, grad_out, grad_loc, grad_attn), rows
  * [0, min(*nrows, R)) are processed, the others neither read nor written — no host synchronisation between the frame
  * plan and the backward of multi_scale_deformable_attn_function.py:130-163, so a training step can be captured in a
- * HIP graph.  Second-generation kernels only: D = 32, P in {4, 8}, L <= 4, value < 2 GiB; else BEVMSDA_ERR_UNSUPPORTED. */
+ * HIP graph.  `grad_value_stride`: floats between two pixels of grad_value (0 = M * D, the dense (N, S, M, D) array;
+ * larger, a multiple of 4: the pixel rows of a wider array — the gradients of the encoder layers' value projections of a
+ * frame side by side, the operand of ONE input-gradient GEMM).
+ * Second-generation kernels only: D = 32, P in {4, 8}, L <= 4, value < 2 GiB; else BEVMSDA_ERR_UNSUPPORTED. */
 int bevmsda_backward_rows_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *loc, const float *attn, const int32_t *row_batch, const float *grad_out,
                               const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
-                              float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+                              float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream);
 int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *loc, const float *attn, const int32_t *row_batch, const uint16_t *grad_out,
                                const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
-                               float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+                               float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream);
 
 /* bevmsda_backward_* whose N * Q operand rows SHARE `grad_rows` rows of grad_out: row r reads grad_scale *
  * grad_out[r % grad_rows] — TemporalSelfAttention averages its queue entries (temporal_self_attention.py:257-262), so the
  * N = 2 entries of a query receive the same output gradient times 1 / 2; no repeated, pre-scaled copy of it is formed.
- * Second-generation kernels only (D = 32, P in {4, 8}, L <= 4). */
+ * `grad_value_stride`: as in bevmsda_backward_rows_*.  Second-generation kernels only (D = 32, P in {4, 8}, L <= 4). */
 int bevmsda_backward_shared_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
                                 const float *attn, const float *grad_out, int64_t grad_rows, float grad_scale, int N, int S, int M,
-                                int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+                                int D, int L, int Q, int P, float *grad_value, int64_t grad_value_stride, float *grad_loc,
+                                float *grad_attn, void *stream);
 int bevmsda_backward_shared_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
                                  const float *attn, const uint16_t *grad_out, int64_t grad_rows, float grad_scale, int N, int S,
-                                 int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
-                                 void *stream);
+                                 int M, int D, int L, int Q, int P, float *grad_value, int64_t grad_value_stride, float *grad_loc,
+                                 float *grad_attn, void *stream);
 
 /* Same as above with explicit tuning. */
 int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes,
