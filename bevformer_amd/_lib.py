@@ -138,6 +138,8 @@ SIGNATURES = {
                                              _c_int),
     "bevmsda_linear_panel_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
                                                   _c_void_p, _c_void_p], _c_int),
+    "bevmsda_linear_panel_rows2_f32": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, ctypes.POINTER(LinearDesc), _c_void_p,
+                                        _c_void_p], _c_int),
     "bevmsda_linear_panel_segments_f32": ([_c_void_p] * 3 + [ctypes.POINTER(LinearDesc), _c_void_p, ctypes.c_int64, _c_void_p,
                                            _c_int, _c_void_p, _c_void_p], _c_int),
     "bevmsda_proj_ffn_chain_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p], _c_int),

@@ -234,8 +234,12 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     take = (lambda t: t.index_select(1, rows_idx)) if sectors else (lambda t: t[:, q0:q1])
     pos_local = take(bev_pos.permute(1, 0, 2)).contiguous()     # (once per frame, not once per layer)
     Q = ref_2d.shape[1]
+    stack_free = False
     if prev_bev is not None:
-        tsa_value = torch.stack([prev_bev.permute(1, 0, 2), full_query], 1).reshape(bs * 2, Q, -1)
+        history = prev_bev.permute(1, 0, 2)
+        # (inference, bs = 1: the value projection reads history and queries where they lie — encoder.py, ``_stack_free``)
+        stack_free = encoder._stack_free(history, full_query, bs)
+        tsa_value = (history, full_query) if stack_free else torch.stack([history, full_query], 1).reshape(bs * 2, Q, -1)
         hybrid = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
     else:
         tsa_value = None
@@ -249,6 +253,9 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
     sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value, plan=tile if world > 1 else None,
                                                             spatial_shapes=spatial_shapes)
+    if stack_free:
+        tsa_value = history.expand(2, Q, history.shape[-1]) if tsa_vals is not None \
+            else torch.stack([history, full_query], 1).reshape(bs * 2, Q, -1)
     for li, layer in enumerate(encoder.layers):
         hoisted = {}
         if history_local is not None:

@@ -276,9 +276,13 @@ int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int
 static int panel_launch(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                         const float *scale, const uint16_t *wpanel, const float *bias,
                         const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream,
-                        const int32_t *seg_start, int64_t seg_len, const int64_t *level_shapes, int num_levels) {
+                        const int32_t *seg_start, int64_t seg_len, const int64_t *level_shapes, int num_levels,
+                        const float *xb = nullptr, int64_t m_split = 0) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0 || d->N < 0 || d->K0 < 0 || d->K1 < 0 || d->group_cols < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (xb && (m_split < 0 || m_split > d->M)) return BEVMSDA_ERR_BAD_SHAPE;
+  if (xb && (d->K1 != 0 || a0 || idx || ln || seg_start)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (xb && misaligned(xb)) return BEVMSDA_ERR_MISALIGNED;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (d->M == 0 || d->N == 0) return BEVMSDA_OK;
   const int K = d->K0 + d->K1;
@@ -304,6 +308,7 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   a.bias = bias; a.y = y; a.ldy = d->ldy; a.M = d->M; a.N = d->N; a.K0 = d->K0; a.K1 = d->K1;
   a.relu = d->relu ? 1 : 0; a.group_cols = gcols; a.out_bf16 = d->out_bf16 ? 1 : 0;
   a.res = nullptr; a.ldres = 0; a.gamma = a.beta = nullptr; a.eps = 0.f;
+  a.xb = xb; a.m_split = m_split;
   a.seg_start = seg_start; a.seg_len = seg_len; a.level_shapes = level_shapes; a.num_levels = level_shapes ? num_levels : 0;
   if (seg_start && (seg_len <= 0 || num_levels < 0)) return BEVMSDA_ERR_BAD_SHAPE;
   if (ln) {
@@ -361,6 +366,13 @@ int bevmsda_linear_panel_segments_f32(const float *x0, const uint16_t *wpanel, c
   if (!seg_start) return BEVMSDA_ERR_NULL_POINTER;
   return panel_launch(x0, nullptr, nullptr, nullptr, nullptr, nullptr, wpanel, bias, d, nullptr, y, stream, seg_start, seg_len,
                       level_shapes, num_levels);
+}
+
+int bevmsda_linear_panel_rows2_f32(const float *x_lo, const float *x_hi, int64_t m_split, const uint16_t *wpanel, const float *bias,
+                                   const bevmsda_linear_desc *d, float *y, void *stream) {
+  if (!x_hi) return BEVMSDA_ERR_NULL_POINTER;
+  return panel_launch(x_lo, nullptr, nullptr, nullptr, nullptr, nullptr, wpanel, bias, d, nullptr, y, stream, nullptr, 0, nullptr, 0,
+                      x_hi, m_split);
 }
 
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)

@@ -161,7 +161,10 @@ linear_chain_kernel(const ChainArgs a) {
   const int wlane = lane * 16;
   lin_f32x16 acc[MT][NT], xk[MT][NT], acc2[MODE == 0 ? MT : 1][MODE == 0 ? NT : 1];
 
-  constexpr int WD = 2;                        // weight fragments in flight (k16 steps ahead); 4 measured no faster
+#ifndef BEVMSDA_CHAIN_WD
+#define BEVMSDA_CHAIN_WD 2
+#endif
+  constexpr int WD = BEVMSDA_CHAIN_WD;         // weight fragments in flight (k16 steps ahead); 4 measured no faster at 40,000 rows
   lin_bf16x8 wf[WD + 1][NT][NPL];              // ring over k16 steps
   // column tile `tile` (32 NT columns) of a weight image with `nstep` k16 steps per 32-row tile
   auto wload = [&](__amdgpu_buffer_rsrc_t wrsrc, int tile, int nstep, int st, int sg) {

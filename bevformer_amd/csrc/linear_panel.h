@@ -66,6 +66,10 @@ struct PanelArgs {
   long seg_len;
   const int64_t *level_shapes;
   int num_levels;
+  // two row blocks (PRE = 0, K1 = 0): rows [m_split, M) of A come from xb (same row stride as x0), row m - m_split —
+  // TSA's value [history BEV ; current queries] read from its two tensors instead of from a stacked copy
+  const float *xb;
+  long m_split;
 #ifdef BEVMSDA_PANEL_DIAG
   int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
                                     //   3 activation fragments of step 0 only, 4 no panel fetch / split
@@ -239,6 +243,7 @@ linear_panel_kernel(const PanelArgs a) {
     constexpr int QPW = PPW / 4;
     const bool add = PRE == 1 && as != nullptr;
     long srow[QPW], arow[QPW];                 // DMA source row; addend row / second gathered row
+    const float *xsu[QPW];                     // DMA source matrix of the row (the second row block has its own)
     int g0[QPW], g1[QPW];
     float gs[QPW];
     int cx[QPW];                               // 16-byte column of this lane's slot: c = d_cc ^ (row & 7)
@@ -249,6 +254,11 @@ linear_panel_kernel(const PanelArgs a) {
       long gm = m0 + row;
       if (gm >= a.M) gm = a.M - 1;             // clamped rows are computed and never stored
       srow[u] = arow[u] = gm;
+      xsu[u] = xs;
+      if (PRE == 0 && a.xb != nullptr && gm >= a.m_split) {
+        xsu[u] = a.xb + kb;
+        srow[u] = gm - a.m_split;
+      }
       g0[u] = 0; g1[u] = -1; gs[u] = 1.f;
       if (PRE == 2) {
         g0[u] = a.gidx[gm * 2];
@@ -268,7 +278,7 @@ linear_panel_kernel(const PanelArgs a) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         if (PANEL_DIAG(a, 4)) break;
-        const float *src = xs + srow[u] * ldx + (2 * p) * 32 + cx[u] * 4;
+        const float *src = xsu[u] + srow[u] * ldx + (2 * p) * 32 + cx[u] * 4;
         unsigned char *dst = lds + ((wave * QPW + u) * 4 + p) * 2048;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
                                          (__attribute__((address_space(3))) void *)(dst), 16, 0, LDAUX);

@@ -222,11 +222,34 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     v._bevmsda_partial = True
         if tsa_value is not None:
             w, b = ops.merged_linear_params(self, *[m.value_proj for m in tsas], slot="_merged_tsa_value")
-            y = ops.linear(tsa_value, w, b, groups=L, out_dtype=store, tag="tsa_value_proj")
+            if isinstance(tsa_value, tuple):
+                # (history (1, Q, C), current (1, Q, C)): the two row blocks of stack([prev_bev, bev_query]) read where
+                # they lie (ops.linear_rows2) — the stack itself is 82 MB written and read per base frame
+                hist, cur = tsa_value
+                y = ops.linear_rows2(hist.reshape(-1, hist.shape[-1]), cur.reshape(-1, cur.shape[-1]), w, b, groups=L,
+                                     out_dtype=store, tag="tsa_value_proj")
+                nb, nv = 2, hist.shape[1]
+                if y is None:
+                    y = ops.linear(torch.stack([hist, cur], 1).reshape(2, nv, -1), w, b, groups=L, out_dtype=store,
+                                   tag="tsa_value_proj")
+            else:
+                y = ops.linear(tsa_value, w, b, groups=L, out_dtype=store, tag="tsa_value_proj")
+                nb, nv = tsa_value.shape[0], tsa_value.shape[1]
             if y is not None:
                 M = tsas[0].num_heads
-                tsa_vals = [y[i].view(tsa_value.shape[0], tsa_value.shape[1], M, -1) for i in range(L)]
+                tsa_vals = [y[i].view(nb, nv, M, -1) for i in range(L)]
         return sca_vals, tsa_vals
+
+    def _stack_free(self, history, bev_query, bs):
+        """May the layers run without the stacked [history, bev_query] tensor?  Inference at bs = 1 on the GPU with every
+        layer's first attention the stock ``TemporalSelfAttention`` (a subclass or another module may read ``value``)."""
+        from .temporal_self_attention import TemporalSelfAttention
+        if bs != 1 or not ops.modes().stack_free or torch.is_grad_enabled() or self.training or not history.is_cuda \
+                or len(self.layers) < 2 \
+                or ops.gemm_mode() == "native" or history.dtype != torch.float32 or bev_query.dtype != torch.float32 \
+                or history.shape != bev_query.shape:
+            return False
+        return all(type(getattr(layer, "attentions", [None])[0]) is TemporalSelfAttention for layer in self.layers)
 
     def hoisted_value_projections_autograd(self, value, tsa_value):
         """``hoisted_value_projections`` with gradients (train_ops.grouped_linear): camera features (Nc, S, bs, C) ->
@@ -296,14 +319,24 @@ class BEVFormerEncoder(TransformerLayerSequence):
         if prev_bev is not None:
             prev_bev = prev_bev.permute(1, 0, 2)
             history = prev_bev
-            prev_bev = torch.stack([prev_bev, bev_query], 1).reshape(bs * 2, len_bev, -1)
+            prev_bev = None                 # stack([history, bev_query]): built below, only if something reads it
             hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
         else:
             hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
 
         output = bev_query
         intermediate = []
-        sca_vals, tsa_vals = self.hoisted_value_projections(value, prev_bev)
+        # TSA's value is stack([history, bev_query]).  Inference, bs = 1: the grouped value projection reads the two tensors
+        # where they lie and every layer's TSA gets its projected value and the history rows — nothing reads the stacked
+        # tensor (82 MB written + read per base frame), a (2, Q, C) VIEW of the history stands in for it (value[:1] IS the
+        # history; TemporalSelfAttention reads nothing else of it when ``tsa_projected_value`` is given)
+        stack_free = history is not None and self._stack_free(history, bev_query, bs)
+        if history is not None and not stack_free:
+            prev_bev = torch.stack([history, bev_query], 1).reshape(bs * 2, len_bev, -1)
+        sca_vals, tsa_vals = self.hoisted_value_projections(value, (history, bev_query) if stack_free else prev_bev)
+        if stack_free:
+            prev_bev = history.expand(2, len_bev, history.shape[-1]) if tsa_vals is not None \
+                else torch.stack([history, bev_query], 1).reshape(bs * 2, len_bev, -1)
         share = None
         fast_train = False
         if sca_vals is None and tsa_vals is None and value.is_cuda and self._train_fast_path(value.device):

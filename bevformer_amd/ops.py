@@ -892,6 +892,55 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
     return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
 
 
+def linear_rows2(x_lo, x_hi, weight, bias=None, *, groups=1, out_dtype=torch.float32, tag="linear"):
+    """``linear(cat([x_lo, x_hi], 0), ...)`` with the two row blocks read where they lie
+    (``bevmsda_linear_panel_rows2_f32``): x_lo (M0, K), x_hi (M1, K) fp32, K = 256 — TSA's value
+    ``stack([prev_bev, bev_query])`` projected without forming the stack.  Returns (groups, M0 + M1, N / groups), or
+    ``None`` when not covered (the caller stacks and calls ``linear``)."""
+    mode = _m().gemm
+    if mode == "native" or not x_lo.is_cuda or torch.is_grad_enabled() and (x_lo.requires_grad or x_hi.requires_grad
+                                                                            or weight.requires_grad):
+        return None
+    if x_lo.dtype != torch.float32 or x_hi.dtype != torch.float32 or weight.dtype != torch.float32:
+        return None
+    N, K = weight.shape
+    if x_lo.shape[-1] != K or x_hi.shape[-1] != K or not _m().gemm_pack or _m().gemm_variant is not None \
+            or not _panel_covers(N, K, 0, groups, False, None) or N % groups or (N // groups) % 128:
+        return None
+    lo, ld0 = _rows2d(x_lo, K)
+    hi, ld1 = _rows2d(x_hi, K)
+    if ld0 != ld1:
+        return None
+    M0, M1 = lo.shape[0], hi.shape[0]
+    M, ncol = M0 + M1, N // groups
+    if M0 == 0 or M1 == 0 or out_dtype not in (torch.float32, torch.bfloat16):
+        return None
+    w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0) else weight.contiguous()
+    b = None
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != N:
+            return None
+        b = bias.contiguous()
+    blob = panel_weight(w)
+    if blob is None:
+        return None
+    y = torch.empty((groups, M, ncol), dtype=out_dtype, device=x_lo.device)
+    desc = _lib.LinearDesc(M=M, ldx0=ld0, lda0=0, ldx1=0, lda1=0, ldw=w.stride(0), ldy=ncol, N=N, K0=K, K1=0, relu=0,
+                           precision=0 if mode == "split" else 1, group_cols=ncol if groups > 1 else 0,
+                           out_bf16=int(out_dtype == torch.bfloat16))
+    desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(_m().gemm_kernel) \
+        or (2 if M >= (1 << 17) else 1)
+    cb = _GEMM_TIMER["cb"]
+    ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)) if cb is not None else _NoTimer()
+    with torch.cuda.device(x_lo.device), ctx:
+        rc = _lib.load().bevmsda_linear_panel_rows2_f32(_ptr(lo), _ptr(hi), M0, _ptr(blob), _ptr(b) if b is not None else None,
+                                                        ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
+        return None
+    _lib.check(rc, "linear_rows2")
+    return y
+
+
 def linear_gather_mean(rows, idx, scale, weight, bias=None, *, tag="linear"):
     """``linear(gather_mean(rows, idx, scale), weight, bias)`` in one kernel
     (``bevmsda_linear_gather_packed_f32``): the camera mean of SpatialCrossAttention folded into

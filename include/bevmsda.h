@@ -464,6 +464,13 @@ int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, 
                              const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,
                              void *stream);
 
+/* bevmsda_linear_panel_f32 whose A has TWO ROW BLOCKS in two tensors: rows [0, m_split) = x_lo, rows [m_split, desc->M) =
+ * x_hi (row m - m_split; both with row stride desc->ldx0; K1 = 0, no addends / gather / LayerNorm).  The value tensor of
+ * TemporalSelfAttention is torch.stack([prev_bev, bev_query]) (encoder.py:216-222 of the reference): its projection reads the
+ * history BEV and the current queries where they lie instead of from a stacked copy (82 MB written and read per frame). */
+int bevmsda_linear_panel_rows2_f32(const float *x_lo, const float *x_hi, int64_t m_split, const uint16_t *wpanel, const float *bias,
+                                   const bevmsda_linear_desc *desc, float *y, void *stream);
+
 /* bevmsda_linear_panel_f32 over ROW SEGMENTS of which only some are needed (BEV tiling over GPUs, SURVEY.md §8e: the
  * camera-feature value projection is a replicated input, but a rank's queries see only some of the cameras): the rows
  * form ceil(M / seg_len) segments of seg_len rows (one per (batch entry, camera)); seg_start (segments + 1, int32, DEVICE

@@ -427,6 +427,26 @@ def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, 
     assert untouched == want
 
 
+@pytest.mark.parametrize("m0,m1", [(4000, 4000), (1000, 37), (33, 5000), (64, 64), (1, 1)])
+@pytest.mark.parametrize("kernel,out", [(None, torch.float32), ("panel64", torch.bfloat16), ("panel128", torch.float32)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_linear_row_panel_two_row_blocks(gemm_mode, m0, m1, kernel, out, mode):
+    """``bevmsda_linear_panel_rows2_f32`` (TSA's value [history ; queries] projected without the stack): the same
+    kernel over the same rows — equal, bit for bit, to the launch over the concatenated tensor; a split inside a panel
+    (m0 not a multiple of 64 / 128) included."""
+    gemm_mode(mode)
+    K, N, L = 256, 1536, 6
+    lo, hi = _rand(m0, K, seed=81), _rand(m1, K, seed=82)
+    w, b = _rand(N, K, seed=83) * 0.05, _rand(N, seed=84)
+    with torch.no_grad(), ops.using(gemm_kernel=kernel):
+        got = ops.linear_rows2(lo, hi, w, b, groups=L, out_dtype=out, tag="t")
+        want = ops.linear(torch.cat([lo, hi], 0), w, b, groups=L, out_dtype=out)
+    assert got is not None and got.shape == (L, m0 + m1, N // L) and got.dtype == out
+    assert torch.equal(got, want)
+    ref = (torch.cat([lo, hi], 0).double() @ w.double().t() + b.double()).view(m0 + m1, L, N // L).transpose(0, 1)
+    assert (got.double() - ref).abs().max().item() < (5e-2 if out == torch.bfloat16 or mode == "bf16" else 1e-4)
+
+
 @pytest.mark.parametrize("kernel", ["panel64", "panel128"])
 def test_linear_row_panel_identity_with_asymmetric_weight(gemm_mode, kernel):
     """A = I picks single weights: catches a permuted k order between the activation image and the weight image,

@@ -1,6 +1,6 @@
 """Which host-side statements launch the small copy / fill / cat kernels of one encoder step?  torch.profiler with stacks over one eager
 base frame; prints every aten::copy_ / fill_ / cat / zeros-like op with its shapes and the innermost bevformer_amd frame.
-GPU box: python tools/copy_audit.py"""
+GPU box: python tools/copy_audit.py [R,G [layout]]   (R,G: the step of simulated rank R of a G-rank BEV-tiled job)"""
 import collections
 import os
 import sys
@@ -14,6 +14,10 @@ from bevformer_amd import synthetic as S  # noqa: E402
 DEV = torch.device("cuda:0")
 enc = bevformer_amd.build_transformer_layer_sequence(S.encoder_cfg("base")).eval().to(DEV)
 q, f, kw = S.make_inputs("base", seed=0, temporal=True, device=DEV)
+if len(sys.argv) > 1:
+    from bevformer_amd import bev_tiling  # noqa: E402
+    r, g = (int(v) for v in sys.argv[1].split(","))
+    bev_tiling.enable_bev_tiling(enc, simulate=(r, g), layout=sys.argv[2] if len(sys.argv) > 2 else "sectors")
 with torch.no_grad():
     for _ in range(2):
         enc(q, f, f, **kw)

@@ -24,6 +24,8 @@ for s in $steps; do
     bwd_small4_bf16) timeout 400 python bench.py --no-cpu-baseline --no-variants --backward --workload small4 --gemm bf16 --value-storage bf16 --steps 5 --warmup 2 --windows 3 ${BWD_ARGS:-} > "$out/bench_bwd_small4_bf16.json" 2> "$out/bench_bwd_small4_bf16.err"; echo "rc=$?" >> "$out/bench_bwd_small4_bf16.err"; cut -c1-500 "$out/bench_bwd_small4_bf16.json"; tail -3 "$out/bench_bwd_small4_bf16.err";;
     trace_bwd) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_bwd${TRACE_TAG:-}" python "$root/bench.py" --no-cpu-baseline --no-variants --backward --graph off --steps 3 --warmup 1 --windows 1 ${BWD_ARGS:-} > "$out/prof_bwd_summary.txt" 2>&1; head -45 "$out/prof_bwd_summary.txt" | cut -c1-170;;
     trace_fwd) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_fwd" python "$root/bench.py" --no-cpu-baseline --no-variants --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_fwd_summary.txt" 2>&1; head -30 "$out/prof_fwd_summary.txt" | cut -c1-170;;
+    trace_sim) PMC=0 PASS_TIMEOUT=240 timeout 300 tools/prof.sh "${tag}_sim" python "$root/bench.py" --no-cpu-baseline --no-variants --simulate-rank ${SIM_RANK:-3,8} --tile-layout ${SIM_LAYOUT:-sectors} --graph off --steps 3 --warmup 1 --windows 1 > "$out/prof_sim_summary.txt" 2>&1; head -45 "$out/prof_sim_summary.txt" | cut -c1-170;;
+    bench_sim) timeout 300 python bench.py --no-cpu-baseline --no-variants --simulate-rank ${SIM_RANK:-3,8} --tile-layout ${SIM_LAYOUT:-sectors} --steps 10 --warmup 3 --windows 3 > "$out/bench_sim.json" 2> "$out/bench_sim.err"; echo "rc=$?" >> "$out/bench_sim.err"; cut -c1-400 "$out/bench_sim.json"; tail -3 "$out/bench_sim.err";;
     traffic_fwd) timeout 900 python tools/profile_traffic.py --config base_fwd --tag "$tag" > "$out/traffic_fwd.log" 2>&1; tail -15 "$out/traffic_fwd.log";;
     traffic_bwd) timeout 900 python tools/profile_traffic.py --config base_bwd --tag "$tag" > "$out/traffic_bwd.log" 2>&1; tail -15 "$out/traffic_bwd.log";;
     custom) timeout ${CUSTOM_TIMEOUT:-600} bash -c "${CUSTOM_CMD}" > "$out/custom.log" 2>&1; echo "rc=$?" >> "$out/custom.log"; tail -${CUSTOM_TAIL:-60} "$out/custom.log";;
