@@ -153,6 +153,8 @@ SIGNATURES = {
     "bevmsda_linear_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                        _c_int),
+    "bevmsda_linear_pack_weight_t_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
+                                         _c_int),
     "bevmsda_rotate_bev_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int, _c_int,
                                 ctypes.POINTER(ctypes.c_float), _c_void_p], _c_int),
     "bevmsda_rotate_bev_dev_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, _c_int, _c_int, _c_int,

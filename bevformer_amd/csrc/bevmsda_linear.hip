@@ -247,8 +247,22 @@ int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, ui
   const long long threads = static_cast<long long>((N + 127) / 128) * 128 * (K / 8);
   const long long nb = (threads + 255) / 256;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+  hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel<false>, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_pack_weight_t_f32(const float *wt, int64_t ldwt, int N, int K, uint16_t *blob, void *stream) {
+  if (N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (K % 32 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldwt < N) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!wt || !blob) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(blob) || (reinterpret_cast<uintptr_t>(wt) & 3u)) return BEVMSDA_ERR_MISALIGNED;
+  const long long threads = static_cast<long long>((N + 127) / 128) * 128 * (K / 8);
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_pack_weight_kernel<true>, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), wt, static_cast<long>(ldwt), N, K, blob);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -530,6 +530,10 @@ linear_splitbf16_kernel(const LinArgs a) {
 // Weight image for WMODE > 0: for every (128-row tile nt, 32-deep chunk kc) a contiguous
 // [plane hi | plane lo][128 rows][32 + 8 pad] bf16 block (rows >= N and the pad are zero), i.e.
 // exactly the LDS image the kernel reads its B fragments from.  One thread per 8 k of a row.
+// TRANSPOSED: element (n, k) of the weight is w[k * ldw + n] — the image of W^T packed straight from W (the operand of an
+// input-gradient GEMM g W: no contiguous transpose in between; the matrices are a few hundred squared, the strided reads
+// cost nothing next to a second launch).
+template <bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__restrict__ w, long ldw, int N,
                                                              int K, uint16_t *__restrict__ blob) {
   constexpr int ROW = 40, PLANE = 128 * ROW;
@@ -541,8 +545,14 @@ __global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__res
   const int k = static_cast<int>(t % (K / 8)) * 8;
   uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
   if (n < N) {
-    const float4 *src = reinterpret_cast<const float4 *>(w + static_cast<long>(n) * ldw + k);
-    lin_split8<true>(src[0], src[1], hi, lo);
+    if constexpr (TRANSPOSED) {
+      const float *src = w + static_cast<long>(k) * ldw + n;
+      lin_split8<true>(make_float4(src[0], src[ldw], src[2 * ldw], src[3 * ldw]),
+                       make_float4(src[4 * ldw], src[5 * ldw], src[6 * ldw], src[7 * ldw]), hi, lo);
+    } else {
+      const float4 *src = reinterpret_cast<const float4 *>(w + static_cast<long>(n) * ldw + k);
+      lin_split8<true>(src[0], src[1], hi, lo);
+    }
   }
   uint16_t *chunk = blob + (static_cast<long>(n / 128) * kch + k / 32) * (2 * PLANE);
   const int off = (n % 128) * ROW + (k % 32);

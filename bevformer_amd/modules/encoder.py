@@ -139,6 +139,23 @@ class BEVFormerEncoder(TransformerLayerSequence):
             return False
         return all(getattr(layer, "chain_trainable", lambda: False)() for layer in self.layers)
 
+    def _flatten_projection_params(self):
+        """Training fast path, once: lay the parameters of every merged projection back to back in memory
+        (``ops.flatten_linear_params``) — the value projections of all layers (one grouped GEMM per family) and each
+        attention's sampling-offset + attention-weight pair — so that their concatenations are views."""
+        if self.__dict__.get("_flat_params") or not ops.modes().flatten_params or torch.cuda.is_current_stream_capturing():
+            return
+        atts = [getattr(layer, "attentions", None) for layer in self.layers]
+        if any(a is None or len(a) != 2 or not hasattr(a[1], "deformable_attention") for a in atts):
+            return
+        tsas = [a[0] for a in atts]
+        scas = [a[1].deformable_attention for a in atts]
+        ops.flatten_linear_params(*[m.value_proj for m in scas])
+        ops.flatten_linear_params(*[m.value_proj for m in tsas])
+        for m in tsas + scas:
+            ops.flatten_linear_params(m.sampling_offsets, m.attention_weights)
+        self.__dict__["_flat_params"] = True
+
     def _contiguous_pos(self, pos):
         """``pos`` (bs, Q, C) with unit stride along C.  The positional encoding of the BEV grid does not change from
         frame to frame: at inference the copy is kept for as long as the caller hands in the same (unmodified) memory —
@@ -340,6 +357,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         share = None
         fast_train = False
         if sca_vals is None and tsa_vals is None and value.is_cuda and self._train_fast_path(value.device):
+            self._flatten_projection_params()
             # autograd fast path: the same two grouped GEMMs as autograd Functions (their backward sums the six input
             # gradients in the GEMM epilogues); with bs = 1 the history BEV and the current queries stay two tensors
             # (no gradient is formed for a detached history)

@@ -654,10 +654,16 @@ def _cache_ok(weight):
     return not (weight.requires_grad and weight.is_cuda and torch.cuda.is_current_stream_capturing())
 
 
+def _is_transposed_view(w):
+    """(N, K) tensor whose memory is the row-major (K, N) matrix (``m.t()`` of a matrix with unit column stride)."""
+    return w.dim() == 2 and w.shape[0] > 1 and w.shape[1] > 1 and w.stride(0) == 1 and w.stride(1) >= w.shape[0]
+
+
 def packed_weight(weight):
     """Pre-split bf16 image of an (N, K) fp32 weight (``bevmsda_linear_pack_weight_f32``),
-    cached on the tensor object until it is written to or moved."""
-    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    cached on the tensor object until it is written to or moved.  A transposed view (``_is_transposed_view``) is packed
+    from the memory it aliases (``bevmsda_linear_pack_weight_t_f32``)."""
+    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_pack", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
         return hit[1]
@@ -668,8 +674,12 @@ def packed_weight(weight):
         return None
     blob = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
     with torch.cuda.device(weight.device):
-        rc = lib.bevmsda_linear_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
-                                                torch.cuda.current_stream().cuda_stream)
+        if _is_transposed_view(weight):
+            rc = lib.bevmsda_linear_pack_weight_t_f32(_ptr(weight), weight.stride(1), N, K, _ptr(blob),
+                                                      torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = lib.bevmsda_linear_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
+                                                    torch.cuda.current_stream().cuda_stream)
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return None
     _lib.check(rc, "linear_pack_weight")
@@ -827,8 +837,15 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
             if x2_add.shape != x2.shape or x2_add.dtype != torch.float32:
                 return None
             a1, lda1 = _rows2d(x2_add, K1)
-    w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0
-                   and weight.data_ptr() % 16 == 0) else weight.contiguous()
+    # a transposed VIEW of a row-major matrix (``transposed_weight``: the operand of an input-gradient GEMM) stays a view
+    # when its weight image can be packed straight from it (first kernel over the packed image)
+    tview = _is_transposed_view(weight) and _m().gemm_pack and _m().gemm_variant is None \
+        and not _panel_covers(N, K0, K1, groups, False, M)
+    if tview:
+        w = weight
+    else:
+        w = weight if (weight.stride(1) == 1 and weight.stride(0) % 4 == 0
+                       and weight.data_ptr() % 16 == 0) else weight.contiguous()
     b = None
     if bias is not None:
         if bias.dtype != torch.float32 or bias.numel() != N:
@@ -866,6 +883,9 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
             return y.view(groups, *lead, ncol) if groups > 1 else y.view(*lead, N)
     variant = _m().gemm_variant
     blob = packed_weight(w) if _m().gemm_pack and (variant is None or variant >= 4) else None
+    if tview and blob is None:
+        w = weight.contiguous()
+        desc.ldw = w.stride(0)
     if variant is not None and (variant >= 4) == (blob is not None):
         desc.variant = 1 + variant
     elif blob is not None and _m().gemm_kernel == "pipe" and accumulate_into is None:
@@ -1204,8 +1224,12 @@ def proj_ln_proj_chain(rows, weight, bias, res, norm0, w1, b1, *, tag="proj_ln_p
 
 
 def transposed_weight(weight):
-    """Contiguous ``weight.t()`` cached on the tensor until it is written to: the operand of the
-    input-gradient GEMM of ``_LinearFunction`` (packed again by ``packed_weight``)."""
+    """``weight.t()`` as the operand of an input-gradient GEMM: with weight packing on, the VIEW (``packed_weight`` builds
+    the MFMA image straight from the aliased memory; ``linear`` copies it only for a kernel that wants the matrix);
+    otherwise a contiguous copy cached on the tensor until it is written to."""
+    if weight.is_cuda and weight.dim() == 2 and weight.stride(1) == 1 and _m().gemm_pack and _m().gemm != "native" \
+            and _m().weight_views and weight.data_ptr() % 4 == 0:
+        return weight.detach().t()
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape))
     hit = getattr(weight, "_bevmsda_wt", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
@@ -1404,13 +1428,79 @@ def linear_or_torch(x, weight, bias=None, *, relu=False, tag="linear", thread=No
     return y
 
 
+def _adjacent(tensors):
+    """Do the tensors lie back to back in one storage (``flatten_linear_params``), so that their row-wise concatenation is
+    a view?"""
+    t0 = tensors[0]
+    if not all(t.is_contiguous() and t.dtype == t0.dtype and t.device == t0.device and t.shape[1:] == t0.shape[1:]
+               for t in tensors):
+        return False
+    st = t0.untyped_storage().data_ptr()
+    end = t0.data_ptr() + t0.numel() * t0.element_size()
+    for t in tensors[1:]:
+        if t.untyped_storage().data_ptr() != st or t.data_ptr() != end:
+            return False
+        end += t.numel() * t.element_size()
+    return True
+
+
+def flatten_linear_params(*linears):
+    """Re-seat the weights (and biases) of ``nn.Linear`` layers that share their input back to back in ONE buffer each
+    (``p.data`` becomes a view of it; values, Parameter objects, state_dict keys and optimizer state are untouched):
+    their concatenation — the operand of the merged projection — is then a VIEW (``merged_linear_params``), where a
+    training step paid a ``cat`` per group and step plus the copies of its backward.  Idempotent; a later ``.to()`` /
+    ``.float()`` of the module gives every parameter its own storage again and the merge falls back to ``cat``."""
+    ws, bs = [m.weight for m in linears], [m.bias for m in linears]
+    if any(b is None for b in bs) or len({w.shape[1] for w in ws}) != 1:
+        return False
+    with torch.no_grad():
+        for group in (ws, bs):
+            if _adjacent([p.data for p in group]):
+                continue
+            flat = torch.cat([p.data for p in group], 0)
+            o = 0
+            for p in group:
+                n = p.shape[0]
+                p.data = flat[o:o + n]
+                o += n
+    return True
+
+
+class _MergedParams(torch.autograd.Function):
+    """(cat of the weights, cat of the biases) as VIEWS of the buffers the parameters were flattened into; the
+    backward hands every parameter its block of the merged gradient, a view as well."""
+
+    @staticmethod
+    def forward(ctx, nw, *params):
+        ws, bs = params[:nw], params[nw:]
+        ctx.rows = [w.shape[0] for w in ws]
+        K = ws[0].shape[1]
+        N = sum(ctx.rows)
+        w = ws[0].detach().as_strided((N, K), (K, 1))
+        b = bs[0].detach().as_strided((N,), (1,))
+        return w, b
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        out_w, out_b, o = [], [], 0
+        for n in ctx.rows:
+            out_w.append(None if gw is None else gw[o:o + n])
+            out_b.append(None if gb is None else gb[o:o + n])
+            o += n
+        return (None, *out_w, *out_b)
+
+
 def merged_linear_params(owner, *linears, slot="_merged_linear"):
     """``cat`` of the weights / biases of ``nn.Linear`` layers that share their input (the
     sampling-offset and attention-weight projections; the value projections of all encoder
     layers), cached on ``owner`` while nothing needs a gradient and the parameters have not
-    been written to."""
+    been written to.  Under autograd: a view when the parameters were laid out back to back
+    (``flatten_linear_params``), else ``torch.cat``."""
     if torch.is_grad_enabled() and any(p.requires_grad for m in linears for p in (m.weight, m.bias)):
-        return (torch.cat([m.weight for m in linears], 0), torch.cat([m.bias for m in linears], 0))
+        ws, bs = [m.weight for m in linears], [m.bias for m in linears]
+        if all(b is not None for b in bs) and _adjacent(ws) and _adjacent(bs):
+            return _MergedParams.apply(len(ws), *ws, *bs)
+        return (torch.cat(ws, 0), torch.cat(bs, 0))
     key = tuple((_ver(m.weight), _ver(m.bias), m.weight.data_ptr(), m.bias.data_ptr())
                 for m in linears)
     hit = owner.__dict__.get(slot)

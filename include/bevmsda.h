@@ -366,6 +366,10 @@ int bevmsda_linear_f32(const float *x0, const float *a0, const float *x1, const 
 int64_t bevmsda_linear_packed_bytes(int N, int K);
 int bevmsda_linear_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob,
                                    void *stream);
+/* The same image of the (N, K) weight whose TRANSPOSE is what lies in memory: wt (K, ldwt), element (n, k) = wt[k * ldwt + n].
+ * The input gradient of a Linear layer, g W, is the projection of g by W^T: its weight image is packed straight from the
+ * layer's own weight — no contiguous transpose per training step.  wt 4-byte aligned, ldwt >= N. */
+int bevmsda_linear_pack_weight_t_f32(const float *wt, int64_t ldwt, int N, int K, uint16_t *blob, void *stream);
 int bevmsda_linear_packed_f32(const float *x0, const float *a0, const float *x1, const float *a1,
                               const uint16_t *wpack, const float *bias,
                               const bevmsda_linear_desc *desc, float *y, void *stream);

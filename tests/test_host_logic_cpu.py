@@ -176,3 +176,41 @@ def test_fused_sampling_rejects_unknown_options():
         ops.msda_fused(v, None, None, torch.zeros(2, 96), 64, torch.zeros(2, 1, 4, 2), None, launch_row=3, **common)
     with pytest.raises(RuntimeError, match="no CPU path"):      # retired names pass the keyword check (and then: CPU tensor)
         ops.msda_fused(v, None, None, torch.zeros(2, 96), 64, torch.zeros(2, 1, 4, 2), None, cam_start=None, **common)
+
+
+def test_flattened_linear_params_merge_as_views_with_the_same_gradients():
+    """``ops.flatten_linear_params``: the parameters of Linear layers that share their input are re-seated back to back
+    (values, Parameter objects and state_dict untouched); ``merged_linear_params`` under autograd is then a view whose
+    backward hands every parameter its block — same gradients as the ``cat`` form, and the view follows optimizer steps."""
+    import torch
+    from bevformer_amd import ops
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(8, 6), torch.nn.Linear(8, 4)
+    ref_a, ref_b = torch.nn.Linear(8, 6), torch.nn.Linear(8, 4)
+    ref_a.load_state_dict(a.state_dict())
+    ref_b.load_state_dict(b.state_dict())
+    ids = [id(p) for p in list(a.parameters()) + list(b.parameters())]
+    assert not ops._adjacent([a.weight, b.weight])
+    assert ops.flatten_linear_params(a, b) and ops.flatten_linear_params(a, b)          # idempotent
+    assert ids == [id(p) for p in list(a.parameters()) + list(b.parameters())]
+    assert all(torch.equal(p, q) for p, q in zip(list(a.parameters()) + list(b.parameters()),
+                                                 list(ref_a.parameters()) + list(ref_b.parameters())))
+    assert ops._adjacent([a.weight, b.weight]) and ops._adjacent([a.bias, b.bias])
+
+    class Owner:
+        pass
+    w, bias = ops.merged_linear_params(Owner(), a, b)
+    assert w.data_ptr() == a.weight.data_ptr() and bias.data_ptr() == a.bias.data_ptr()
+    x = torch.randn(3, 8)
+    (x @ w.t() + bias).pow(2).sum().backward()
+    (x @ torch.cat([ref_a.weight, ref_b.weight]).t() + torch.cat([ref_a.bias, ref_b.bias])).pow(2).sum().backward()
+    for p, q in zip(list(a.parameters()) + list(b.parameters()), list(ref_a.parameters()) + list(ref_b.parameters())):
+        torch.testing.assert_close(p.grad, q.grad)
+    torch.optim.SGD(list(a.parameters()) + list(b.parameters()), lr=0.1).step()
+    w2, _ = ops.merged_linear_params(Owner(), a, b)
+    assert torch.equal(w2, torch.cat([a.weight, b.weight])) and not torch.equal(w2, torch.cat([ref_a.weight, ref_b.weight]))
+    # a module that was moved / cast afterwards owns separate storages again: the merge is a cat, still correct
+    a.double(), b.double()
+    a.float(), b.float()
+    w3, _ = ops.merged_linear_params(Owner(), a, b)
+    assert torch.equal(w3, torch.cat([a.weight, b.weight]))

@@ -427,6 +427,25 @@ def test_linear_row_panel_skips_unused_row_segments(gemm_mode, kernel, seg_len, 
     assert untouched == want
 
 
+@pytest.mark.parametrize("n,k,col0", [(256, 256, 0), (256, 768, 0), (512, 192, 0), (200, 96, 0), (256, 192, 256)])
+def test_weight_image_packed_from_the_transposed_matrix(gemm_mode, n, k, col0):
+    """``bevmsda_linear_pack_weight_t_f32``: the image of W^T built from W where it lies (a transposed view, also of a
+    column block of a wider matrix — the two halves of TSA's two-source weight) is the image of the contiguous
+    transpose, byte for byte; ``ops.linear`` over the view equals ``ops.linear`` over the copy."""
+    gemm_mode("split")
+    wide = _rand(k, col0 + n + 8, seed=91)          # W: (k = out features, in features ...), row-major
+    view = wide[:, col0:col0 + n].t()                # (n, k) view of W[:, col0 : col0 + n]^T
+    assert ops._is_transposed_view(view)
+    blob_t = ops.packed_weight(view)
+    blob_c = ops.packed_weight(view.contiguous())
+    assert blob_t is not None and torch.equal(blob_t, blob_c)
+    x = _rand(777, k, seed=92)
+    with torch.no_grad(), ops.using(gemm_kernel="first"):
+        got = ops.linear(x, view, None, _inside_autograd=True)
+        want = ops.linear(x, view.contiguous(), None, _inside_autograd=True)
+    assert got is not None and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("m0,m1", [(4000, 4000), (1000, 37), (33, 5000), (64, 64), (1, 1)])
 @pytest.mark.parametrize("kernel,out", [(None, torch.float32), ("panel64", torch.bfloat16), ("panel128", torch.float32)])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
