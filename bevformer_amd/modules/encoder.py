@@ -358,6 +358,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         fast_train = False
         if sca_vals is None and tsa_vals is None and value.is_cuda and self._train_fast_path(value.device):
             self._flatten_projection_params()
+            from .. import train_ops
+            train_ops.begin_step(sum(p.numel() for p in self.parameters() if p.requires_grad))
             # autograd fast path: the same two grouped GEMMs as autograd Functions (their backward sums the six input
             # gradients in the GEMM epilogues); with bs = 1 the history BEV and the current queries stay two tensors
             # (no gradient is formed for a detached history)

@@ -454,7 +454,7 @@ class _FusedSampleFunction(Function):
         if ctx.value_sink is not None:
             sink, slot = ctx.value_sink
             sink[slot] = gv
-            gv_out = torch.zeros((), dtype=ctx.value_dtype, device=dev).expand(value.shape)
+            gv_out = _zero_scalar(ctx.value_dtype, dev).expand(value.shape)
         else:
             gv_out = gv.to(ctx.value_dtype)
         return gv_out, gproj, None, None, None, None, None, None, None, None, None, None, None, None, None
@@ -652,6 +652,21 @@ def _cache_ok(weight):
     captured over a TRAINABLE weight: the replayed graph must rebuild them from the weight's current values (an optimizer
     step between replays changes them without the capture noticing), so the conversion kernels are captured too."""
     return not (weight.requires_grad and weight.is_cuda and torch.cuda.is_current_stream_capturing())
+
+
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(dtype, device):
+    """A 0-d zero per (dtype, device), made once (outside any stream capture): the zero-stride placeholder gradients of
+    tensors whose real gradient travels through a sink."""
+    key = (dtype, torch.device(device))
+    z = _ZERO_SCALARS.get(key)
+    if z is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros((), dtype=dtype, device=device)
+        z = _ZERO_SCALARS[key] = torch.zeros((), dtype=dtype, device=device)
+    return z
 
 
 def _is_transposed_view(w):

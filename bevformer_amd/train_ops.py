@@ -177,10 +177,38 @@ def _wgrad_multi(problems, tag):
     _lib.check(rc, "linear_wgrad_multi")
 
 
+# Parameter-gradient accumulators of one backward pass: the weight-gradient kernels ADD into zeroed buffers.  ``begin_step``
+# (the encoder's forward, which knows the parameter count) arms an arena; the first ``_zeros`` of the backward pass
+# allocates and clears it in ONE fill and every later call carves its views out of it (20 launches of a few microseconds
+# each per base frame otherwise).  Whatever does not fit gets its own buffer.
+_ARENA = {"floats": 0, "buf": None, "used": 0}
+
+
+def begin_step(param_floats):
+    """Arm the gradient arena for the backward pass of the forward that is being recorded."""
+    _ARENA["floats"] = int(param_floats) + 64
+    _ARENA["buf"] = None
+    _ARENA["used"] = 0
+
+
 def _zeros(device, *shapes):
     """One zero fill for several accumulators: views of a single buffer (every size a multiple of 4 floats)."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
-    buf = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    total = sum(sizes)
+    buf = None
+    if _ARENA["floats"] and total % 4 == 0:
+        if _ARENA["buf"] is None:
+            _ARENA["buf"] = torch.zeros(_ARENA["floats"], dtype=torch.float32, device=device)
+            _ARENA["used"] = 0
+        a = _ARENA["buf"]
+        if a.device == torch.device(device) and _ARENA["used"] + total <= a.numel():
+            buf = a[_ARENA["used"]:_ARENA["used"] + total]
+            _ARENA["used"] += total
+            if _ARENA["used"] + 1024 > a.numel():          # spent: the next backward pass starts a fresh one
+                _ARENA["buf"] = None
+                _ARENA["floats"] = 0
+    if buf is None:
+        buf = torch.zeros(total, dtype=torch.float32, device=device)
     out, o = [], 0
     for s, n in zip(shapes, sizes):
         out.append(buf[o:o + n].view(*s))
@@ -348,9 +376,11 @@ class _TwoSourceLinearFunction(Function):
         dW = db = None
         if ni[3] or (ctx.has_b and ni[4]):
             dW, db = _zeros(w.device, (N, K0 + K1), (N,))
-            qp = query if not ctx.has_pos else query + pos
-            _wgrad_multi([(g2, first.reshape(-1, K0), dW[:, :K0], db), (g2, qp.reshape(-1, K1), dW[:, K0:], None)],
-                         ctx.tag + "_dw")
+            # (x2 = query + pos: g^T x2 = g^T query + g^T pos — a third problem ADDING into the same block instead of an add pass)
+            probs = [(g2, first.reshape(-1, K0), dW[:, :K0], db), (g2, query.reshape(-1, K1), dW[:, K0:], None)]
+            if ctx.has_pos:
+                probs.append((g2, pos.reshape(-1, K1), dW[:, K0:], None))
+            _wgrad_multi(probs, ctx.tag + "_dw")
         d_pos = None
         if ctx.has_pos and ni[2]:
             d_pos = d_q if not ni[1] else d_q.clone()      # (one buffer per consumer: either may be added into)
