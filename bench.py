@@ -539,16 +539,17 @@ def oracle_frame(workload, first_frame):
         return O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
 
 
-def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 8)):
+def multi_gpu_model(args, dev, fence, gemm, t1_ms, replicated_us, worlds=(2, 4, 8), storage="fp32"):
     """What the BEV-tiled schedule costs per rank, measured on THIS GPU one rank at a time
     (bev_tiling.BevTiling.simulate: every kernel of rank r's step, the all-gather replaced by a local copy),
     plus a stated model of the all-gather.  Strong-scaling efficiency modelled from it = t1 / (G * T_G) with
     T_G = max over ranks + all-gather.  NOT a multi-GPU measurement: one GPU per box here."""
     from bevformer_amd import bev_tiling
     LINK_GBS, LAT_US = 50.0, 20.0
-    cfg = Config(args, dev, "base", gemm, "fp32", False, args.first_frame, 1, False)
+    cfg = Config(args, dev, "base", gemm, storage, False, args.first_frame, 1, False)
     cfg.modes()
-    out = {"assumptions": {"xgmi_link_GBs_per_direction": LINK_GBS, "collective_latency_us": LAT_US,
+    out = {"arithmetic": {"gemm": gemm, "value_storage": storage},
+           "assumptions": {"xgmi_link_GBs_per_direction": LINK_GBS, "collective_latency_us": LAT_US,
                            "all_gather": "direct: every rank sends its (Q/G, 256) fp32 shard to the G - 1 peers over "
                                          "min(G - 1, 7) links in parallel"},
            "t1_ms": t1_ms, "replicated_value_projections_us": replicated_us,
@@ -870,6 +871,10 @@ def main():
                 if gs is not None:
                     rep = sum(gs["per_tag"][t]["avg_us"] for t in ("sca_value_proj", "tsa_value_proj") if t in gs["per_tag"])
                 line["multi_gpu_model"] = multi_gpu_model(args, dev, fence, gemm, line["ms_per_step"], rep)
+                # the same model in the arithmetic BASELINE configs[4] names (bf16 value storage, bf16-input GEMMs): the
+                # replicated projections are MFMA work, a third of it there, so the schedule's Amdahl bound moves
+                line["multi_gpu_model_bf16"] = multi_gpu_model(args, dev, fence, "bf16", v["bf16"]["ms_per_step"], None,
+                                                               storage="bf16")
                 line["native_fp32_ms_per_step"] = v["native_fp32"]["ms_per_step"]
                 ok = ok and all(x["parity"]["ok"] for x in v.values() if "parity" in x)
     else:

@@ -731,6 +731,42 @@ def panel_weight(weight):
     return blob
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# ONE table for every measured threshold that picks a projection kernel.  The Python-side rules read
+# their numbers from here; the rules that live in the library (csrc/bevmsda_linear.hip: the library must choose when it
+# is called without this package) are listed with the constant that holds them, and tests/test_host_logic_cpu.py checks
+# that the two agree and that every profile named exists.
+#   rule                       value    what it picks                                          measured                         profile
+KERNEL_SELECTION = {
+    "panel_min_cols":          (1024,   "row-panel kernel for plain projections with N >= this (the hoisted value projections)",
+                                "split mode: camera values 572 (64-row) / 556 (128-row) vs 630 us on the first kernel, BEV values 254 vs 270 us",
+                                "profiles/r3/r3a_gemm_ab_first_vs_panel.txt"),
+    "panel_two_source_rows":   (16384,  "row-panel kernel (64-row panels) for the K = 512 two-source projection up to this many rows",
+                                "a rank's step of an 8-way tiled frame 1.56 -> 1.49 ms (6 launches of 5,000 rows: 19.0 vs 26.1 us isolated, tools/tsa_proj_small_m.py); level from 20,000 rows on",
+                                "profiles/r3/r3r_bench_default_sector_tiles_small_m_panel.json"),
+    "panel_128_rows":          (1 << 17, "128-row panels (8 wavefronts, half the weight traffic per MFMA) from this many rows on",
+                                "camera values (184,950 rows) 556 vs 572 us on 64-row panels; BEV values (80,000 rows) 267 vs 254 us: 64-row panels stay ahead",
+                                "profiles/r3/r3a_gemm_ab_first_vs_panel.txt"),
+    "layernorm_fused":         (True,   "row-panel kernel whenever the residual + LayerNorm epilogue is wanted (N = 256)",
+                                "output_proj + LN 45.4 vs 51.6 us, fc2 + LN 59.3 vs 66.1 us against two launches",
+                                "profiles/r3/r3a_gemm_ab_first_vs_panel.txt"),
+    # ---- in the library (constants of csrc/bevmsda_linear.hip)
+    "pipe_max_rows":           (8192,   "kLinearPipeMaxRows: software-pipelined kernel for first-kernel calls of up to this many rows",
+                                "13.1-19.9 vs 14.7-23.0 us at 2,500-5,000 rows; level at 10,000, behind from 20,000 rows on",
+                                "profiles/r2/r2_gemm_small_m.txt"),
+    "chain_small_rows":        (8192,   "kChainSmallRows: 32-row workgroups of the chain kernels up to this many rows",
+                                "FFN tail 20.9 vs 28.5 us at 5,000 rows, 33.5 vs 31.1 at 10,000 (the crossover), 56.8 vs 62.0 at 20,000",
+                                "profiles/r3/r3k_chain_small_m.txt"),
+    "chain_mixed_rows":        (256 * 64, "chain kernels: whole rounds of 64-row workgroups + the tail on 32-row ones from this many rows on",
+                                "103.2-103.6 vs 106.6-107.2 us and 100.4-101.5 vs 103.8-105.7 us at 40,000 rows",
+                                "profiles/r4/r4f_chain_mixed_shape_ab.txt"),
+}
+
+
+def _sel(name):
+    return KERNEL_SELECTION[name][0]
+
+
 def _panel_covers(N, K0, K1, groups, ln, M=None):
     """Shapes ``bevmsda_linear_panel_f32`` takes (include/bevmsda.h) and, unless a kernel is forced, the ones it is
     faster on (tools/gemm_ab.py, profiles/r3): the hoisted value projections (N >= 1024: 510-570 vs 630 us and 254 vs
@@ -740,7 +776,8 @@ def _panel_covers(N, K0, K1, groups, ln, M=None):
     the plain per-layer projections (N <= 768, 40 k rows) stay on the first kernel (30-70 us, 5-10 % ahead)."""
     K = K0 + K1
     kern = _m().gemm_kernel
-    want = (ln or N >= 1024 or (K1 > 0 and M is not None and M <= 16384)) if kern is None else kern.startswith("panel")
+    want = ((ln and _sel("layernorm_fused")) or N >= _sel("panel_min_cols")
+            or (K1 > 0 and M is not None and M <= _sel("panel_two_source_rows"))) if kern is None else kern.startswith("panel")
     if not want or _m().gemm_variant is not None or K not in (256, 512) or K0 not in (256, 512) \
             or K1 not in (0, 256) or N % 4:
         return False
@@ -761,7 +798,7 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
         return False
     # panel shape: 128-row panels (half the weight traffic per MFMA, one workgroup per CU) pay from ~128 k rows on
     desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(_m().gemm_kernel) \
-        or (2 if desc.M >= (1 << 17) and ln is None else 1)
+        or (2 if desc.M >= _sel("panel_128_rows") and ln is None else 1)
     desc.reserved[3] = {"panel64w2": 2, "panel64w6": 6}.get(_m().gemm_kernel, 0)      # benchmark knob: weight prefetch depth
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
@@ -964,7 +1001,7 @@ def linear_rows2(x_lo, x_hi, weight, bias=None, *, groups=1, out_dtype=torch.flo
                            precision=0 if mode == "split" else 1, group_cols=ncol if groups > 1 else 0,
                            out_bf16=int(out_dtype == torch.bfloat16))
     desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(_m().gemm_kernel) \
-        or (2 if M >= (1 << 17) else 1)
+        or (2 if M >= _sel("panel_128_rows") else 1)
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)) if cb is not None else _NoTimer()
     with torch.cuda.device(x_lo.device), ctx:

@@ -214,3 +214,19 @@ def test_flattened_linear_params_merge_as_views_with_the_same_gradients():
     a.float(), b.float()
     w3, _ = ops.merged_linear_params(Owner(), a, b)
     assert torch.equal(w3, torch.cat([a.weight, b.weight]))
+
+
+def test_kernel_selection_table_names_existing_profiles_and_matches_the_library_constants():
+    """``ops.KERNEL_SELECTION``: every threshold that picks a projection kernel in one place, each with the profile it was
+    measured in (the file must exist) — and the rules that live in the library carry the same numbers there."""
+    import os
+    import re
+    from bevformer_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, (value, what, measured, profile) in ops.KERNEL_SELECTION.items():
+        assert os.path.exists(os.path.join(root, profile)), (name, profile)
+        assert what and measured
+    src = open(os.path.join(root, "bevformer_amd", "csrc", "bevmsda_linear.hip")).read()
+    assert int(re.search(r"kLinearPipeMaxRows\s*=\s*(\d+)", src).group(1)) == ops.KERNEL_SELECTION["pipe_max_rows"][0]
+    assert int(re.search(r"kChainSmallRows\s*=\s*(\d+)", src).group(1)) == ops.KERNEL_SELECTION["chain_small_rows"][0]
+    assert "256LL * 64" in src and ops.KERNEL_SELECTION["chain_mixed_rows"][0] == 256 * 64

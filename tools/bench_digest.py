@@ -25,3 +25,11 @@ if "cpu_baseline" in d:
     print(f"cpu {c['value']:.0f} q/s on {c['cores']} threads, runs {c.get('runs_s')}; vs_cpu {d.get('vs_cpu_baseline'):.0f}x")
 for k, v in (d.get("variants") or {}).items():
     print(f"  variant {k}: {v['ms_per_step']:.3f} ms (min {v['ms_per_step_min']:.3f}) {v['launch_mode']} parity {v.get('parity')}")
+for key in ("multi_gpu_model", "multi_gpu_model_bf16"):
+    m = d.get(key)
+    if m:
+        print(f"  {key}: t1 {m['t1_ms']:.3f} ms")
+        for g in ("2", "4", "8"):
+            e = m[g]
+            print(f"    G={g} ({e['layout']}): per-rank max {max(e['per_rank_ms']):.3f} ms + all-gather {e['all_gather_model_us']:.0f} us -> "
+                  f"efficiency {e['efficiency']:.3f} (Amdahl bound {e['amdahl_bound_efficiency']})")
