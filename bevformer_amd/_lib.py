@@ -110,6 +110,8 @@ SIGNATURES = {
                                        _c_int),
     "bevmsda_fused_forward_rows_bf16": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc), _c_void_p, _c_void_p],
                                         _c_int),
+    "bevmsda_fused_forward_rows_save_f32": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
+    "bevmsda_fused_forward_rows_save_bf16": ([_c_void_p] * 9 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_frontend_expand_f32": ([_c_void_p] * 6 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_frontend_chain_f32": ([_c_void_p] * 5 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 3, _c_int),
     "bevmsda_frontend_chain_gather_f32": ([_c_void_p] * 4 + [ctypes.c_int64, _c_int, _c_void_p, _c_void_p,

@@ -345,7 +345,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
 template <typename T>
 int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, const float *offs,
                const float *logits, const float *ref, const int32_t *row_batch, const int32_t *row_src,
-               const bevmsda_fused_desc *d, T *out, void *stream, const int32_t *nrows = nullptr) {
+               const bevmsda_fused_desc *d, T *out, void *stream, const int32_t *nrows = nullptr,
+               float *save_loc = nullptr, float *save_attn = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->R < 0 || d->N < 0 || d->S < 0 || d->M <= 0 || d->L < 0 || d->P < 0 || d->Q < 0 || d->K < 0 ||
       d->A <= 0)
@@ -368,6 +369,12 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   a.NQ = d->R; a.N = d->N; a.S = d->S; a.M = d->M; a.D = d->D; a.L = d->L; a.Q = d->Q > 0 ? d->Q : 1; a.P = d->P;
   a.qtile = kDefaultQtileFwd; a.xcd_remap = 1;
   a.mshift = ilog2_exact(a.M); a.qshift = ilog2_exact(a.qtile);
+  // SAVE kernels (training forward): SCA's shape only — device-side row count, one queue entry, 8 points, several levels
+  const bool save = save_loc != nullptr || save_attn != nullptr;
+  if (save && (!save_loc || !save_attn)) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && (!nrows || d->K != 1 || d->P != 8 || d->L < 2)) return BEVMSDA_ERR_UNSUPPORTED;
+  if (save && (misaligned(save_loc) || misaligned(save_attn))) return BEVMSDA_ERR_MISALIGNED;
+  f.save_loc = save_loc; f.save_attn = save_attn;
   f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
   f.off_head = d->off_head; f.off_k = d->off_k; f.lg_head = d->lg_head; f.lg_k = d->lg_k;
   f.K = d->K; f.A = d->A; f.ref_mode = d->ref_mode; f.vmul = d->vmul; f.vadd = d->vadd;
@@ -407,13 +414,15 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   } while (0)
     if constexpr (sizeof(T) == 2) {
       if (d->reserved[1] != 0 || d->reserved[0] != 0) return BEVMSDA_ERR_BAD_OPTION;
-      if (d->P == 8) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<8, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<8, 1, 4>));
+      if (d->P == 8 && save) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<8, 1, 4, true>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<8, 1, 4, true>));
+      else if (d->P == 8) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<8, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<8, 1, 4>));
       else if (d->K == 2) BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<4, 2, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 2, 4>));
       else BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<4, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 1, 4>));
     } else {
       if (d->reserved[0] != 0) return BEVMSDA_ERR_BAD_OPTION;
       if (d->P == 8) {
-        if (d->L > 1) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>));
+        if (d->L > 1 && save) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4, true>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4, true>));
+        else if (d->L > 1) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>));
         else BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 8>));
       } else if (d->K == 2) {
         BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 4, 2, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 4, 2, 8>));
@@ -675,6 +684,24 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
   if (!nrows) return BEVMSDA_ERR_NULL_POINTER;
   return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out,
                             stream, nrows);
+}
+
+int bevmsda_fused_forward_rows_save_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                        const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                        const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
+                                        float *save_loc, float *save_attn, void *stream) {
+  if (!nrows || !save_loc || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
+  return fused_impl<float>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out, stream, nrows,
+                           save_loc, save_attn);
+}
+
+int bevmsda_fused_forward_rows_save_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                         const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                         const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc,
+                                         uint16_t *out, float *save_loc, float *save_attn, void *stream) {
+  if (!nrows || !save_loc || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
+  return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out, stream, nrows,
+                            save_loc, save_attn);
 }
 
 int bevmsda_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,

@@ -222,6 +222,8 @@ struct FusedArgs {
                         // capacity of the row arrays and the launch geometry comes from `launch_rows`
                         // (see DynRows), so one captured launch serves every frame
   int launch_rows;      // host hint of the row count (<= capacity)
+  float *save_loc;      // SAVE kernels (training forward, K = 1): the sampling locations (R, M, L, P, 2) and attention weights
+  float *save_attn;     // (R, M, L, P) the backward kernels read — written here instead of recomputed by the expand pass
 };
 
 // Launches whose row count lives on the device.  Two kernels cover the rows:
@@ -273,8 +275,9 @@ __device__ __forceinline__ float lanes_sum(float v) {
 // owned by the lanes of the group: lane j -> queue entry j / PT, point j % PT.  With
 // KT = 2 (TemporalSelfAttention: PT = 4) both queue entries are sampled in the same
 // round and summed into the same accumulator (their mean is the output).
-template <typename T, int PT, int KT>
+template <typename T, int PT, int KT, bool SAVE = false>
 __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblock, long NQ, int tid, long row0 = 0) {
+  static_assert(!SAVE || KT == 1, "SAVE: one queue entry");
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
@@ -325,6 +328,13 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
     const float e = l == 0 ? e0 : (l == 1 ? e1 : (l == 2 ? e2 : e3));
     const float aw = live ? e / sum : 0.f;
     const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
+    if constexpr (SAVE) {
+      if (live) {                   // (r, m, l, pj): 64 + 32 contiguous bytes per (row, head, level)
+        const long o = ((r * a.M + m) * L + l) * PT + pj;
+        reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);
+        f.save_attn[o] = aw;
+      }
+    }
     if (l + 1 < L) {                // next level's record travels under this level's taps
       of = ofp[(l + 1) * PT];
       if (f.ref_mode == 1) rf = rfp[l + 1];
@@ -353,16 +363,16 @@ msda_fused_d32_kernel(const FusedArgs f) {
 
 // The same kernel over a device-side row count (DynRows): head = one workgroup per logical block of
 // the hinted count, tail = a small strided grid for rows beyond the hint.
-template <typename T, int PT, int KT, int WPE>
+template <typename T, int PT, int KT, int WPE, bool SAVE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_head_kernel(const FusedArgs f) {
   const DynRows d = dyn_rows(f, false);
   const int b = blockIdx.x;
   if ((b >> 3) >= d.per) return;
-  msda_fused_d32_body<T, PT, KT>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
+  msda_fused_d32_body<T, PT, KT, SAVE>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
 }
 
-template <typename T, int PT, int KT, int WPE>
+template <typename T, int PT, int KT, int WPE, bool SAVE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_dyn_kernel(const FusedArgs f) {
   const DynRows d = dyn_rows(f, true);
@@ -371,7 +381,7 @@ msda_fused_d32_dyn_kernel(const FusedArgs f) {
   for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    msda_fused_d32_body<T, PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
+    msda_fused_d32_body<T, PT, KT, SAVE>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
   }
 }
 
@@ -421,8 +431,9 @@ __device__ __forceinline__ void sample_points_b8(const PointParams &p, __amdgpu_
   }
 }
 
-template <int PT, int KT>
+template <int PT, int KT, bool SAVE = false>
 __device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, int lblock, long NQ, int tid, long row0 = 0) {
+  static_assert(!SAVE || KT == 1, "SAVE: one queue entry");
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
   const KArgs &a = f.k;
@@ -472,6 +483,13 @@ __device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, i
     const float e = l == 0 ? e0 : (l == 1 ? e1 : (l == 2 ? e2 : e3));
     const float aw = live ? e / sum : 0.f;
     const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
+    if constexpr (SAVE) {
+      if (live) {
+        const long o = ((r * a.M + m) * L + l) * PT + pj;
+        reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);
+        f.save_attn[o] = aw;
+      }
+    }
     if (l + 1 < L) {
       of = ofp[(l + 1) * PT];
       if (f.ref_mode == 1) rf = rfp[l + 1];
@@ -504,16 +522,16 @@ msda_fused_d32_bf16x8_kernel(const FusedArgs f) {
   msda_fused_d32_bf16x8_body<PT, KT>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
 }
 
-template <int PT, int KT, int WPE>
+template <int PT, int KT, int WPE, bool SAVE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_bf16x8_head_kernel(const FusedArgs f) {
   const DynRows d = dyn_rows(f, false);
   const int b = blockIdx.x;
   if ((b >> 3) >= d.per) return;
-  msda_fused_d32_bf16x8_body<PT, KT>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
+  msda_fused_d32_bf16x8_body<PT, KT, SAVE>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
 }
 
-template <int PT, int KT, int WPE>
+template <int PT, int KT, int WPE, bool SAVE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_bf16x8_dyn_kernel(const FusedArgs f) {
   const DynRows d = dyn_rows(f, true);
@@ -522,7 +540,7 @@ msda_fused_d32_bf16x8_dyn_kernel(const FusedArgs f) {
   for (int pb = blockIdx.x; pb < d.per * 8; pb += gridDim.x) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    msda_fused_d32_bf16x8_body<PT, KT>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
+    msda_fused_d32_bf16x8_body<PT, KT, SAVE>(f, (pb & 7) * d.per + (pb >> 3), d.NQ, tid, d.row0);
   }
 }
 

@@ -208,7 +208,7 @@ _RETIRED_FUSED_KWARGS = frozenset(("cam_start", "max_cam_rows", "lds_pixels"))
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", nrows=None, launch_rows=0, **retired):
+               tag="msda_fwd", nrows=None, launch_rows=0, save=None, **retired):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -222,7 +222,10 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     ``nrows`` ((1,) int32 device tensor, from a device-side frame plan): the ACTUAL number of
     rows; R above is then the capacity of the row arrays and the returned tensor has that many
     rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``);
-    ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint)."""
+    ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint).
+    ``save = (loc (R, M, L, P, 2), attn (R, M, L, P))`` fp32 (with ``nrows``; K = 1, P = 8, L >= 2): the kernel also
+    writes the sampling locations and attention weights its rows used (``bevmsda_fused_forward_rows_save_*``) — what the
+    operator's backward reads."""
     unknown = set(retired) - _RETIRED_FUSED_KWARGS
     if unknown:         # (the options of the retired LDS-staged kernels are still accepted and ignored; a typo is not)
         raise TypeError(f"msda_fused() got unexpected keyword arguments {sorted(unknown)}")
@@ -273,13 +276,24 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                 _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
                      "bevmsda: nrows must be an int32 device tensor")
                 desc.reserved[3] = int(max(0, min(launch_rows, R)))
-                fnr = lib.bevmsda_fused_forward_rows_f32 if store == torch.float32 \
-                    else lib.bevmsda_fused_forward_rows_bf16
+                extra = ()
+                if save is not None:
+                    sl, sa = save
+                    _req(sl.dtype == torch.float32 and sa.dtype == torch.float32 and sl.is_contiguous() and sa.is_contiguous()
+                         and sl.numel() == R * M * L * P * 2 and sa.numel() == R * M * L * P,
+                         "bevmsda: save = (loc (R, M, L, P, 2), attn (R, M, L, P)) contiguous fp32 tensors")
+                    fnr = lib.bevmsda_fused_forward_rows_save_f32 if store == torch.float32 \
+                        else lib.bevmsda_fused_forward_rows_save_bf16
+                    extra = (_ptr(sl), _ptr(sa))
+                else:
+                    fnr = lib.bevmsda_fused_forward_rows_f32 if store == torch.float32 \
+                        else lib.bevmsda_fused_forward_rows_bf16
                 rc = fnr(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
                          logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
                          _ptr(row_src) if row_src is not None else None, nrows.data_ptr(),
-                         ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
+                         ctypes.byref(desc), _ptr(out), *extra, torch.cuda.current_stream().cuda_stream)
             else:
+                _req(save is None, "bevmsda: save needs the device-side row count form (nrows)")
                 rc = fn(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), proj.data_ptr(),
                         logits.data_ptr(), _ptr(ref), _ptr(row_batch) if row_batch is not None else None,
                         _ptr(row_src) if row_src is not None else None, ctypes.byref(desc), _ptr(out), torch.cuda.current_stream().cuda_stream)
@@ -321,14 +335,26 @@ class _FusedSampleFunction(Function):
         # bf16 storage: ONE rounded copy of the value serves the forward kernel and, saved, the backward kernels
         vs = value.detach().to(_m().value_storage).contiguous()
         dyn = {} if nrows is None else dict(nrows=nrows, launch_rows=launch_rows)
+        # SCA's shape on the device-side row count: the forward kernel writes the locations / weights of its rows, the
+        # backward reads them instead of recomputing them (step (1) of the docstring: 79 us per base layer)
+        saved = None
+        if nrows is not None and meta["K"] == 1 and meta["P"] == 8 and meta["L"] >= 2 and row_src is not None \
+                and meta["vmul"] == 1 and meta["vadd"] == 0 and row_batch is not None and _m().fused_save \
+                and not (_m().value_storage == torch.bfloat16 and _m().bf16_lanes8):
+            Rr, Mh, Lv, Pp = row_src.numel(), meta["M"], meta["L"], meta["P"]
+            saved = (torch.empty((Rr, Mh, Lv, Pp, 2), dtype=torch.float32, device=vs.device),
+                     torch.empty((Rr, Mh, Lv, Pp), dtype=torch.float32, device=vs.device))
+            dyn["save"] = saved
         out = msda_fused(vs, shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
                          tag=tag, **meta, **dyn)
         if out is None:
             raise RuntimeError("bevmsda: fused sampling kernel does not cover this call")
         ctx.value_dtype = value.dtype
+        ctx.has_saved = saved is not None
         ctx.save_for_backward(vs, proj, shapes, start, ref.float().contiguous(),
                               row_batch if row_batch is not None else shapes.new_empty(0),
-                              row_src if row_src is not None else shapes.new_empty(0))
+                              row_src if row_src is not None else shapes.new_empty(0),
+                              *(saved if saved is not None else ()))
         ctx.n_off, ctx.meta, ctx.tag = n_off, meta, tag
         ctx.store = _m().value_storage     # the value storage the forward sampled (bf16: rounded copy of `value`)
         ctx.q_rows = q_rows               # (slots, J) int32 rows of every projection row, or None
@@ -339,7 +365,8 @@ class _FusedSampleFunction(Function):
     @once_differentiable
     @_forward_modes
     def backward(ctx, grad_out):
-        value, proj, shapes, start, ref, row_batch, row_src = ctx.saved_tensors
+        value, proj, shapes, start, ref, row_batch, row_src = ctx.saved_tensors[:7]
+        kept = ctx.saved_tensors[7:] if ctx.has_saved else None
         row_batch = row_batch if row_batch.numel() else None
         row_src = row_src if row_src.numel() else None
         m = ctx.meta
@@ -354,9 +381,12 @@ class _FusedSampleFunction(Function):
         lib = _lib.load()
         st = torch.cuda.current_stream().cuda_stream
         RK = R * K
-        loc = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
-        attn = torch.empty((RK, M, L, P), dtype=torch.float32, device=dev)
-        rbk = torch.empty(RK, dtype=torch.int32, device=dev)
+        if kept is not None:
+            loc, attn, rbk = kept[0], kept[1], row_batch        # (K = 1: the value batch entry of a row is its row_batch)
+        else:
+            loc = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
+            attn = torch.empty((RK, M, L, P), dtype=torch.float32, device=dev)
+            rbk = torch.empty(RK, dtype=torch.int32, device=dev)
         bf = ctx.store == torch.bfloat16
         value = value.detach().to(ctx.store).contiguous()      # bf16 storage: the rounded values the forward saw
         proj = proj.detach()
@@ -365,7 +395,9 @@ class _FusedSampleFunction(Function):
         if nrows is not None and (K != 1 or row_batch is None or row_src is None or ctx.q_rows is None):
             raise RuntimeError("bevmsda: a device-side row count needs the ragged single-entry form with a q_rows table")
         with torch.cuda.device(dev):
-            if nrows is not None:
+            if kept is not None:
+                pass                        # (the forward kernel wrote them: bevmsda_fused_forward_rows_save_*)
+            elif nrows is not None:
                 _lib.check(lib.bevmsda_frontend_expand_rows_f32(
                     proj.data_ptr(), logits.data_ptr(), _ptr(ref), _ptr(row_batch), _ptr(row_src), nrows.data_ptr(),
                     _ptr(shapes), ctypes.byref(desc), _ptr(loc), _ptr(attn), _ptr(rbk), st), "fused backward: expand (rows)")

@@ -232,6 +232,21 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
                                     const int32_t *nrows, const bevmsda_fused_desc *desc, uint16_t *out,
                                     void *stream);
 
+/* bevmsda_fused_forward_rows_* that also WRITE what the operator's backward reads (training forward of
+ * SpatialCrossAttention's sampling: K = 1, P = 8, L >= 2; else BEVMSDA_ERR_UNSUPPORTED): save_loc (R, M, L, P, 2) = the
+ * sampling locations reference + offset / (W_l, H_l) (spatial_cross_attention.py:357-372), save_attn (R, M, L, P) = the
+ * softmax over the L * P logits of a head (:340-348) — the operands `sampling_locations` / `attention_weights` that
+ * multi_scale_deformable_attn_function.py:94-128 saves for backward.  Rows [0, *nrows) are written.  The backward then
+ * needs no bevmsda_frontend_expand_rows_f32 pass. */
+int bevmsda_fused_forward_rows_save_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                        const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                        const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
+                                        float *save_loc, float *save_attn, void *stream);
+int bevmsda_fused_forward_rows_save_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                         const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
+                                         const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc,
+                                         uint16_t *out, float *save_loc, float *save_attn, void *stream);
+
 /* Backward of bevmsda_fused_forward_f32 in three steps (the autograd path of the modules; reference statements:
  * bevformer/modules/spatial_cross_attention.py:340-372, temporal_self_attention.py:209-229, 257-262 — what
  * autograd records there as softmax / divide / add / view nodes):
