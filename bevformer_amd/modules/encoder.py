@@ -259,14 +259,16 @@ class BEVFormerEncoder(TransformerLayerSequence):
 
     def _stack_free(self, history, bev_query, bs):
         """May the layers run without the stacked [history, bev_query] tensor?  Inference at bs = 1 on the GPU with every
-        layer's first attention the stock ``TemporalSelfAttention`` (a subclass or another module may read ``value``)."""
+        layer a stock ``BEVFormerLayer`` whose first attention is the stock ``TemporalSelfAttention`` (a subclass or another
+        module may read ``value`` / ``prev_bev``)."""
         from .temporal_self_attention import TemporalSelfAttention
         if bs != 1 or not ops.modes().stack_free or torch.is_grad_enabled() or self.training or not history.is_cuda \
                 or len(self.layers) < 2 \
                 or ops.gemm_mode() == "native" or history.dtype != torch.float32 or bev_query.dtype != torch.float32 \
                 or history.shape != bev_query.shape:
             return False
-        return all(type(getattr(layer, "attentions", [None])[0]) is TemporalSelfAttention for layer in self.layers)
+        return all(type(layer) is BEVFormerLayer and type(getattr(layer, "attentions", [None])[0]) is TemporalSelfAttention
+                   for layer in self.layers)
 
     def hoisted_value_projections_autograd(self, value, tsa_value):
         """``hoisted_value_projections`` with gradients (train_ops.grouped_linear): camera features (Nc, S, bs, C) ->

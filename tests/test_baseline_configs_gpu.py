@@ -72,7 +72,8 @@ def test_encoder_forward_bf16_configurations(name, gemm, storage, modes):
     assert cos > 0.999, cos
 
 
-def test_fused_sca_kernel_at_the_full_base_row_count():
+@pytest.mark.parametrize("row_order", ["polar", "image"])
+def test_fused_sca_kernel_at_the_full_base_row_count(row_order):
     """The launch the bench times — fused SCA sampling over all R ~ 46 k ragged rows with the
     shared projection rows (row_src), the device-side row count and 32-bit byte offsets into the
     189 MB value tensor — against the oracle's statement of the fused contract on row slices
@@ -89,7 +90,8 @@ def test_fused_sca_kernel_at_the_full_base_row_count():
     proj = torch.randn(Q, M * L * P * 3, generator=g)
     n_off = M * L * P * 2
     proj[:, :n_off] *= 4.0                                            # offsets of a few pixels
-    pl = G.DevicePlanner(w["bev_h"], w["bev_w"], 1, S.PC_RANGE, 4, S.NUM_CAMS, DEV, row_order="polar")
+    # ("image" = the calibrated order the bench runs; "polar" = the order that needs no calibration)
+    pl = G.DevicePlanner(w["bev_h"], w["bev_w"], 1, S.PC_RANGE, 4, S.NUM_CAMS, DEV, row_order=row_order)
     plan = pl.plan(S.make_img_metas(name))
     host = plan.materialize()
     R = host.row_batch.numel()

@@ -243,3 +243,31 @@ def test_train_mode_with_active_dropout_on_the_gpu(temporal, monkeypatch):
     torch.testing.assert_close(got.detach().cpu(), want, **TOL)
     got.sum().backward()
     assert torch.isfinite(qd.grad).all()
+
+
+@pytest.mark.parametrize("name,storage", [("micro4", torch.float32), ("small4", torch.float32), ("micro4", torch.bfloat16)])
+def test_value_projection_without_the_stacked_history_tensor(name, storage):
+    """Inference, bs = 1: TSA's value ``stack([prev_bev, bev_query])`` is projected from its two tensors
+    (``bevmsda_linear_panel_rows2_f32``) and the layers get a view of the history in its place — bit for bit the output of the
+    run that stacks (``stack_free = False``); the switch must really change the path (one ``cat`` kernel less)."""
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=2, temporal=True, device=DEV)
+    seen = []
+    real_stack = torch.stack
+
+    def counting_stack(ts, *a, **k):
+        seen.append(tuple(ts[0].shape))
+        return real_stack(ts, *a, **k)
+    with torch.no_grad(), ops.using(value_storage=storage):
+        torch.stack = counting_stack
+        try:
+            free = enc(q, f, f, **kw)
+            n_free = sum(1 for s in seen if len(s) == 3 and s[-1] == 256)
+            seen.clear()
+            with ops.using(stack_free=False):
+                stacked = enc(q, f, f, **kw)
+            n_stacked = sum(1 for s in seen if len(s) == 3 and s[-1] == 256)
+        finally:
+            torch.stack = real_stack
+    assert torch.equal(free, stacked)
+    assert n_free == 0 and n_stacked == 1, (n_free, n_stacked)
