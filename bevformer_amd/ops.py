@@ -1008,8 +1008,10 @@ def linear_rows2(x_lo, x_hi, weight, bias=None, *, groups=1, out_dtype=torch.flo
     if x_lo.dtype != torch.float32 or x_hi.dtype != torch.float32 or weight.dtype != torch.float32:
         return None
     N, K = weight.shape
+    # (what the row-panel kernel TAKES, not where it is the faster GEMM: the stack it saves outweighs the few per cent the first
+    # kernel is ahead at N < 1024)
     if x_lo.shape[-1] != K or x_hi.shape[-1] != K or not _m().gemm_pack or _m().gemm_variant is not None \
-            or not _panel_covers(N, K, 0, groups, False, None) or N % groups or (N // groups) % 128:
+            or _m().gemm_kernel in ("first", "pipe") or K != 256 or N % groups or (N // groups) % 128:
         return None
     lo, ld0 = _rows2d(x_lo, K)
     hi, ld1 = _rows2d(x_hi, K)
