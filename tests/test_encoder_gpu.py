@@ -258,7 +258,9 @@ def test_value_projection_without_the_stacked_history_tensor(name, storage):
     def counting_stack(ts, *a, **k):
         seen.append(tuple(ts[0].shape))
         return real_stack(ts, *a, **k)
-    with torch.no_grad(), ops.using(value_storage=storage):
+    # (forced onto the row-panel kernel both runs project with the same kernel over the same rows: bit-equal; by default the
+    # stacked run of these small configurations takes the first kernel for N < 1024 — GEMM round-off apart)
+    with torch.no_grad(), ops.using(value_storage=storage, gemm_kernel="panel"):
         torch.stack = counting_stack
         try:
             free = enc(q, f, f, **kw)
@@ -271,3 +273,6 @@ def test_value_projection_without_the_stacked_history_tensor(name, storage):
             torch.stack = real_stack
     assert torch.equal(free, stacked)
     assert n_free == 0 and n_stacked == 1, (n_free, n_stacked)
+    with torch.no_grad(), ops.using(value_storage=storage):
+        default = enc(q, f, f, **kw)
+    torch.testing.assert_close(default, stacked, rtol=0, atol=5e-2 if storage == torch.bfloat16 else 2e-4)
