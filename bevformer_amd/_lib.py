@@ -96,6 +96,8 @@ SIGNATURES = {
     "bevmsda_cast_rows_bf16": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_int, ctypes.c_float, _c_void_p, _c_void_p], _c_int),
     "bevmsda_rows_from_slots_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, _c_int,
                                      _c_void_p, _c_void_p], _c_int),
+    "bevmsda_proj_ffn_chain_backward_f32": ([_c_void_p, ctypes.c_int64] + [_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 7,
+                                            _c_int),
     "bevmsda_proj_ffn_chain_train_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 9, _c_int),
     "bevmsda_proj_ln_proj_chain_train_f32": ([_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 5, _c_int),
     "bevmsda_forward_f32_ex": ([_c_void_p] * 5 + _DIMS + [_c_void_p, _c_void_p,
@@ -137,6 +139,8 @@ SIGNATURES = {
                                           ctypes.POINTER(LinearDesc), _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_panel_packed_bytes": ([_c_int, _c_int], ctypes.c_int64),
     "bevmsda_linear_panel_pack_weight_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
+                                             _c_int),
+    "bevmsda_linear_panel_pack_weight_t_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                              _c_int),
     "bevmsda_linear_panel_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
                                                   _c_void_p, _c_void_p], _c_int),

@@ -282,8 +282,23 @@ int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int
   const long long threads = 1LL * tiles32 * (K / 16) * 64;
   const long long nb = (threads + 255) / 256;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  hipLaunchKernelGGL(bevmsda::lin_panel_pack_weight_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+  hipLaunchKernelGGL(bevmsda::lin_panel_pack_weight_kernel<false>, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<long>(ldw), N, K, tiles32, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+int bevmsda_linear_panel_pack_weight_t_f32(const float *wt, int64_t ldwt, int N, int K, uint16_t *blob, void *stream) {
+  if (N <= 0 || K <= 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (K % bevmsda::kPanelK != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ldwt < N) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!wt || !blob) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(blob) || (reinterpret_cast<uintptr_t>(wt) & 3u)) return BEVMSDA_ERR_MISALIGNED;
+  const int tiles32 = ((N + 63) / 64) * 2;
+  const long long threads = 1LL * tiles32 * (K / 16) * 64;
+  const long long nb = (threads + 255) / 256;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_panel_pack_weight_kernel<true>, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), wt, static_cast<long>(ldwt), N, K, tiles32, blob);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
@@ -494,6 +509,44 @@ int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, cons
                                      const float *drop1, void *stream) {
   return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, true,
                           save_z0, save_x, save_h, save_z1, drop0, droph, drop1);
+}
+
+// ---- backward of the projection + FFN chain (linear_chain.h, MODE 2)
+int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, const float *save_z0, const float *save_h,
+                                        const float *save_z1, const float *gamma0, const float *gamma1, const uint16_t *w0t_p,
+                                        const uint16_t *w1t_p, const uint16_t *w2t_p, const bevmsda_chain_desc *d, float *grad_z1,
+                                        float *grad_h, float *grad_z0, float *grad_in, float *grad_gamma_beta1,
+                                        float *grad_gamma_beta0, void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->C != bevmsda::kChainC || d->F != bevmsda::kChainF) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->M == 0) return BEVMSDA_OK;
+  if (!grad_y || !save_z0 || !save_h || !save_z1 || !gamma0 || !gamma1 || !w0t_p || !w1t_p || !w2t_p || !grad_z1 || !grad_h ||
+      !grad_z0 || !grad_in || !grad_gamma_beta1 || !grad_gamma_beta0)
+    return BEVMSDA_ERR_NULL_POINTER;
+  if (ld_grad_y % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ld_grad_y < d->C) return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(grad_y) || misaligned(save_z0) || misaligned(save_h) || misaligned(save_z1) || misaligned(gamma0) ||
+      misaligned(gamma1) || misaligned(w0t_p) || misaligned(w1t_p) || misaligned(w2t_p) || misaligned(grad_z1) ||
+      misaligned(grad_h) || misaligned(grad_z0) || misaligned(grad_in) || (reinterpret_cast<uintptr_t>(grad_gamma_beta1) & 3u) ||
+      (reinterpret_cast<uintptr_t>(grad_gamma_beta0) & 3u))
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = (d->M + 31) / 32;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::ChainArgs a{};
+  // the three GEMMs of the backward read the images of the TRANSPOSED weights in the slots of the forward's: stage "0" =
+  // gz0 W0 (256 x 256), stage "1" = gz1 W2 (512 columns, K = 256), stage "2" = gh W1 (256 columns, K = 512)
+  a.w0 = w0t_p; a.w1 = w2t_p; a.w2 = w1t_p;
+  a.gamma0 = gamma0; a.gamma1 = gamma1; a.eps0 = d->eps0; a.eps1 = d->eps1; a.M = d->M;
+  a.bw_gy = grad_y; a.bw_ld_gy = ld_grad_y; a.bw_z1 = save_z1; a.bw_h = save_h; a.bw_z0 = save_z0;
+  a.bw_gz1 = grad_z1; a.bw_gh = grad_h; a.bw_gz0 = grad_z0; a.bw_din = grad_in;
+  a.bw_dgb1 = grad_gamma_beta1; a.bw_dgb0 = grad_gamma_beta0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(nb));
+  if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 2, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0, 2, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
 static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,

@@ -32,6 +32,7 @@
 // The accumulator -> plane write uses the same slot map the DMA + split pass produces, so the fragment reads of every
 // stage are the conflict-free ones of linear_panel.h (tests/test_linear_layout_model.py replays the arithmetic).
 #pragma once
+#include <type_traits>
 #include "linear_panel.h"
 
 namespace bevmsda {
@@ -65,6 +66,16 @@ struct ChainArgs {
                                     //           temporal_self_attention.py:272)
   const float *dkh;                 // MODE 0, (M, 512): on relu(x W1^T + b1) (mmcv FFN: Linear, ReLU, Dropout)
   const float *dk1;                 // MODE 0, (M, 256): on h W2^T + b2, before "+ x"
+  // MODE 2 (the backward of MODE 0, round 4): the incoming gradient, the four tensors SAVE stored, the gradients out.
+  // w0 / w1 / w2 are then the images of W0^T (256 x 256), W2^T (512 x 256) and W1^T (256 x 512).
+  const float *bw_gy;               // (M, bw_ld_gy): gradient of y
+  long bw_ld_gy;
+  const float *bw_z1, *bw_h, *bw_z0;   // dense (M, 256), (M, 512), (M, 256)
+  float *bw_gz1;                    // (M, 256) gradient of z1 = LayerNorm1's input (also the FFN output's and, added in, x's)
+  float *bw_gh;                     // (M, 512) gradient of the hidden pre-activation (ReLU mask applied)
+  float *bw_gz0;                    // (M, 256) gradient of z0 = LayerNorm0's input (= the residual's gradient)
+  float *bw_din;                    // (M, 256) gz0 W0: gradient of the seam's input rows (A)
+  float *bw_dgb1, *bw_dgb0;         // (2, 256) each: [grad gamma | grad beta] of LayerNorm1 / 0, ADDED to (caller zeroes)
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -98,6 +109,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
   static_assert(PRE == 0 || PRE == 2, "PRE: 0 plain rows, 2 two-row gather");
+  static_assert(MODE != 2 || (MT == 1 && NT == 2 && PRE == 0 && !SAVE && !DROP), "MODE 2: 32-row workgroups of 4 wavefronts");
   static_assert(NW * NT == 8 && (MT == 1 || MT == 2) && (NT == 1 || NT == 2), "workgroup shape");
   constexpr bool LO = NPROD == 3;
   constexpr int NPL = LO ? 2 : 1;
@@ -106,11 +118,12 @@ linear_chain_kernel(const ChainArgs a) {
   constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: BM KiB
   constexpr int PPW = (BM / 8) * 4 / NW;       // (row block, line pair) DMA pairs per wavefront
   constexpr int NCST = 4 * kChainC + kChainMaxN2 + 2 * kChainC;       // gamma0, beta0, gamma1, beta1 | b1 | b0, b2
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NW * BM * 4 + NCST * 4];
+  constexpr int NSTAT = MODE == 2 ? 2 : 1;    // (the LayerNorm backward exchanges two row sums at once)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NSTAT * NW * BM * 4 + NCST * 4];
   unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
   float *const stat = reinterpret_cast<float *>(lds + 2 * BUF);       // [wave][row]
   // the per-column constants of every epilogue, copied once: read from LDS instead of as an L2 round trip per stage
-  float *const cst = stat + NW * BM;
+  float *const cst = stat + NSTAT * NW * BM;
   float *const c_g0 = cst, *const c_be0 = cst + 256, *const c_g1 = cst + 512, *const c_be1 = cst + 768;
   float *const c_b1 = cst + 1024, *const c_b0 = cst + 1024 + kChainMaxN2, *const c_b2 = c_b0 + 256;
   const int nb1 = MODE == 1 ? a.N2 : kChainF;
@@ -128,8 +141,8 @@ linear_chain_kernel(const ChainArgs a) {
     for (int t4 = tid * 4; t4 < NCST; t4 += NTHREADS * 4) {
       const float *src = nullptr;
       if (t4 < 256) src = a.gamma0 + t4;
-      else if (t4 < 512) src = a.beta0 + (t4 - 256);
-      else if (t4 < 768) src = MODE == 0 ? a.gamma1 + (t4 - 512) : nullptr;
+      else if (t4 < 512) src = MODE == 2 ? nullptr : a.beta0 + (t4 - 256);
+      else if (t4 < 768) src = MODE != 1 ? a.gamma1 + (t4 - 512) : nullptr;
       else if (t4 < 1024) src = MODE == 0 ? a.beta1 + (t4 - 768) : nullptr;
       else if (t4 < 1024 + kChainMaxN2) src = (a.b1 && t4 - 1024 < nb1) ? a.b1 + (t4 - 1024) : nullptr;
       else if (t4 < 1024 + kChainMaxN2 + 256) src = a.b0 ? a.b0 + (t4 - 1024 - kChainMaxN2) : nullptr;
@@ -159,7 +172,7 @@ linear_chain_kernel(const ChainArgs a) {
     }
 
   const int wlane = lane * 16;
-  lin_f32x16 acc[MT][NT], xk[MT][NT], acc2[MODE == 0 ? MT : 1][MODE == 0 ? NT : 1];
+  lin_f32x16 acc[MT][NT], xk[MT][NT], acc2[MODE != 1 ? MT : 1][MODE != 1 ? NT : 1];
 
 #ifndef BEVMSDA_CHAIN_WD
 #define BEVMSDA_CHAIN_WD 2
@@ -325,7 +338,7 @@ linear_chain_kernel(const ChainArgs a) {
   const unsigned w0b = 8u * 16 * 2 * 1024, w1b = static_cast<unsigned>((nb1 + 63) / 64 * 2) * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
   __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
-  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(MODE == 0 ? a.w2 : a.w0), 0, static_cast<int>(MODE == 0 ? w2b : w0b), 0x00020000);
+  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(MODE != 1 ? a.w2 : a.w0), 0, static_cast<int>(MODE != 1 ? w2b : w0b), 0x00020000);
   long mrow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) mrow[i] = m0 + i * 32 + (lane & 31);
@@ -340,7 +353,7 @@ linear_chain_kernel(const ChainArgs a) {
       for (int g = 0; g < 4; ++g)
         rs[i][j][g] = rrow ? *reinterpret_cast<const float4 *>(rrow + ncol(j) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  wprefetch(r0, wave, 16, 0);
+  if constexpr (MODE != 2) wprefetch(r0, wave, 16, 0);
 
   auto store_tile = [&](const auto &c, float *out, long ld, int col0) {
 #pragma unroll
@@ -371,6 +384,182 @@ linear_chain_kernel(const ChainArgs a) {
     }
   };
 
+  if constexpr (MODE == 2) {
+    // ================================================================== MODE 2: the backward of MODE 0 on the same machinery
+    //   gz1 = LN1'(z1; gy)                         column sums -> grad gamma1 / beta1
+    //   gh  = (gz1 W2) where h > 0                  (two halves of 256 hidden columns, as the forward)
+    //   gx  = gh W1 + gz1                           (x feeds the FFN and, as its residual, LayerNorm1's input)
+    //   gz0 = LN0'(z0; gx)                          column sums -> grad gamma0 / beta0
+    //   din = gz0 W0
+    // Rows live where the forward's accumulators had them (lane = row, 4 consecutive columns per register quad), so the
+    // LayerNorm backward is elementwise + the forward LayerNorm's row-sum exchange, and every GEMM is the forward's.
+    float *const stat2 = stat + NW * BM;
+    const bool row_ok = mrow[0] < a.M;
+    const long mclamp = row_ok ? mrow[0] : a.M - 1;
+    auto load_tile = [&](auto &c, const float *src, long ld, int col0, bool zero_invalid) {
+      const float *rowp = src + mclamp * ld + col0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = *reinterpret_cast<const float4 *>(rowp + j * 32 + 4 * (lane >> 5) + 8 * g);
+          if (zero_invalid && !row_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          c[0][j][4 * g] = v.x; c[0][j][4 * g + 1] = v.y; c[0][j][4 * g + 2] = v.z; c[0][j][4 * g + 3] = v.w;
+        }
+    };
+    // sum over the 32 rows (lanes with equal lane >> 5) of 32 per-lane values by recursive halving: lane l ends up with
+    // the total of value (l & 31), which is added to out[column of that value] (31 exchanges instead of 160)
+    auto colsum_add = [&](float (&v)[32], float *out) {
+      auto level = [&](auto xtag) {          // X values stay per lane after the exchange with lane ^ X
+        constexpr int X = decltype(xtag)::value;
+        const bool up = (lane & X) != 0;
+#pragma unroll
+        for (int k = 0; k < X; ++k) {
+          const float keep = up ? v[k + X] : v[k];
+          const float send = up ? v[k] : v[k + X];
+          v[k] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), (X << 10) | 0x1f));
+        }
+      };
+      level(std::integral_constant<int, 16>{});
+      level(std::integral_constant<int, 8>{});
+      level(std::integral_constant<int, 4>{});
+      level(std::integral_constant<int, 2>{});
+      level(std::integral_constant<int, 1>{});
+      const int idx = lane & 31, j = idx >> 4, r = idx & 15;
+      unsafeAtomicAdd(out + (NT * wave + j) * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3), v[0]);
+    };
+    // g <- the gradient of the LayerNorm's INPUT z, given g = the gradient of its output; z is overwritten (x hat)
+    auto layernorm_bwd = [&](auto &z, auto &g, const float *gamma, float eps, float *dgb) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += z[0][j][r];
+      sum += __shfl_xor(sum, 32, 64);
+      if (lane < 32) stat[wave * BM + lane] = sum;
+      __syncthreads();
+      float mean = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mean += stat[w * BM + (lane & 31)];
+      mean *= (1.0f / kChainC);
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = z[0][j][r] - mean;
+          ss = fmaf(d, d, ss);
+        }
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 32) stat2[wave * BM + lane] = ss;
+      __syncthreads();
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) var += stat2[w * BM + (lane & 31)];
+      const float rstd = rsqrtf(var * (1.0f / kChainC) + eps);
+      // x hat; the column sums of g * xhat and of g
+      float tmp[32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          z[0][j][r] = (z[0][j][r] - mean) * rstd;
+          tmp[j * 16 + r] = g[0][j][r] * z[0][j][r];
+        }
+      colsum_add(tmp, dgb);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[j * 16 + r] = g[0][j][r];
+      colsum_add(tmp, dgb + kChainC);
+      // t = g * gamma; s1 = mean_c t, s2 = mean_c (t * xhat)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 ga = *reinterpret_cast<const float4 *>(gamma + ncol(j) + 8 * q);
+          g[0][j][4 * q] *= ga.x; g[0][j][4 * q + 1] *= ga.y; g[0][j][4 * q + 2] *= ga.z; g[0][j][4 * q + 3] *= ga.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s1 += g[0][j][4 * q + e];
+            s2 = fmaf(g[0][j][4 * q + e], z[0][j][4 * q + e], s2);
+          }
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      __syncthreads();                         // (every wavefront has read the statistics above)
+      if (lane < 32) {
+        stat[wave * BM + lane] = s1;
+        stat2[wave * BM + lane] = s2;
+      }
+      __syncthreads();
+      s1 = 0.f; s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        s1 += stat[w * BM + (lane & 31)];
+        s2 += stat2[w * BM + (lane & 31)];
+      }
+      s1 *= (1.0f / kChainC);
+      s2 *= (1.0f / kChainC);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[0][j][r] = rstd * (g[0][j][r] - s1 - z[0][j][r] * s2);
+      __syncthreads();                         // `stat` / `stat2` may be written again
+    };
+
+    load_tile(acc, a.bw_gy, a.bw_ld_gy, NT * wave * 32, true);
+    load_tile(acc2, a.bw_z1, kChainC, NT * wave * 32, false);
+    __syncthreads();                           // the per-column constants are in LDS
+    layernorm_bwd(acc2, acc, c_g1, a.eps1, a.bw_dgb1);
+    wprefetch(r1, wave, 16, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xk[0][j] = acc[0][j];
+    store_tile(xk, a.bw_gz1, kChainC, NT * wave * 32);
+    to_planes(xk, buf1);
+    __syncthreads();
+    zero(acc2);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      zero(acc);
+      gemm16(acc, buf1, r1, half * NW + wave, 16, 0);
+      wprefetch(r2, wave, 32, half * 16);
+      {                                        // ReLU backward: the forward's hidden activations are the mask
+        const float *hrow = a.bw_h + mclamp * kChainF + half * 256 + NT * wave * 32;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 hv = *reinterpret_cast<const float4 *>(hrow + j * 32 + 4 * (lane >> 5) + 8 * g);
+            acc[0][j][4 * g] = hv.x > 0.f ? acc[0][j][4 * g] : 0.f;
+            acc[0][j][4 * g + 1] = hv.y > 0.f ? acc[0][j][4 * g + 1] : 0.f;
+            acc[0][j][4 * g + 2] = hv.z > 0.f ? acc[0][j][4 * g + 2] : 0.f;
+            acc[0][j][4 * g + 3] = hv.w > 0.f ? acc[0][j][4 * g + 3] : 0.f;
+          }
+      }
+      store_tile(acc, a.bw_gh, kChainF, half * 256 + NT * wave * 32);
+      to_planes(acc, buf0);
+      __syncthreads();
+      gemm16(acc2, buf0, r2, wave, 32, half * 16);
+      if (half == 0) wprefetch(r1, NW + wave, 16, 0);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[0][j][r] += xk[0][j][r];
+    load_tile(acc, a.bw_z0, kChainC, NT * wave * 32, false);
+    layernorm_bwd(acc, acc2, c_g0, a.eps0, a.bw_dgb0);
+    wprefetch(r0, wave, 16, 0);
+    store_tile(acc2, a.bw_gz0, kChainC, NT * wave * 32);
+    to_planes(acc2, buf1);
+    __syncthreads();
+    zero(acc);
+    gemm16(acc, buf1, r0, wave, 16, 0);
+    store_tile(acc, a.bw_din, kChainC, NT * wave * 32);
+    return;
+  }
   // ------------------------------------------------------------------ stage 0: fetch + split the A panel (buffer 0)
   {
     const int d_rl = lane >> 3, d_cc = lane & 7;

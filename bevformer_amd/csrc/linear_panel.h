@@ -523,6 +523,8 @@ linear_panel_kernel(const PanelArgs a) {
 //   blob[(((T * K/16 + sg) * 2 + plane) * 64 + lane) * 8 + e] = plane(w[T*32 + (lane & 31)][k])
 //   k = 256 (sg / 16) + 32 (2 p + (e >> 2)) + 4 c + (e & 3),  8 p + c = 2 (sg % 16) + (lane >> 5)
 // Rows >= N are zero (N is padded to the launcher's column-tile width).  One thread per (T, sg, lane).
+// TRANSPOSED: element (n, k) of the weight is w[k * ldw + n] (the image of W^T from W where it lies: backward GEMMs).
+template <bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float *__restrict__ w, long ldw, int N, int K,
                                                                    int n_tiles32, uint16_t *__restrict__ blob) {
   const int nstep = K / 16;
@@ -537,8 +539,14 @@ __global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float 
   const int k = (sg / 16) * kPanelK + (2 * p) * 32 + 4 * c;
   uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
   if (n < N) {
-    const float *src = w + static_cast<long>(n) * ldw + k;
-    lin_split8<true>(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 32), hi, lo);
+    if constexpr (TRANSPOSED) {
+      const float *src = w + static_cast<long>(k) * ldw + n;
+      lin_split8<true>(make_float4(src[0], src[ldw], src[2 * ldw], src[3 * ldw]),
+                       make_float4(src[32 * ldw], src[33 * ldw], src[34 * ldw], src[35 * ldw]), hi, lo);
+    } else {
+      const float *src = w + static_cast<long>(n) * ldw + k;
+      lin_split8<true>(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 32), hi, lo);
+    }
   }
   uint4 *dst = reinterpret_cast<uint4 *>(blob) + ((static_cast<long>(T) * nstep + sg) * 2) * 64 + lane;
   dst[0] = hi;

@@ -19,7 +19,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward")
 
     def __init__(self):
         env = os.environ.get
@@ -41,6 +41,7 @@ class Modes:
         self.weight_views = env("BEVMSDA_WEIGHT_VIEWS", "1") == "1"  # training: W^T images packed from W (no transposed copies)
         self.flatten_params = env("BEVMSDA_FLATTEN_PARAMS", "1") == "1"  # training: merged projections' parameters back to back (views, no cat)
         self.fused_save = env("BEVMSDA_FUSED_SAVE", "1") == "1"      # training: SCA's forward kernel writes the locations / weights its backward reads
+        self.chain_backward = env("BEVMSDA_CHAIN_BWD", "1") == "1"   # training: the row-local backward of the SCA seam in one kernel
         self.chain_shape = int(env("BEVMSDA_CHAIN_SHAPE", "0"))     # benchmark knob: workgroup shape of the row-chain kernels
         self.grad_thread = env("BEVMSDA_GRAD_THREAD", "1") == "1"   # training: value-projection input gradients summed in the GEMMs
         # autograd path of the encoder layer on the inference kernels (train_ops.py): chain kernels that save what their

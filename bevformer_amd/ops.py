@@ -740,7 +740,7 @@ def packed_weight(weight):
 def panel_weight(weight):
     """Fragment-order bf16 image of an (N, K) fp32 weight for the row-panel kernel
     (``bevmsda_linear_panel_pack_weight_f32``), cached on the tensor until it is written to or moved."""
-    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0))
+    key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_panel", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
         return hit[1]
@@ -751,8 +751,12 @@ def panel_weight(weight):
         return None
     blob = torch.empty(nbytes // 2, dtype=torch.int16, device=weight.device)
     with torch.cuda.device(weight.device):
-        rc = lib.bevmsda_linear_panel_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
-                                                      torch.cuda.current_stream().cuda_stream)
+        if _is_transposed_view(weight):     # (the image of W^T from W where it lies)
+            rc = lib.bevmsda_linear_panel_pack_weight_t_f32(_ptr(weight), weight.stride(1), N, K, _ptr(blob),
+                                                            torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = lib.bevmsda_linear_panel_pack_weight_f32(_ptr(weight), weight.stride(0), N, K, _ptr(blob),
+                                                          torch.cuda.current_stream().cuda_stream)
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return None
     _lib.check(rc, "linear_panel_pack_weight")

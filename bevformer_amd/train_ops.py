@@ -573,16 +573,42 @@ class _SeamSFunction(Function):
         if gy.dtype != torch.float32 or not gy.is_contiguous():
             gy = gy.float().contiguous()
         dW0, db0, dW1, db1, dW2, db2 = _zeros(dev, (256, 256), (256,), (512, 256), (512,), (256, 512), (256,))
-        # LayerNorm1, FFN
-        dz1, dg1, dbe1 = _ln_backward(z1, gamma1, gy, ctx.eps1)
-        df = dz1 if ctx.drop1 is None else dz1 * ctx.drop1                     # through the FFN's output dropout
-        # (dz1 w2) where h > 0 (h: after its dropout — zero where dropped), times 1 / (1 - p) of that dropout
-        dh = _dgrad_relu(df, w2, h, tag + "_dx2", ctx.hidden_scale)            # (M, 512)
-        dxf = _dgrad(dh, w1, tag + "_dx1")                                    # the FFN's share of the gradient of x
-        # LayerNorm0 (d/dx = the residual branch's dz1 + the FFN's share: added inside the kernel), output projection
-        dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dz1, ctx.eps0, out_shape=ctx.res_shape, g2=dxf)
-        dz0 = dzr.view(M, 256)
-        dzp = dz0 if ctx.drop0 is None else dz0 * ctx.drop0                    # through the attention's dropout
+        dg = None
+        if ctx.drop0 is None and ctx.drop1 is None and ctx.hidden_scale == 1.0 and _m().chain_backward:
+            # ONE kernel for the row-local part of the backward (linear_chain.h MODE 2): both LayerNorm backwards, the
+            # ReLU-masked FFN input gradients and the output projection's, with the rows resident as in the forward
+            dz1 = torch.empty((M, 256), dtype=torch.float32, device=dev)
+            dh = torch.empty((M, 512), dtype=torch.float32, device=dev)
+            dzr = torch.empty(ctx.res_shape, dtype=torch.float32, device=dev)
+            dg = torch.empty((M, 256), dtype=torch.float32, device=dev)
+            gb1, gb0 = _zeros(dev, (2, 256), (2, 256))
+            desc = _lib.ChainDesc(M=M, ld_rows=256, ld_res=256, ld_y=256, C=256, F=512, precision=_prec(), eps0=ctx.eps0,
+                                  eps1=ctx.eps1)
+            blobs = [ops.panel_weight(_aligned(w.detach()).t()) for w in (w0, w1, w2)]      # images of w^T, from w
+            if any(b is None for b in blobs):
+                raise RuntimeError("bevmsda: no transposed panel image for the chain backward")
+            cb = ops._GEMM_TIMER["cb"]
+            tctx = cb(tag + "_bwd", 2.0 * M * (256 * 256 + 2 * 256 * 512), 4.0 * M * 256 * 10) if cb is not None else ops._NoTimer()
+            with torch.cuda.device(dev), tctx:
+                _lib.check(_lib.load().bevmsda_proj_ffn_chain_backward_f32(
+                    _ptr(gy), 256, _ptr(z0), _ptr(h), _ptr(z1), _ptr(gamma0.detach().contiguous()),
+                    _ptr(gamma1.detach().contiguous()), _ptr(blobs[0]), _ptr(blobs[1]), _ptr(blobs[2]), ctypes.byref(desc),
+                    _ptr(dz1), _ptr(dh), _ptr(dzr), _ptr(dg), _ptr(gb1), _ptr(gb0),
+                    torch.cuda.current_stream().cuda_stream), "proj_ffn_chain backward")
+            dg1, dbe1, dg0, dbe0 = gb1[0], gb1[1], gb0[0], gb0[1]
+            df, dz0 = dz1, dzr.view(M, 256)
+            dzp = dz0
+        else:
+            # LayerNorm1, FFN
+            dz1, dg1, dbe1 = _ln_backward(z1, gamma1, gy, ctx.eps1)
+            df = dz1 if ctx.drop1 is None else dz1 * ctx.drop1                     # through the FFN's output dropout
+            # (dz1 w2) where h > 0 (h: after its dropout — zero where dropped), times 1 / (1 - p) of that dropout
+            dh = _dgrad_relu(df, w2, h, tag + "_dx2", ctx.hidden_scale)            # (M, 512)
+            dxf = _dgrad(dh, w1, tag + "_dx1")                                    # the FFN's share of the gradient of x
+            # LayerNorm0 (d/dx = the residual branch's dz1 + the FFN's share: added inside the kernel), output projection
+            dzr, dg0, dbe0 = _ln_backward(z0, gamma0, dz1, ctx.eps0, out_shape=ctx.res_shape, g2=dxf)
+            dz0 = dzr.view(M, 256)
+            dzp = dz0 if ctx.drop0 is None else dz0 * ctx.drop0                    # through the attention's dropout
         probs = [(df, h, dW2, db2), (dh, x, dW1, db1)]
         d_rows = None
         if ni[0] or ni[1] or ni[2]:
@@ -590,7 +616,8 @@ class _SeamSFunction(Function):
             probs.append((dzp, g, dW0, db0))
         _wgrad_multi(probs, tag + "_dw")            # the three weight gradients of the seam: one launch
         if ni[0]:
-            dg = _dgrad(dzp, w0, tag + "_dx0")
+            if dg is None:
+                dg = _dgrad(dzp, w0, tag + "_dx0")
             R = rows2.shape[0]
             d_rows = torch.empty((R, 256), dtype=torch.float32, device=dev)
             lib = _lib.load()

@@ -478,6 +478,8 @@ typedef struct bevmsda_layernorm_desc {
  * order, not bit for bit. */
 int64_t bevmsda_linear_panel_packed_bytes(int N, int K);
 int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream);
+/* ... of the (N, K) weight whose transpose lies in memory: wt (K, ldwt), element (n, k) = wt[k * ldwt + n] (backward GEMMs). */
+int bevmsda_linear_panel_pack_weight_t_f32(const float *wt, int64_t ldwt, int N, int K, uint16_t *blob, void *stream);
 int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                              const float *scale, const uint16_t *wpanel, const float *bias,
                              const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,
@@ -544,6 +546,22 @@ int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, cons
                                      const float *beta1, const bevmsda_chain_desc *desc, float *y, float *save_z0,
                                      float *save_x, float *save_h, float *save_z1, const float *drop0, const float *droph,
                                      const float *drop1, void *stream);
+
+/* The BACKWARD of that launch in one kernel (linear_chain.h MODE 2; the rows are complete in a workgroup, so both LayerNorm
+ * backwards are row-local like the forward's LayerNorms): from grad_y (M, ld_grad_y) and the saved save_z0 / save_h / save_z1
+ *     grad_z1 = LayerNorm1'(save_z1; grad_y)                     grad_gamma_beta1 (2, 256) += [sum g xhat | sum g]
+ *     grad_h  = (grad_z1 w2) where save_h > 0                     (M, 512)
+ *     grad_z0 = LayerNorm0'(save_z0; grad_h w1 + grad_z1)         grad_gamma_beta0 (2, 256) += ...      (= the residual's gradient)
+ *     grad_in = grad_z0 w0                                        (M, 256): the gradient of the seam's (gathered) input rows
+ * i.e. encoder.py:376-404 / the mmcv FFN / spatial_cross_attention.py:173-175 differentiated.  w0t_p / w1t_p / w2t_p: the
+ * row-panel weight images (bevmsda_linear_panel_pack_weight_f32) of w0^T (256 x 256), w1^T (256 x 512), w2^T (512 x 256).
+ * grad_z1 / grad_h / grad_z0 are outputs because the weight gradients read them (bevmsda_linear_wgrad_multi_f32).  The
+ * caller zeroes grad_gamma_beta*.  No dropout scales (train() mode with active dropout takes the per-kernel backward). */
+int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, const float *save_z0, const float *save_h,
+                                        const float *save_z1, const float *gamma0, const float *gamma1, const uint16_t *w0t_p,
+                                        const uint16_t *w1t_p, const uint16_t *w2t_p, const bevmsda_chain_desc *desc,
+                                        float *grad_z1, float *grad_h, float *grad_z0, float *grad_in, float *grad_gamma_beta1,
+                                        float *grad_gamma_beta0, void *stream);
 /* drop0 (M, 256), droph (M, 512), drop1 (M, 256): dropout scale tensors (0 or 1 / (1 - p); NULL = inactive) of the three
  * nn.Dropout sites of the chain in train() mode — on the attention's projected output before "+ identity"
  * (spatial_cross_attention.py:175), on the FFN's hidden activations and on its output (mmcv FFN); save_h then holds the
