@@ -549,6 +549,37 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+// ---- backward of the projection + LayerNorm + projection chain (linear_chain.h, MODE 3)
+int bevmsda_proj_ln_proj_chain_backward_f32(const float *grad_proj, int64_t ld_grad_proj, const float *grad_x, const float *save_z0,
+                                            const float *gamma0, const uint16_t *w0t_p, const uint16_t *w1t_p,
+                                            const bevmsda_chain_desc *d, float *grad_z0, float *grad_in, float *grad_gamma_beta0,
+                                            void *stream) {
+  if (!d) return BEVMSDA_ERR_NULL_POINTER;
+  if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
+  const int N2 = d->reserved[0];
+  if (d->C != bevmsda::kChainC || N2 <= 0 || N2 % 256 != 0 || N2 > bevmsda::kChainMaxN2) return BEVMSDA_ERR_UNSUPPORTED;
+  if (d->M == 0) return BEVMSDA_OK;
+  if (!grad_proj || !save_z0 || !gamma0 || !w0t_p || !w1t_p || !grad_z0 || !grad_in || !grad_gamma_beta0) return BEVMSDA_ERR_NULL_POINTER;
+  if (ld_grad_proj % 4 != 0) return BEVMSDA_ERR_UNSUPPORTED;
+  if (ld_grad_proj < N2) return BEVMSDA_ERR_BAD_SHAPE;
+  if (misaligned(grad_proj) || (grad_x && misaligned(grad_x)) || misaligned(save_z0) || misaligned(gamma0) || misaligned(w0t_p) ||
+      misaligned(w1t_p) || misaligned(grad_z0) || misaligned(grad_in) || (reinterpret_cast<uintptr_t>(grad_gamma_beta0) & 3u))
+    return BEVMSDA_ERR_MISALIGNED;
+  const long long nb = (d->M + 31) / 32;
+  if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  bevmsda::ChainArgs a{};
+  a.w0 = w0t_p; a.w1 = w1t_p; a.N2 = N2;
+  a.gamma0 = gamma0; a.eps0 = d->eps0; a.M = d->M;
+  a.bw_gy = grad_proj; a.bw_ld_gy = ld_grad_proj; a.bw_z1 = grad_x; a.bw_z0 = save_z0;
+  a.bw_gz0 = grad_z0; a.bw_din = grad_in; a.bw_dgb0 = grad_gamma_beta0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(nb));
+  if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 3, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<1, 0, 3, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
 static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                                 const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                                 const bevmsda_chain_desc *d, float *x_out, float *proj_out, void *stream, bool save,

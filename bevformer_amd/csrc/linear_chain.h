@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
   static_assert(PRE == 0 || PRE == 2, "PRE: 0 plain rows, 2 two-row gather");
-  static_assert(MODE != 2 || (MT == 1 && NT == 2 && PRE == 0 && !SAVE && !DROP), "MODE 2: 32-row workgroups of 4 wavefronts");
+  static_assert(MODE < 2 || (MT == 1 && NT == 2 && PRE == 0 && !SAVE && !DROP), "MODE 2 / 3: 32-row workgroups of 4 wavefronts");
   static_assert(NW * NT == 8 && (MT == 1 || MT == 2) && (NT == 1 || NT == 2), "workgroup shape");
   constexpr bool LO = NPROD == 3;
   constexpr int NPL = LO ? 2 : 1;
@@ -118,7 +118,7 @@ linear_chain_kernel(const ChainArgs a) {
   constexpr int BUF = (BM / 8) * 4 * 2048;     // one plane buffer: BM KiB
   constexpr int PPW = (BM / 8) * 4 / NW;       // (row block, line pair) DMA pairs per wavefront
   constexpr int NCST = 4 * kChainC + kChainMaxN2 + 2 * kChainC;       // gamma0, beta0, gamma1, beta1 | b1 | b0, b2
-  constexpr int NSTAT = MODE == 2 ? 2 : 1;    // (the LayerNorm backward exchanges two row sums at once)
+  constexpr int NSTAT = MODE >= 2 ? 2 : 1;    // (the LayerNorm backward exchanges two row sums at once)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NSTAT * NW * BM * 4 + NCST * 4];
   unsigned char *const buf0 = lds, *const buf1 = lds + BUF;
   float *const stat = reinterpret_cast<float *>(lds + 2 * BUF);       // [wave][row]
@@ -141,8 +141,8 @@ linear_chain_kernel(const ChainArgs a) {
     for (int t4 = tid * 4; t4 < NCST; t4 += NTHREADS * 4) {
       const float *src = nullptr;
       if (t4 < 256) src = a.gamma0 + t4;
-      else if (t4 < 512) src = MODE == 2 ? nullptr : a.beta0 + (t4 - 256);
-      else if (t4 < 768) src = MODE != 1 ? a.gamma1 + (t4 - 512) : nullptr;
+      else if (t4 < 512) src = MODE >= 2 ? nullptr : a.beta0 + (t4 - 256);
+      else if (t4 < 768) src = (MODE == 0 || MODE == 2) ? a.gamma1 + (t4 - 512) : nullptr;
       else if (t4 < 1024) src = MODE == 0 ? a.beta1 + (t4 - 768) : nullptr;
       else if (t4 < 1024 + kChainMaxN2) src = (a.b1 && t4 - 1024 < nb1) ? a.b1 + (t4 - 1024) : nullptr;
       else if (t4 < 1024 + kChainMaxN2 + 256) src = a.b0 ? a.b0 + (t4 - 1024 - kChainMaxN2) : nullptr;
@@ -335,7 +335,9 @@ linear_chain_kernel(const ChainArgs a) {
         }
   };
 
-  const unsigned w0b = 8u * 16 * 2 * 1024, w1b = static_cast<unsigned>((nb1 + 63) / 64 * 2) * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
+  const unsigned w0b = 8u * 16 * 2 * 1024, w2b = 8u * 32 * 2 * 1024;   // image bytes
+  const unsigned w1b = MODE == 3 ? 8u * static_cast<unsigned>(a.N2 / 16) * 2 * 1024      // (W1^T: 256 rows, K = N2)
+                                 : static_cast<unsigned>((nb1 + 63) / 64 * 2) * 16 * 2 * 1024;
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w0), 0, static_cast<int>(w0b), 0x00020000);
   __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w1), 0, static_cast<int>(w1b), 0x00020000);
   __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(MODE != 1 ? a.w2 : a.w0), 0, static_cast<int>(MODE != 1 ? w2b : w0b), 0x00020000);
@@ -353,7 +355,7 @@ linear_chain_kernel(const ChainArgs a) {
       for (int g = 0; g < 4; ++g)
         rs[i][j][g] = rrow ? *reinterpret_cast<const float4 *>(rrow + ncol(j) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if constexpr (MODE != 2) wprefetch(r0, wave, 16, 0);
+  if constexpr (MODE < 2) wprefetch(r0, wave, 16, 0);
 
   auto store_tile = [&](const auto &c, float *out, long ld, int col0) {
 #pragma unroll
@@ -384,8 +386,8 @@ linear_chain_kernel(const ChainArgs a) {
     }
   };
 
-  if constexpr (MODE == 2) {
-    // ================================================================== MODE 2: the backward of MODE 0 on the same machinery
+  if constexpr (MODE >= 2) {
+    // ================================================================== MODE 2 / 3: the backwards of MODE 0 / 1 on the same machinery
     //   gz1 = LN1'(z1; gy)                         column sums -> grad gamma1 / beta1
     //   gh  = (gz1 W2) where h > 0                  (two halves of 256 hidden columns, as the forward)
     //   gx  = gh W1 + gz1                           (x feeds the FFN and, as its residual, LayerNorm1's input)
@@ -509,6 +511,76 @@ linear_chain_kernel(const ChainArgs a) {
       __syncthreads();                         // `stat` / `stat2` may be written again
     };
 
+    if constexpr (MODE == 3) {
+      // ---------------------------------------------------------------- MODE 3: the backward of MODE 1
+      //   gx  = gp W1 (+ the gradient that reached x directly)      gp (M, N2): N2 / 256 panel passes, K = N2
+      //   gz0 = LN0'(z0; gx)                                        column sums -> grad gamma0 / beta0
+      //   din = gz0 W0
+      // bw_gy = gp (row stride bw_ld_gy), bw_z1 = the direct gradient of x (M, 256) or nullptr, w1 = image of W1^T
+      auto fetch_plain = [&](const float *src, long ld, unsigned char *buf) {     // 32 rows x 256 floats -> planes
+        const int d_rl = lane >> 3, d_cc = lane & 7;
+        const int row = panel_row_of(wave * PPW / 4, d_rl);
+        static_assert(PPW == 4, "one row block (4 line pairs) per wavefront");
+        const int cx = d_cc ^ (row & 7);
+        long gm = m0 + row;
+        if (gm >= a.M) gm = a.M - 1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float *sp = src + gm * ld + (2 * p) * 32 + cx * 4;
+          unsigned char *dst = buf + (wave * 4 + p) * 2048;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp),
+                                           (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + 32),
+                                           (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned char *slot = buf + (wave * 4 + p) * 2048 + lane * 16;
+          const float4 va = *reinterpret_cast<const float4 *>(slot);
+          const float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
+          uint4 hi, lo;
+          lin_split8<LO>(va, vb, hi, lo);
+          *reinterpret_cast<uint4 *>(slot) = hi;
+          if (LO) *reinterpret_cast<uint4 *>(slot + 1024) = lo;
+        }
+      };
+      const int nck = a.N2 / 256, nstep1 = a.N2 / 16;
+      zero(acc);
+#pragma unroll 1
+      for (int c = 0; c < nck; ++c) {
+        unsigned char *buf = (c & 1) ? buf1 : buf0;
+        wprefetch(r1, wave, nstep1, c * 16);
+        fetch_plain(a.bw_gy + c * 256, a.bw_ld_gy, buf);
+        __syncthreads();                       // the pass's planes are complete (and, c >= 2: the buffer was free)
+        gemm16(acc, buf, r1, wave, nstep1, c * 16);
+        if (c + 2 < nck) __syncthreads();      // pass c + 2 rewrites this buffer
+      }
+      if (a.bw_z1) {                           // the gradient x received as the next attention's residual
+        load_tile(xk, a.bw_z1, kChainC, NT * wave * 32, true);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][j][r] += xk[0][j][r];
+      }
+      if (!row_ok) {                           // rows past M: no contribution to the column sums
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+      }
+      load_tile(acc2, a.bw_z0, kChainC, NT * wave * 32, false);
+      layernorm_bwd(acc2, acc, c_g0, a.eps0, a.bw_dgb0);
+      wprefetch(r0, wave, 16, 0);
+      store_tile(acc, a.bw_gz0, kChainC, NT * wave * 32);
+      unsigned char *bufz = (nck & 1) ? buf1 : buf0;      // the buffer the last pass did not read
+      to_planes(acc, bufz);
+      __syncthreads();
+      zero(acc2);
+      gemm16(acc2, bufz, r0, wave, 16, 0);
+      store_tile(acc2, a.bw_din, kChainC, NT * wave * 32);
+      return;
+    }
     load_tile(acc, a.bw_gy, a.bw_ld_gy, NT * wave * 32, true);
     load_tile(acc2, a.bw_z1, kChainC, NT * wave * 32, false);
     __syncthreads();                           // the per-column constants are in LDS

@@ -454,6 +454,32 @@ class _SeamTFunction(Function):
                 gx = gx.float().contiguous()
         probs = []
         gp2 = dxp = None
+        if gp is not None and ctx.drop0 is None and N2 % 256 == 0 and N2 <= 768 and _m().chain_backward and ni[0]:
+            # ONE kernel for the row-local part (linear_chain.h MODE 3): gp w1 (+ gx) -> LayerNorm backward -> . w0
+            gp2, ldp = ops._rows2d(gp.reshape(M, N2).float(), N2)
+            if ni[6] or ni[7]:
+                probs.append((gp2, x, dW1, db1))
+            dzr = torch.empty(ctx.res_shape, dtype=torch.float32, device=dev)
+            d_in = torch.empty((M, 256), dtype=torch.float32, device=dev)
+            gb0, = _zeros(dev, (2, 256))
+            desc = _lib.ChainDesc(M=M, ld_rows=256, ld_res=256, ld_y=256, C=256, F=N2, precision=_prec(), eps0=ctx.eps0, eps1=0.0)
+            desc.reserved[0] = N2
+            blobs = [ops.panel_weight(_aligned(w.detach()).t()) for w in (w0, w1)]
+            if any(b is None for b in blobs):
+                raise RuntimeError("bevmsda: no transposed panel image for the chain backward")
+            cb = ops._GEMM_TIMER["cb"]
+            tctx = cb(ctx.tag + "_bwd", 2.0 * M * 256 * (256 + N2), 4.0 * M * (N2 + 256 * 4)) if cb is not None else ops._NoTimer()
+            with torch.cuda.device(dev), tctx:
+                _lib.check(_lib.load().bevmsda_proj_ln_proj_chain_backward_f32(
+                    _ptr(gp2), ldp, _ptr(gx) if gx is not None else None, _ptr(z0), _ptr(gamma0.detach().contiguous()),
+                    _ptr(blobs[0]), _ptr(blobs[1]), ctypes.byref(desc), _ptr(dzr), _ptr(d_in), _ptr(gb0),
+                    torch.cuda.current_stream().cuda_stream), "proj_ln_proj_chain backward")
+            if ni[1] or ni[2]:
+                probs.append((dzr.view(M, 256), rows2, dW0, db0))
+            _wgrad_multi(probs, ctx.tag + "_dw")
+            return (d_in.view(ctx.rows_shape), dW0 if ni[1] else None, db0 if (ctx.has_b0 and ni[2]) else None,
+                    dzr if ni[3] else None, gb0[0] if ni[4] else None, gb0[1] if ni[5] else None, dW1 if ni[6] else None,
+                    db1 if (ctx.has_b1 and ni[7]) else None, None, None, None)
         if gp is not None:
             gp2 = gp.reshape(M, N2).float()
             if ni[6] or ni[7]:

@@ -562,6 +562,18 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
                                         const uint16_t *w1t_p, const uint16_t *w2t_p, const bevmsda_chain_desc *desc,
                                         float *grad_z1, float *grad_h, float *grad_z0, float *grad_in, float *grad_gamma_beta1,
                                         float *grad_gamma_beta0, void *stream);
+
+/* The backward of bevmsda_proj_ln_proj_chain_train_f32 in one kernel (linear_chain.h MODE 3):
+ *     grad_z0 = LayerNorm0'(save_z0; grad_proj w1 + grad_x)     grad_gamma_beta0 (2, 256) += [sum g xhat | sum g]
+ *     grad_in = grad_z0 w0
+ * grad_proj (M, ld_grad_proj) with desc->reserved[0] = N2 columns (a multiple of 256, <= 768: N2 / 256 panel passes), grad_x
+ * (M, 256) or NULL: the gradient x received directly (it is the next attention's residual).  w0t_p / w1t_p: row-panel images
+ * of w0^T (256 x 256) and w1^T (256 x N2).  temporal_self_attention.py:267-272 + the projections of
+ * spatial_cross_attention.py:338-348 differentiated. */
+int bevmsda_proj_ln_proj_chain_backward_f32(const float *grad_proj, int64_t ld_grad_proj, const float *grad_x, const float *save_z0,
+                                            const float *gamma0, const uint16_t *w0t_p, const uint16_t *w1t_p,
+                                            const bevmsda_chain_desc *desc, float *grad_z0, float *grad_in,
+                                            float *grad_gamma_beta0, void *stream);
 /* drop0 (M, 256), droph (M, 512), drop1 (M, 256): dropout scale tensors (0 or 1 / (1 - p); NULL = inactive) of the three
  * nn.Dropout sites of the chain in train() mode — on the attention's projected output before "+ identity"
  * (spatial_cross_attention.py:175), on the FFN's hidden activations and on its output (mmcv FFN); save_h then holds the
