@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--backward", action="store_true",
                     help="time forward + backward of the encoder (autograd path; one captured HIP graph of the whole "
                          "step unless --graph off; BASELINE configs[2] style)")
+    ap.add_argument("--train-mode", action="store_true",
+                    help="with --backward: the encoder in train() mode (dropout p = 0.1 active, the reference's training step)")
     ap.add_argument("--first-frame", action="store_true", help="no history BEV (prev_bev=None)")
     ap.add_argument("--static-rig", action="store_true",
                     help="same camera matrices every step (the frame plan is then built once)")
@@ -664,7 +666,8 @@ def main():
     from bevformer_amd import synthetic as S
 
     gemm = args.gemm or ops.gemm_mode()
-    cfg = Config(args, dev, args.workload, gemm, args.value_storage, args.backward, args.first_frame, world, tiling)
+    cfg = Config(args, dev, args.workload, gemm, args.value_storage, args.backward, args.first_frame, world, tiling,
+                 train_mode=bool(args.backward and args.train_mode))
     cfg.modes()
     timer = KernelTimer()
     if not args.no_kernel_timers:

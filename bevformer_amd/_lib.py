@@ -96,9 +96,10 @@ SIGNATURES = {
     "bevmsda_cast_rows_bf16": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_int, ctypes.c_float, _c_void_p, _c_void_p], _c_int),
     "bevmsda_rows_from_slots_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, _c_int,
                                      _c_void_p, _c_void_p], _c_int),
-    "bevmsda_proj_ln_proj_chain_backward_f32": ([_c_void_p, ctypes.c_int64] + [_c_void_p] * 5 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 4,
+    "bevmsda_proj_ln_proj_chain_backward_f32": ([_c_void_p, ctypes.c_int64] + [_c_void_p] * 5 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 6,
                                                 _c_int),
-    "bevmsda_proj_ffn_chain_backward_f32": ([_c_void_p, ctypes.c_int64] + [_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 7,
+    "bevmsda_proj_ffn_chain_backward_f32": ([_c_void_p, ctypes.c_int64] + [_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 6
+                                            + [_c_void_p, _c_void_p, ctypes.c_float, _c_void_p, _c_void_p],
                                             _c_int),
     "bevmsda_proj_ffn_chain_train_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 9, _c_int),
     "bevmsda_proj_ln_proj_chain_train_f32": ([_c_void_p] * 8 + [ctypes.POINTER(ChainDesc)] + [_c_void_p] * 5, _c_int),

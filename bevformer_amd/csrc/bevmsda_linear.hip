@@ -516,7 +516,8 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
                                         const float *save_z1, const float *gamma0, const float *gamma1, const uint16_t *w0t_p,
                                         const uint16_t *w1t_p, const uint16_t *w2t_p, const bevmsda_chain_desc *d, float *grad_z1,
                                         float *grad_h, float *grad_z0, float *grad_in, float *grad_gamma_beta1,
-                                        float *grad_gamma_beta0, void *stream) {
+                                        float *grad_gamma_beta0, const float *drop0, const float *drop1, float hidden_scale,
+                                        float *grad_zp, void *stream) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -542,6 +543,9 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
   a.bw_gy = grad_y; a.bw_ld_gy = ld_grad_y; a.bw_z1 = save_z1; a.bw_h = save_h; a.bw_z0 = save_z0;
   a.bw_gz1 = grad_z1; a.bw_gh = grad_h; a.bw_gz0 = grad_z0; a.bw_din = grad_in;
   a.bw_dgb1 = grad_gamma_beta1; a.bw_dgb0 = grad_gamma_beta0;
+  if (drop0 && !grad_zp) return BEVMSDA_ERR_NULL_POINTER;
+  if ((drop0 && misaligned(drop0)) || (drop1 && misaligned(drop1)) || (grad_zp && misaligned(grad_zp))) return BEVMSDA_ERR_MISALIGNED;
+  a.dk0 = drop0; a.dk1 = drop1; a.bw_hscale = hidden_scale; a.bw_gzp = grad_zp;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
   if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 2, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);
@@ -553,7 +557,7 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
 int bevmsda_proj_ln_proj_chain_backward_f32(const float *grad_proj, int64_t ld_grad_proj, const float *grad_x, const float *save_z0,
                                             const float *gamma0, const uint16_t *w0t_p, const uint16_t *w1t_p,
                                             const bevmsda_chain_desc *d, float *grad_z0, float *grad_in, float *grad_gamma_beta0,
-                                            void *stream) {
+                                            const float *drop0, float *grad_zp, void *stream) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   if (d->M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (d->precision != 0 && d->precision != 1) return BEVMSDA_ERR_BAD_OPTION;
@@ -573,6 +577,9 @@ int bevmsda_proj_ln_proj_chain_backward_f32(const float *grad_proj, int64_t ld_g
   a.gamma0 = gamma0; a.eps0 = d->eps0; a.M = d->M;
   a.bw_gy = grad_proj; a.bw_ld_gy = ld_grad_proj; a.bw_z1 = grad_x; a.bw_z0 = save_z0;
   a.bw_gz0 = grad_z0; a.bw_din = grad_in; a.bw_dgb0 = grad_gamma_beta0;
+  if (drop0 && !grad_zp) return BEVMSDA_ERR_NULL_POINTER;
+  if ((drop0 && misaligned(drop0)) || (grad_zp && misaligned(grad_zp))) return BEVMSDA_ERR_MISALIGNED;
+  a.dk0 = drop0; a.bw_gzp = grad_zp; a.bw_hscale = 1.f;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
   if (d->precision == 0) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<3, 0, 3, 1, 2, 4, false, false>), grid, dim3(256), 0, st, a);

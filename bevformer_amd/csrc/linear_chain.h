@@ -76,6 +76,11 @@ struct ChainArgs {
   float *bw_gz0;                    // (M, 256) gradient of z0 = LayerNorm0's input (= the residual's gradient)
   float *bw_din;                    // (M, 256) gz0 W0: gradient of the seam's input rows (A)
   float *bw_dgb1, *bw_dgb0;         // (2, 256) each: [grad gamma | grad beta] of LayerNorm1 / 0, ADDED to (caller zeroes)
+  // train() mode (the forward ran with DROP): dk1 / dk0 above are the scale tensors of the FFN-output / attention dropouts —
+  // bw_gz1 then holds gz1 * dk1 (the FFN output's gradient; x still receives gz1), gh is scaled by bw_hscale = 1 / (1 - p) of
+  // the hidden dropout (h is zero where dropped), and the projection's gradient gz0 * dk0 goes to bw_gzp (din = that W0)
+  float bw_hscale;
+  float *bw_gzp;
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -573,6 +578,10 @@ linear_chain_kernel(const ChainArgs a) {
       layernorm_bwd(acc2, acc, c_g0, a.eps0, a.bw_dgb0);
       wprefetch(r0, wave, 16, 0);
       store_tile(acc, a.bw_gz0, kChainC, NT * wave * 32);
+      if (a.dk0) {                             // through the dropout on the projection's output
+        scale_tile(acc, a.dk0, kChainC, NT * wave * 32);
+        store_tile(acc, a.bw_gzp, kChainC, NT * wave * 32);
+      }
       unsigned char *bufz = (nck & 1) ? buf1 : buf0;      // the buffer the last pass did not read
       to_planes(acc, bufz);
       __syncthreads();
@@ -588,8 +597,9 @@ linear_chain_kernel(const ChainArgs a) {
     wprefetch(r1, wave, 16, 0);
 #pragma unroll
     for (int j = 0; j < NT; ++j) xk[0][j] = acc[0][j];
-    store_tile(xk, a.bw_gz1, kChainC, NT * wave * 32);
-    to_planes(xk, buf1);
+    if (a.dk1) scale_tile(acc, a.dk1, kChainC, NT * wave * 32);     // the FFN's output dropout: df = gz1 * dk1 (x keeps gz1)
+    store_tile(acc, a.bw_gz1, kChainC, NT * wave * 32);
+    to_planes(acc, buf1);
     __syncthreads();
     zero(acc2);
 #pragma unroll 1
@@ -604,10 +614,11 @@ linear_chain_kernel(const ChainArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const float4 hv = *reinterpret_cast<const float4 *>(hrow + j * 32 + 4 * (lane >> 5) + 8 * g);
-            acc[0][j][4 * g] = hv.x > 0.f ? acc[0][j][4 * g] : 0.f;
-            acc[0][j][4 * g + 1] = hv.y > 0.f ? acc[0][j][4 * g + 1] : 0.f;
-            acc[0][j][4 * g + 2] = hv.z > 0.f ? acc[0][j][4 * g + 2] : 0.f;
-            acc[0][j][4 * g + 3] = hv.w > 0.f ? acc[0][j][4 * g + 3] : 0.f;
+            const float hs = a.bw_hscale;
+            acc[0][j][4 * g] = hv.x > 0.f ? acc[0][j][4 * g] * hs : 0.f;
+            acc[0][j][4 * g + 1] = hv.y > 0.f ? acc[0][j][4 * g + 1] * hs : 0.f;
+            acc[0][j][4 * g + 2] = hv.z > 0.f ? acc[0][j][4 * g + 2] * hs : 0.f;
+            acc[0][j][4 * g + 3] = hv.w > 0.f ? acc[0][j][4 * g + 3] * hs : 0.f;
           }
       }
       store_tile(acc, a.bw_gh, kChainF, half * 256 + NT * wave * 32);
@@ -625,6 +636,10 @@ linear_chain_kernel(const ChainArgs a) {
     layernorm_bwd(acc, acc2, c_g0, a.eps0, a.bw_dgb0);
     wprefetch(r0, wave, 16, 0);
     store_tile(acc2, a.bw_gz0, kChainC, NT * wave * 32);
+    if (a.dk0) {                               // through the attention's dropout
+      scale_tile(acc2, a.dk0, kChainC, NT * wave * 32);
+      store_tile(acc2, a.bw_gzp, kChainC, NT * wave * 32);
+    }
     to_planes(acc2, buf1);
     __syncthreads();
     zero(acc);

@@ -454,13 +454,14 @@ class _SeamTFunction(Function):
                 gx = gx.float().contiguous()
         probs = []
         gp2 = dxp = None
-        if gp is not None and ctx.drop0 is None and N2 % 256 == 0 and N2 <= 768 and _m().chain_backward and ni[0]:
+        if gp is not None and N2 % 256 == 0 and N2 <= 768 and _m().chain_backward and ni[0]:
             # ONE kernel for the row-local part (linear_chain.h MODE 3): gp w1 (+ gx) -> LayerNorm backward -> . w0
             gp2, ldp = ops._rows2d(gp.reshape(M, N2).float(), N2)
             if ni[6] or ni[7]:
                 probs.append((gp2, x, dW1, db1))
             dzr = torch.empty(ctx.res_shape, dtype=torch.float32, device=dev)
             d_in = torch.empty((M, 256), dtype=torch.float32, device=dev)
+            dzp = torch.empty((M, 256), dtype=torch.float32, device=dev) if ctx.drop0 is not None else None
             gb0, = _zeros(dev, (2, 256))
             desc = _lib.ChainDesc(M=M, ld_rows=256, ld_res=256, ld_y=256, C=256, F=N2, precision=_prec(), eps0=ctx.eps0, eps1=0.0)
             desc.reserved[0] = N2
@@ -473,9 +474,10 @@ class _SeamTFunction(Function):
                 _lib.check(_lib.load().bevmsda_proj_ln_proj_chain_backward_f32(
                     _ptr(gp2), ldp, _ptr(gx) if gx is not None else None, _ptr(z0), _ptr(gamma0.detach().contiguous()),
                     _ptr(blobs[0]), _ptr(blobs[1]), ctypes.byref(desc), _ptr(dzr), _ptr(d_in), _ptr(gb0),
+                    _ptr(ctx.drop0) if ctx.drop0 is not None else None, _ptr(dzp) if dzp is not None else None,
                     torch.cuda.current_stream().cuda_stream), "proj_ln_proj_chain backward")
             if ni[1] or ni[2]:
-                probs.append((dzr.view(M, 256), rows2, dW0, db0))
+                probs.append((dzp if dzp is not None else dzr.view(M, 256), rows2, dW0, db0))
             _wgrad_multi(probs, ctx.tag + "_dw")
             return (d_in.view(ctx.rows_shape), dW0 if ni[1] else None, db0 if (ctx.has_b0 and ni[2]) else None,
                     dzr if ni[3] else None, gb0[0] if ni[4] else None, gb0[1] if ni[5] else None, dW1 if ni[6] else None,
@@ -600,13 +602,14 @@ class _SeamSFunction(Function):
             gy = gy.float().contiguous()
         dW0, db0, dW1, db1, dW2, db2 = _zeros(dev, (256, 256), (256,), (512, 256), (512,), (256, 512), (256,))
         dg = None
-        if ctx.drop0 is None and ctx.drop1 is None and ctx.hidden_scale == 1.0 and _m().chain_backward:
+        if _m().chain_backward:
             # ONE kernel for the row-local part of the backward (linear_chain.h MODE 2): both LayerNorm backwards, the
             # ReLU-masked FFN input gradients and the output projection's, with the rows resident as in the forward
             dz1 = torch.empty((M, 256), dtype=torch.float32, device=dev)
             dh = torch.empty((M, 512), dtype=torch.float32, device=dev)
             dzr = torch.empty(ctx.res_shape, dtype=torch.float32, device=dev)
             dg = torch.empty((M, 256), dtype=torch.float32, device=dev)
+            dzp = torch.empty((M, 256), dtype=torch.float32, device=dev) if ctx.drop0 is not None else None
             gb1, gb0 = _zeros(dev, (2, 256), (2, 256))
             desc = _lib.ChainDesc(M=M, ld_rows=256, ld_res=256, ld_y=256, C=256, F=512, precision=_prec(), eps0=ctx.eps0,
                                   eps1=ctx.eps1)
@@ -620,10 +623,13 @@ class _SeamSFunction(Function):
                     _ptr(gy), 256, _ptr(z0), _ptr(h), _ptr(z1), _ptr(gamma0.detach().contiguous()),
                     _ptr(gamma1.detach().contiguous()), _ptr(blobs[0]), _ptr(blobs[1]), _ptr(blobs[2]), ctypes.byref(desc),
                     _ptr(dz1), _ptr(dh), _ptr(dzr), _ptr(dg), _ptr(gb1), _ptr(gb0),
+                    _ptr(ctx.drop0) if ctx.drop0 is not None else None, _ptr(ctx.drop1) if ctx.drop1 is not None else None,
+                    float(ctx.hidden_scale), _ptr(dzp) if dzp is not None else None,
                     torch.cuda.current_stream().cuda_stream), "proj_ffn_chain backward")
             dg1, dbe1, dg0, dbe0 = gb1[0], gb1[1], gb0[0], gb0[1]
-            df, dz0 = dz1, dzr.view(M, 256)
-            dzp = dz0
+            df, dz0 = dz1, dzr.view(M, 256)            # (train() mode: dz1 already carries the FFN-output dropout's scale)
+            if dzp is None:
+                dzp = dz0
         else:
             # LayerNorm1, FFN
             dz1, dg1, dbe1 = _ln_backward(z1, gamma1, gy, ctx.eps1)

@@ -556,12 +556,16 @@ int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, cons
  * i.e. encoder.py:376-404 / the mmcv FFN / spatial_cross_attention.py:173-175 differentiated.  w0t_p / w1t_p / w2t_p: the
  * row-panel weight images (bevmsda_linear_panel_pack_weight_f32) of w0^T (256 x 256), w1^T (256 x 512), w2^T (512 x 256).
  * grad_z1 / grad_h / grad_z0 are outputs because the weight gradients read them (bevmsda_linear_wgrad_multi_f32).  The
- * caller zeroes grad_gamma_beta*.  No dropout scales (train() mode with active dropout takes the per-kernel backward). */
+ * caller zeroes grad_gamma_beta*.  train() mode (the forward ran with drop0 / droph / drop1): drop1 (M, 256) scales grad_z1 on
+ * its way into the FFN (grad_z1 then holds the scaled gradient; x still receives the unscaled one), hidden_scale = 1 / (1 - p)
+ * of the hidden dropout (save_h is zero where it dropped), drop0 (M, 256) scales grad_z0 on its way into the projection:
+ * grad_zp (M, 256) = grad_z0 * drop0 is stored and grad_in = grad_zp w0.  NULL / 1.0 / NULL: no dropout. */
 int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, const float *save_z0, const float *save_h,
                                         const float *save_z1, const float *gamma0, const float *gamma1, const uint16_t *w0t_p,
                                         const uint16_t *w1t_p, const uint16_t *w2t_p, const bevmsda_chain_desc *desc,
                                         float *grad_z1, float *grad_h, float *grad_z0, float *grad_in, float *grad_gamma_beta1,
-                                        float *grad_gamma_beta0, void *stream);
+                                        float *grad_gamma_beta0, const float *drop0, const float *drop1, float hidden_scale,
+                                        float *grad_zp, void *stream);
 
 /* The backward of bevmsda_proj_ln_proj_chain_train_f32 in one kernel (linear_chain.h MODE 3):
  *     grad_z0 = LayerNorm0'(save_z0; grad_proj w1 + grad_x)     grad_gamma_beta0 (2, 256) += [sum g xhat | sum g]
@@ -569,11 +573,11 @@ int bevmsda_proj_ffn_chain_backward_f32(const float *grad_y, int64_t ld_grad_y, 
  * grad_proj (M, ld_grad_proj) with desc->reserved[0] = N2 columns (a multiple of 256, <= 768: N2 / 256 panel passes), grad_x
  * (M, 256) or NULL: the gradient x received directly (it is the next attention's residual).  w0t_p / w1t_p: row-panel images
  * of w0^T (256 x 256) and w1^T (256 x N2).  temporal_self_attention.py:267-272 + the projections of
- * spatial_cross_attention.py:338-348 differentiated. */
+ * spatial_cross_attention.py:338-348 differentiated.  drop0 / grad_zp: as above (the attention's dropout of train() mode). */
 int bevmsda_proj_ln_proj_chain_backward_f32(const float *grad_proj, int64_t ld_grad_proj, const float *grad_x, const float *save_z0,
                                             const float *gamma0, const uint16_t *w0t_p, const uint16_t *w1t_p,
                                             const bevmsda_chain_desc *desc, float *grad_z0, float *grad_in,
-                                            float *grad_gamma_beta0, void *stream);
+                                            float *grad_gamma_beta0, const float *drop0, float *grad_zp, void *stream);
 /* drop0 (M, 256), droph (M, 512), drop1 (M, 256): dropout scale tensors (0 or 1 / (1 - p); NULL = inactive) of the three
  * nn.Dropout sites of the chain in train() mode — on the attention's projected output before "+ identity"
  * (spatial_cross_attention.py:175), on the FFN's hidden activations and on its output (mmcv FFN); save_h then holds the
