@@ -104,17 +104,21 @@ def query_blocks(num_queries, world):
     return out
 
 
-_PERMS = {}
+_PERMS = {}                      # for callers without an encoder (tests, tools); guarded by _PERMS_LOCK
+_PERMS_LOCK = __import__("threading").Lock()
 
 
-def sector_order(bev_h, bev_w, pc_range, device, group=None, collective=False):
+def sector_order(bev_h, bev_w, pc_range, device, group=None, collective=False, cache=None):
     """(name, perm, inverse, perm on the CPU) of the sector layout on ``device``: ``perm[q'] = cell``,
     ``inverse[cell] = q'``.  ``collective`` (a real process group, not a simulated rank): every rank takes RANK 0's
     permutation (one broadcast, once per grid) — the order comes out of float ``arctan2`` / ``hypot`` and a sort, and
     ranks whose libm or numpy round a tie differently would otherwise slice their tiles from different orders and
     reassemble a silently scrambled grid."""
     key = (bev_h, bev_w, tuple(float(v) for v in pc_range), str(device), id(group) if collective else None)
-    hit = _PERMS.get(key)
+    if cache is None:               # ``cache``: the encoder's own table (``tiled_forward``) — no state shared between encoders
+        with _PERMS_LOCK:
+            return sector_order(bev_h, bev_w, pc_range, device, group, collective, cache=_PERMS)
+    hit = cache.get(key)
     if hit is None:
         from .modules.geometry import sector_permutation
         perm = sector_permutation(bev_h, bev_w, [float(v) for v in pc_range])
@@ -125,7 +129,7 @@ def sector_order(bev_h, bev_w, pc_range, device, group=None, collective=False):
             perm = shared.cpu()
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(perm.numel())
-        hit = _PERMS[key] = (f"sectors{bev_h}x{bev_w}", perm.to(device), inv.to(device), perm)
+        hit = cache[key] = (f"sectors{bev_h}x{bev_w}", perm.to(device), inv.to(device), perm)
     return hit
 
 
@@ -203,7 +207,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     if sectors:
         # queries in sector order: tile = a contiguous range of that order; blocks in units of ONE query
         pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, bev_query.device, group=group,
-                                                      collective=tiling.simulate is None)
+                                                      collective=tiling.simulate is None,
+                                                      cache=encoder.__dict__.setdefault("_sector_orders", {}))
         cell_perm = (pname, perm_cpu)
         blocks, unit = query_blocks(bev_h * bev_w, world), 1
         q0, q1 = blocks[rank]

@@ -19,7 +19,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj")
 
     def __init__(self):
         env = os.environ.get
@@ -49,6 +49,10 @@ class Modes:
         self.train_chain = env("BEVMSDA_TRAIN_CHAIN", "1") == "1"
         self.wgrad_workgroups = int(env("BEVMSDA_WGRAD_WGS", "0"))  # benchmark knob: workgroup target of the multi-problem weight gradient
         self.wgrad_variant = int(env("BEVMSDA_WGRAD_VARIANT", "0"))  # 0: bf16 planes + transposing LDS reads; 1: gathered fragments
+        # training: the parameter-gradient arena of the encoder call being recorded (train_ops.GradArena; set by
+        # BEVFormerEncoder.forward for the duration of its call, carried to the backward pass by the Functions' snapshots)
+        self.grad_arena = None
+        self.overlap_value_proj = env("BEVMSDA_OVERLAP", "0") == "1"  # inference: hoisted SCA value projection on a side stream
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 
     def snapshot(self):

@@ -71,12 +71,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # sync, row count on the device); False keeps the torch-op builder with its host syncs
         self.device_plans = True
         self._planners = {}
-        # inference, opt-in (BEVMSDA_OVERLAP=1): issue the hoisted SCA value projection on a second stream so
+        # inference, opt-in (``ops.using(overlap_value_proj=True)`` / BEVMSDA_OVERLAP=1 at import): issue the hoisted SCA value projection on a second stream so
         # that it runs beside the first layer's TemporalSelfAttention chain, joined before the first
         # SpatialCrossAttention.  Measured: 4.956 vs 4.995 ms per base frame (0.8 %: the chain's kernels
         # leave few CUs idle) — not worth a second stream by default.
-        import os
-        self.overlap_value_proj = os.environ.get("BEVMSDA_OVERLAP", "0") == "1"
+        self.overlap_value_proj = None      # None: the ``overlap_value_proj`` mode (bevformer_amd/modes.py)
         self._side_stream = None
 
     # kept as static/instance methods with the reference's names and outputs
@@ -91,12 +90,13 @@ class BEVFormerEncoder(TransformerLayerSequence):
             return self.sca_row_order
         return "image"
 
-    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None, cell_perm=None):
+    def frame_plan(self, bev_h, bev_w, bs, img_metas, device, dtype, tile=None, cell_perm=None, train_fast=None):
         """The per-frame geometry.  On a GPU: two kernel launches into the planner's buffers, no
         host synchronisation (under autograd the plan is then materialised: one read of the row
         count, the torch statements of that path need sizes).  ``tile = (q0, q1)``: rows only for
         those BEV queries (bev_tiling).  ``cell_perm = (name, perm)``: the plan's queries are the BEV cells in that order
-        (bev_tiling's sector layout; ``name`` keys the caches)."""
+        (bev_tiling's sector layout; ``name`` keys the caches).  ``train_fast``: the caller's decision whether this call
+        runs the autograd fast path (``forward`` decides it once from its tensors; None: decided here from ``dtype``)."""
         device = torch.device(device)
         order = self.row_order()
         pname, perm = cell_perm if cell_perm is not None else (None, None)
@@ -115,7 +115,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 return plan
             # autograd: the fast path (train_ops.py) keeps the row count on the device and works on a private copy of
             # the row arrays; the per-op path needs sizes on the host (one read of the counters)
-            return plan.snapshot() if self._train_fast_path(device) else plan.materialize()
+            fast = self._train_fast_path(device) and dtype == torch.float32 if train_fast is None else train_fast
+            return plan.snapshot() if fast else plan.materialize()
         assert tile is None, "tiles of a host-built plan come from bev_tiling.slice_plan"
         assert order in geometry.ROW_ORDERS, f"host-built plans know the row orders {geometry.ROW_ORDERS}"
         key = geometry.plan_key(bev_h, bev_w, bs, self.pc_range, self.num_points_in_pillar,
@@ -130,12 +131,18 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._plan_cache[key] = plan
         return plan
 
-    def _train_fast_path(self, device=None):
+    def _train_fast_path(self, device=None, tensors=()):
         """Gradients are recorded and every layer can run its row-local parts on the chain kernels (train_ops.py):
-        the reference's operation order, dropout inactive, the MFMA kernels in use."""
-        from .. import train_ops
+        the reference's operation order, the MFMA kernels in use, every parameter (and every tensor of ``tensors``:
+        the call's floating-point inputs) fp32 — a ``.half()`` / ``.bfloat16()`` / ``.double()`` model or input takes
+        the per-op path, whose statements fall back to torch for the dtypes the kernels do not cover."""
         if not (torch.is_grad_enabled() and ops.modes().train_chain and not torch.is_autocast_enabled()
                 and ops.gemm_mode() != "native" and (device is None or torch.device(device).type == "cuda")):
+            return False
+        if any(t is not None and torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.float32
+               for t in tensors):
+            return False
+        if any(p.dtype != torch.float32 for p in self.parameters()):
             return False
         return all(getattr(layer, "chain_trainable", lambda: False)() for layer in self.layers)
 
@@ -143,13 +150,17 @@ class BEVFormerEncoder(TransformerLayerSequence):
         """Training fast path, once: lay the parameters of every merged projection back to back in memory
         (``ops.flatten_linear_params``) — the value projections of all layers (one grouped GEMM per family) and each
         attention's sampling-offset + attention-weight pair — so that their concatenations are views."""
-        if self.__dict__.get("_flat_params") or not ops.modes().flatten_params or torch.cuda.is_current_stream_capturing():
+        if not ops.modes().flatten_params or torch.cuda.is_current_stream_capturing():
             return
         atts = [getattr(layer, "attentions", None) for layer in self.layers]
         if any(a is None or len(a) != 2 or not hasattr(a[1], "deformable_attention") for a in atts):
             return
         tsas = [a[0] for a in atts]
         scas = [a[1].deformable_attention for a in atts]
+        if self.__dict__.get("_flat_params") and len(scas) > 1 \
+                and ops._adjacent([m.value_proj.weight.data for m in scas]):
+            return      # (still laid out back to back; a ``.to()`` / ``.float()`` / ``load_state_dict(assign=True)`` since
+            #             the last call gave every parameter its own storage again: lay them out anew)
         ops.flatten_linear_params(*[m.value_proj for m in scas])
         ops.flatten_linear_params(*[m.value_proj for m in tsas])
         for m in tsas + scas:
@@ -214,7 +225,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
             # which reach one image row + 1 pixel into the neighbouring cameras' rows: ops.linear docstring)
             seg = (plan.cam_start, S, spatial_shapes.contiguous())
         self._last_segments = seg            # (bench.py reports how many cameras a rank projects)
-        if self.overlap_value_proj and ops._GEMM_TIMER["cb"] is None:
+        overlap = ops.modes().overlap_value_proj if self.overlap_value_proj is None else self.overlap_value_proj
+        if overlap and ops._GEMM_TIMER["cb"] is None:
             cur = torch.cuda.current_stream(value.device)
             if self._side_stream is None or self._side_stream.device != value.device:
                 self._side_stream = torch.cuda.Stream(value.device)
@@ -281,6 +293,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         Nc, S, bs, C = value.shape
         if C != 256 or any(m.value_proj.weight.shape != (256, 256) for m in scas + tsas):
             return None, None
+        srcs = [value] + ([] if tsa_value is None else list(tsa_value) if isinstance(tsa_value, tuple) else [tsa_value])
+        srcs += [p for m in scas + tsas for p in (m.value_proj.weight, m.value_proj.bias)]
+        if any(t is None or not t.is_cuda or t.dtype != torch.float32 for t in srcs):
+            return None, None           # (the grouped GEMM is an fp32 kernel: other dtypes take the per-op path)
         feats = value.permute(2, 0, 1, 3).reshape(bs * Nc, S, C)
         w, b = ops.merged_linear_params(self, *[m.value_proj for m in scas], slot="_merged_sca_value")
         # bf16 value storage: the GEMM rounds in its epilogue, the sampling Functions hand their fp32 gradients back
@@ -316,6 +332,35 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 shift=0.0, **kwargs):
         """bev_query / bev_pos / prev_bev (Q, bs, C); key = value (Nc, S, bs, C);
         returns (bs, Q, C), or (num_layers, bs, Q, C) with return_intermediate."""
+        lowp = [t for t in (bev_query, key, value, bev_pos, prev_bev)
+                if torch.is_tensor(t) and t.dtype in (torch.float16, torch.bfloat16)]
+        if lowp:
+            # fp16 wrapper of the reference (``@auto_fp16()`` at encoder.py:151 with ``fp16_enabled`` set by
+            # ``wrap_fp16_model``, tools/fp16/train.py:224-226; ``get_bev_features`` hands over half ``bev_queries`` /
+            # ``prev_bev`` / ``bev_pos``, transformer.py:103): the inputs arrive ROUNDED to half precision; the kernels of
+            # this package compute in fp32 (bf16 storage at most), so the rounded inputs are widened once and the
+            # layer stack runs its fp32 path with autocast off — at least the reference's arithmetic (its Linear layers
+            # run in fp16 under autocast, its sampling and SpatialCrossAttention in fp32: ``custom_fwd(cast_inputs=
+            # torch.float32)``, ``force_fp32`` at spatial_cross_attention.py:75) — and returns fp32 like the
+            # reference's last LayerNorm does under autocast
+            def up(t):
+                return t.float() if torch.is_tensor(t) and t.dtype in (torch.float16, torch.bfloat16) else t
+            dev_type = bev_query.device.type
+            with torch.autocast(dev_type, enabled=False):
+                same = key is value
+                value = up(value)
+                return self._forward(up(bev_query), value if same else up(key), value, *[up(a) for a in args],
+                                     bev_h=bev_h, bev_w=bev_w, bev_pos=up(bev_pos), spatial_shapes=spatial_shapes,
+                                     level_start_index=level_start_index, valid_ratios=valid_ratios, prev_bev=up(prev_bev),
+                                     shift=up(shift), **kwargs)
+        return self._forward(bev_query, key, value, *args, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
+                             spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,
+                             prev_bev=prev_bev, shift=shift, **kwargs)
+
+    def _forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
+                 shift=0.0, **kwargs):
+        """``forward`` behind the precision wrapper (fp32 tensors, or whatever dtype an fp32-unaware caller chose)."""
         if self.bev_tiling is not None:
             from .. import bev_tiling
             return bev_tiling.tiled_forward(self, bev_query, key, value, *args, bev_h=bev_h,
@@ -324,8 +369,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
                                             level_start_index=level_start_index,
                                             prev_bev=prev_bev, shift=shift, **kwargs)
         bs = bev_query.size(1)
+        train_fast = bev_query.is_cuda and value.is_cuda and self._train_fast_path(
+            value.device, (bev_query, value, bev_pos, prev_bev))
         plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                               bev_query.dtype)
+                               bev_query.dtype, train_fast=train_fast)
         ref_2d = plan.ref_2d
         shift_ref_2d = ref_2d + shift[:, None, None, :]
 
@@ -343,8 +390,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
         else:
             hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
 
-        output = bev_query
-        intermediate = []
         # TSA's value is stack([history, bev_query]).  Inference, bs = 1: the grouped value projection reads the two tensors
         # where they lie and every layer's TSA gets its projected value and the history rows — nothing reads the stacked
         # tensor (82 MB written + read per base frame), a (2, Q, C) VIEW of the history stands in for it (value[:1] IS the
@@ -356,22 +401,37 @@ class BEVFormerEncoder(TransformerLayerSequence):
         if stack_free:
             prev_bev = history.expand(2, len_bev, history.shape[-1]) if tsa_vals is not None \
                 else torch.stack([history, bev_query], 1).reshape(bs * 2, len_bev, -1)
-        share = None
-        fast_train = False
-        if sca_vals is None and tsa_vals is None and value.is_cuda and self._train_fast_path(value.device):
-            self._flatten_projection_params()
-            from .. import train_ops
-            train_ops.begin_step(sum(p.numel() for p in self.parameters() if p.requires_grad))
-            # autograd fast path: the same two grouped GEMMs as autograd Functions (their backward sums the six input
-            # gradients in the GEMM epilogues); with bs = 1 the history BEV and the current queries stay two tensors
-            # (no gradient is formed for a detached history)
-            sca_vals, tsa_vals = self.hoisted_value_projections_autograd(
-                value, None if history is None else (history, bev_query) if bs == 1 else prev_bev)
-            fast_train = sca_vals is not None
-        if not fast_train and torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda and ops.modes().grad_thread:
-            # training: the camera features and [prev_bev, bev_query] feed every layer's value projection — their six
-            # input gradients are summed inside the GEMMs instead of by autograd's adds (ops.GradThread)
-            share = {"sca": ops.GradThread(), "tsa": ops.GradThread()}
+        import contextlib
+        with contextlib.ExitStack() as scope:
+            share = None
+            fast_train = False
+            if sca_vals is None and tsa_vals is None and train_fast:
+                self._flatten_projection_params()
+                from .. import train_ops
+                # the parameter-gradient arena of THIS call's backward pass: it travels in the modes snapshot every
+                # autograd Function of the step takes in its forward (no module-global state: two encoders, or two
+                # threads, never share accumulators)
+                scope.enter_context(ops.using(grad_arena=train_ops.begin_step(
+                    sum(p.numel() for p in self.parameters() if p.requires_grad))))
+                # autograd fast path: the same two grouped GEMMs as autograd Functions (their backward sums the six input
+                # gradients in the GEMM epilogues); with bs = 1 the history BEV and the current queries stay two tensors
+                # (no gradient is formed for a detached history)
+                sca_vals, tsa_vals = self.hoisted_value_projections_autograd(
+                    value, None if history is None else (history, bev_query) if bs == 1 else prev_bev)
+                fast_train = sca_vals is not None
+            if not fast_train and torch.is_grad_enabled() and len(self.layers) > 1 and value.is_cuda \
+                    and ops.modes().grad_thread:
+                # training: the camera features and [prev_bev, bev_query] feed every layer's value projection — their six
+                # input gradients are summed inside the GEMMs instead of by autograd's adds (ops.GradThread)
+                share = {"sca": ops.GradThread(), "tsa": ops.GradThread()}
+            return self._run_layers(bev_query, key, value, args, kwargs, plan, bev_pos, hybird_ref_2d, bev_h, bev_w,
+                                    spatial_shapes, level_start_index, prev_bev, history, share, fast_train, sca_vals,
+                                    tsa_vals)
+
+    def _run_layers(self, bev_query, key, value, args, kwargs, plan, bev_pos, hybird_ref_2d, bev_h, bev_w, spatial_shapes,
+                    level_start_index, prev_bev, history, share, fast_train, sca_vals, tsa_vals):
+        """The layer loop of ``forward`` (encoder.py:211-233)."""
+        intermediate = []
         for li, layer in enumerate(self.layers):
             hoisted = {}
             if share is not None:

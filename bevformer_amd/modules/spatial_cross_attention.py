@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..registry import ATTENTION, BaseModule, build_attention, constant_, xavier_uniform_
+from ..registry import ATTENTION, BaseModule, build_attention, constant_, force_fp32, xavier_uniform_
 from . import geometry
 from .temporal_self_attention import _direction_grid, _is_power_of_2
 
@@ -216,6 +216,7 @@ class SpatialCrossAttention(BaseModule):
     def init_weight(self):
         xavier_uniform_(self.output_proj)
 
+    @force_fp32(apply_to=("query", "key", "value", "query_pos", "reference_points_cam"))   # spatial_cross_attention.py:75
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag="encoder", frame_plan=None,
@@ -304,7 +305,8 @@ class SpatialCrossAttention(BaseModule):
             da_ok = projected_value.shape[-1] == 32 and da.num_levels <= 4 and da.num_points in (4, 8) \
                 and (projected_value.dtype == torch.float32
                      or (projected_value.dtype == torch.bfloat16 == ops.value_storage() and sink is not None)) \
-                and da.num_points % row_ref.shape[-2] == 0
+                and da.num_points % row_ref.shape[-2] == 0 \
+                and (not dyn or da.num_levels in (1, 2, 4))     # (device-side row count: the gather-form chain pass)
             q_tab = frame_plan.q_rows_all if (dyn and frame_plan.q_rows_all is not None) else frame_plan.q_rows
             if da_ok and (dyn or frame_plan.row_query32.numel() > 0):
                 proj_rows = query_proj

@@ -114,6 +114,19 @@ class PerceptionTransformer(BaseModule):
                          bev_pos=None, prev_bev=None, **kwargs):
         """mlvl_feats: list of (bs, Nc, C, h, w); bev_queries (Q, C); bev_pos (bs, C, bev_h,
         bev_w); prev_bev (bs, Q, C) / (Q, bs, C) / None -> bev_embed (bs, Q, C)."""
+        low = (torch.float16, torch.bfloat16)
+        if any(torch.is_tensor(t) and t.dtype in low for t in (*mlvl_feats, bev_queries, prev_bev, bev_pos)):
+            # ``fp16_enabled`` (the decorator above rounded the inputs to half, transformer.py:103): the prologue and
+            # encoder kernels are fp32 kernels — widen the rounded inputs once, run with autocast off
+            # (BEVFormerEncoder.forward says why that is at least the reference's arithmetic), return fp32
+            def up(t):
+                return t.float() if torch.is_tensor(t) and t.dtype in low else t
+            with torch.autocast(mlvl_feats[0].device.type, enabled=False):
+                return self._get_bev_features([up(f) for f in mlvl_feats], up(bev_queries), bev_h, bev_w, grid_length,
+                                              up(bev_pos), up(prev_bev), **kwargs)
+        return self._get_bev_features(mlvl_feats, bev_queries, bev_h, bev_w, grid_length, bev_pos, prev_bev, **kwargs)
+
+    def _get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length, bev_pos, prev_bev, **kwargs):
         bs = mlvl_feats[0].size(0)
         img_metas = kwargs["img_metas"]
         bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)

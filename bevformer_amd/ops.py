@@ -477,6 +477,10 @@ class _FusedSampleFunction(Function):
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st)
                 if rc != _lib.ERR_UNSUPPORTED:
                     _lib.check(rc, "fused backward: chain (gather)")
+            if rc == _lib.ERR_UNSUPPORTED and nrows is not None:
+                # the atomic chain pass below has no row count: it would walk all CAPACITY rows and add the uninitialised
+                # gl / ga rows beyond the count into gproj (the callers only send level counts the gather kernel takes)
+                raise RuntimeError("bevmsda: a device-side row count needs bevmsda_frontend_chain_gather_f32 (L in 1, 2, 4)")
             if rc == _lib.ERR_UNSUPPORTED:
                 # (with row_src the chain pass ADDS the rows of a query with atomics; without it every element is stored)
                 gproj = torch.zeros_like(proj) if row_src is not None else torch.empty_like(proj)

@@ -12,6 +12,7 @@ surface is used, so configs written for the reference work unchanged here.
 """
 import copy
 
+import torch
 import torch.nn as nn
 
 
@@ -80,12 +81,58 @@ except Exception:  # no mmcv in this environment (or only the oracle's stub)
     TRANSFORMER_LAYER = Registry("transformerLayer")
     TRANSFORMER_LAYER_SEQUENCE = Registry("transformer-layers sequence")
 
-    def _passthrough(*args, **kwargs):
-        def deco(fn):
-            return fn
-        return deco
+    def _cast_floating(x, src, dst):
+        """Tensors of dtype ``src`` inside ``x`` (nested lists / tuples / dicts) -> ``dst``; everything else as it is
+        (integer level tensors, numpy camera matrices, strings)."""
+        if isinstance(x, torch.Tensor):
+            return x.to(dst) if x.dtype == src else x
+        if isinstance(x, (str, bytes, nn.Module)):
+            return x
+        if isinstance(x, dict):
+            return type(x)({k: _cast_floating(v, src, dst) for k, v in x.items()})
+        if isinstance(x, (list, tuple)):
+            return type(x)(_cast_floating(v, src, dst) for v in x)
+        return x
 
-    force_fp32 = auto_fp16 = _passthrough
+    def _precision_wrapper(src, dst, autocast_on, out_attr):
+        """``mmcv.runner.auto_fp16`` / ``force_fp32`` restated [third party: mmcv-full 1.4.0, docs/install.md:27; not on
+        disk — mmcv/runner/fp16_utils.py as published]: a method decorator that is the identity while the module's
+        ``fp16_enabled`` is False (the default; ``wrap_fp16_model`` sets it); otherwise the arguments NAMED in
+        ``apply_to`` (default: the method's named positional parameters — keyword-only parameters are not in
+        ``getfullargspec().args`` and stay as they are) are cast ``src`` -> ``dst`` and the method runs with CUDA
+        autocast switched ``autocast_on`` (torch >= 1.6 branch of mmcv)."""
+        import functools
+        import inspect
+
+        def factory(apply_to=None, **opts):
+            out_cast = bool(opts.get(out_attr, False))
+
+            def deco(fn):
+                spec = inspect.getfullargspec(fn)
+
+                @functools.wraps(fn)
+                def wrapper(*args, **kwargs):
+                    if not isinstance(args[0], nn.Module):
+                        raise TypeError("@auto_fp16 / @force_fp32 can only decorate the methods of an nn.Module")
+                    if not getattr(args[0], "fp16_enabled", False):
+                        return fn(*args, **kwargs)
+                    names = spec.args if apply_to is None else apply_to
+                    arg_names = spec.args[:len(args)]
+                    new_args = [_cast_floating(a, src, dst) if i < len(arg_names) and arg_names[i] in names else a
+                                for i, a in enumerate(args)]
+                    new_kwargs = {k: (_cast_floating(v, src, dst) if k in names else v) for k, v in kwargs.items()}
+                    if torch.cuda.is_available():
+                        with torch.autocast("cuda", enabled=autocast_on):
+                            out = fn(*new_args, **new_kwargs)
+                    else:
+                        out = fn(*new_args, **new_kwargs)
+                    return _cast_floating(out, dst, src) if out_cast else out
+                return wrapper
+            return deco
+        return factory
+
+    auto_fp16 = _precision_wrapper(torch.float, torch.half, True, "out_fp32")
+    force_fp32 = _precision_wrapper(torch.half, torch.float, False, "out_fp16")
 
     class BaseModule(nn.Module):
         """``mmcv.runner.BaseModule`` surface used by this path."""
@@ -145,6 +192,16 @@ def build_transformer_layer_sequence(cfg, default_args=None):
 
 def build_transformer(cfg, default_args=None):
     return _build(cfg, TRANSFORMER, default_args)
+
+
+def wrap_fp16_model(model):
+    """``mmcv.runner.wrap_fp16_model`` on torch >= 1.6 [third party, restated]: the parameters stay fp32, every
+    submodule that has an ``fp16_enabled`` attribute gets it set — the ``@auto_fp16`` / ``@force_fp32`` methods then
+    cast their inputs (reference call site: tools/fp16/train.py:224-226)."""
+    for m in model.modules():
+        if hasattr(m, "fp16_enabled"):
+            m.fp16_enabled = True
+    return model
 
 
 def xavier_uniform_(module, bias=0.0):

@@ -177,18 +177,42 @@ def _wgrad_multi(problems, tag):
     _lib.check(rc, "linear_wgrad_multi")
 
 
-# Parameter-gradient accumulators of one backward pass: the weight-gradient kernels ADD into zeroed buffers.  ``begin_step``
-# (the encoder's forward, which knows the parameter count) arms an arena; the first ``_zeros`` of the backward pass
-# allocates and clears it in ONE fill and every later call carves its views out of it (20 launches of a few microseconds
-# each per base frame otherwise).  Whatever does not fit gets its own buffer.
-_ARENA = {"floats": 0, "buf": None, "used": 0}
+# Parameter-gradient accumulators of one backward pass: the weight-gradient kernels ADD into zeroed buffers.  The encoder's
+# forward (which knows the parameter count) creates a ``GradArena`` for its call and puts it into the modes of the calling
+# thread (``ops.using(grad_arena=...)``); every Function of the step snapshots those modes in its forward and re-activates
+# them in its backward, so the first ``_zeros`` of the backward pass allocates and clears the arena in ONE fill and every
+# later call carves its views out of it (20 launches of a few microseconds each per base frame otherwise).  Whatever does
+# not fit — or a backward pass over a graph recorded without an arena — gets its own buffer.  No module-global state.
+class GradArena:
+    __slots__ = ("floats", "buf", "used", "lock")
+
+    def __init__(self, floats):
+        import threading
+        self.floats = int(floats) + 64
+        self.buf = None
+        self.used = 0
+        self.lock = threading.Lock()
+
+    def carve(self, total, device):
+        """``total`` zeroed floats out of the arena, or None (does not fit / other device)."""
+        with self.lock:
+            if self.buf is None:
+                if self.used:                       # spent by an earlier backward pass over the same graph
+                    return None
+                self.buf = torch.zeros(self.floats, dtype=torch.float32, device=device)
+            a = self.buf
+            if a.device != torch.device(device) or self.used + total > a.numel():
+                return None
+            out = a[self.used:self.used + total]
+            self.used += total
+            if self.used + 1024 > a.numel():        # spent: drop the reference (the views keep the storage alive)
+                self.buf = None
+            return out
 
 
 def begin_step(param_floats):
-    """Arm the gradient arena for the backward pass of the forward that is being recorded."""
-    _ARENA["floats"] = int(param_floats) + 64
-    _ARENA["buf"] = None
-    _ARENA["used"] = 0
+    """The gradient arena for the backward pass of the forward that is about to be recorded."""
+    return GradArena(param_floats)
 
 
 def _zeros(device, *shapes):
@@ -196,17 +220,9 @@ def _zeros(device, *shapes):
     sizes = [int(torch.Size(s).numel()) for s in shapes]
     total = sum(sizes)
     buf = None
-    if _ARENA["floats"] and total % 4 == 0:
-        if _ARENA["buf"] is None:
-            _ARENA["buf"] = torch.zeros(_ARENA["floats"], dtype=torch.float32, device=device)
-            _ARENA["used"] = 0
-        a = _ARENA["buf"]
-        if a.device == torch.device(device) and _ARENA["used"] + total <= a.numel():
-            buf = a[_ARENA["used"]:_ARENA["used"] + total]
-            _ARENA["used"] += total
-            if _ARENA["used"] + 1024 > a.numel():          # spent: the next backward pass starts a fresh one
-                _ARENA["buf"] = None
-                _ARENA["floats"] = 0
+    arena = _m().grad_arena
+    if arena is not None and total % 4 == 0:
+        buf = arena.carve(total, device)
     if buf is None:
         buf = torch.zeros(total, dtype=torch.float32, device=device)
     out, o = [], 0
@@ -229,7 +245,12 @@ class _GroupedLinearFunction(Function):
                        segments=segments, out_dtype=out_dtype or torch.float32)
         ctx.sink = sink
         if y is None:
-            raise RuntimeError("bevmsda: grouped projection not covered")
+            # a shape / dtype the grouped kernel declines: the same numbers from the library GEMM (the backward below
+            # only reads x, wcat and the incoming gradients)
+            y = torch.nn.functional.linear(x.detach().to(wcat.dtype), wcat.detach(), bcat.detach())
+            y = y.view(-1, L, wcat.shape[0] // L).transpose(0, 1).contiguous()
+            if out_dtype is not None:
+                y = y.to(out_dtype)
         ctx.L, ctx.tag = L, tag
         ctx.x_shapes = [tuple(t.shape) for t in xs]
         ctx.save_for_backward(x, wcat)

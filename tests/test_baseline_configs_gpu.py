@@ -50,7 +50,10 @@ def modes():
     ops.set_value_storage(saved[1])
 
 
-@pytest.mark.parametrize("name", ["base", "small4"])
+# "small" = the reference-true bevformer_small (projects/configs/bevformer/bevformer_small.py:41-43,88: ONE feature level
+# (23, 40), 3 layers, 150 x 150 queries); "small4" = BASELINE configs[2]'s synthetic 4-level shape set of the same grid;
+# "tiny" = BASELINE configs[1] (bevformer_tiny.py:45-47,90: 50 x 50 queries, one level (15, 25), 3 layers)
+@pytest.mark.parametrize("name", ["base", "small4", "small", "tiny"])
 @pytest.mark.parametrize("temporal", [True, False])
 @pytest.mark.parametrize("gemm", ["split", "native"])
 def test_encoder_forward_on_the_benched_configs(name, temporal, gemm, modes):
@@ -60,7 +63,7 @@ def test_encoder_forward_on_the_benched_configs(name, temporal, gemm, modes):
     torch.testing.assert_close(got, want, **ENC_TOL)
 
 
-@pytest.mark.parametrize("name", ["base", "small4"])
+@pytest.mark.parametrize("name", ["base", "small4", "small"])
 @pytest.mark.parametrize("gemm,storage", [("split", torch.bfloat16), ("bf16", torch.bfloat16), ("bf16", torch.float32)])
 def test_encoder_forward_bf16_configurations(name, gemm, storage, modes):
     ops.set_gemm_mode(gemm)
@@ -187,7 +190,16 @@ def _gradient_case(name, storage, l2_tol, max_tol):
 # oracle is itself 2e-3 (d query) / 6e-3 (worst parameter) away from a float64 evaluation (profiles/r2/train_fwd_table.txt)
 # measured (r3c): small4 fp32 5.1e-3 / 4.6e-2, small4 bf16 3.1e-2 / 9.0e-2, base1 fp32 2.0e-3 / 2.9e-2, base1 bf16 2.0e-2 / 5.0e-2
 GRAD_TOL = {("small4", torch.float32): (1e-2, 0.1), ("small4", torch.bfloat16): (5e-2, 0.27),
-            ("base1", torch.float32): (6e-3, 0.09), ("base1", torch.bfloat16): (5e-2, 0.15)}
+            ("base1", torch.float32): (6e-3, 0.09), ("base1", torch.bfloat16): (5e-2, 0.15),
+            # reference-true small (one level): the same three layers over a 920-pixel map — small4's bounds
+            ("small", torch.float32): (1e-2, 0.1), ("small", torch.bfloat16): (5e-2, 0.27)}
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_small_reference_true_forward_backward_gradients(storage, modes):
+    """The reference's own bevformer_small shape set (1 level (23, 40), 3 layers, 150 x 150 queries;
+    projects/configs/bevformer/bevformer_small.py:41-43,88), forward + backward."""
+    _gradient_case("small", storage, *GRAD_TOL[("small", storage)])
 
 
 @pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
@@ -201,3 +213,68 @@ def test_base_geometry_one_layer_forward_backward_gradients(storage, modes):
     """One encoder layer at the base geometry (200x200 queries, 45,960 image-ordered SCA rows, 128-row sort
     workgroups, 16x16 TSA tiles): what ``fwd_bwd_base`` of the bench runs six times."""
     _gradient_case("base1", storage, *GRAD_TOL[("base1", storage)])
+
+
+def _rank_cells(w, world, rank, layout):
+    from bevformer_amd import bev_tiling
+    if layout == "rows":
+        h0, h1 = bev_tiling.row_blocks(w["bev_h"], world)[rank]
+        return torch.arange(h0 * w["bev_w"], h1 * w["bev_w"], device=DEV)
+    q0, q1 = bev_tiling.query_blocks(w["bev_h"] * w["bev_w"], world)[rank]
+    return bev_tiling.sector_order(w["bev_h"], w["bev_w"], S.PC_RANGE, DEV)[1][q0:q1]
+
+
+@pytest.mark.parametrize("layout", ["rows", "sectors"])
+def test_base_size_tiled_ranks_equal_the_untiled_rows(layout):
+    """SURVEY.md §8e at the size BASELINE configs[3] names: rank r of an 8-GPU BEV-tiled job (simulated in this process:
+    the rank's device-side tile plan at 200 x 200 / 4 levels, camera-segment skipping of the replicated value projection,
+    the sector gather / scatter, every kernel at tile size) must produce the untiled base frame's rows — against the
+    untiled GPU frame (tight: the same kernels over other row partitions) and against the CPU oracle (``ENC_TOL``)."""
+    from bevformer_amd import bev_tiling
+    name, world = "base", 8
+    w = S.WORKLOADS[name]
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=True, device=DEV)
+    want_cpu = _oracle_frame(name, True)
+    with torch.no_grad():
+        want = enc(q, f, f, **kw)
+        for rank in (0, 3, 7):
+            bev_tiling.enable_bev_tiling(enc, simulate=(rank, world), layout=layout)
+            got = enc(q, f, f, **kw)
+            bev_tiling.disable_bev_tiling(enc)
+            mine = _rank_cells(w, world, rank, layout)
+            assert mine.numel() == w["bev_h"] * w["bev_w"] // world
+            torch.testing.assert_close(got[:, mine], want[:, mine], rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(got[:, mine].cpu(), want_cpu[:, mine.cpu()], **ENC_TOL)
+
+
+@pytest.mark.parametrize("name", ["micro4", "small4"])
+def test_fp16_enabled_encoder_with_half_inputs_on_the_gpu(name):
+    """The reference's fp16 mode (``@auto_fp16()`` at encoder.py:151, ``wrap_fp16_model`` in tools/fp16/train.py:224-226,
+    config bevformer_fp16/bevformer_tiny_fp16.py:270): ``fp16_enabled`` set on every module that has it, half
+    ``bev_query`` / camera features (cast by the decorator) and half ``bev_pos`` / ``prev_bev`` (as ``get_bev_features``
+    hands them over).  The product widens the ROUNDED inputs and computes in fp32, so the result is held to the fp32
+    tolerance against the oracle on the rounded inputs (the reference's own fp16 arithmetic is coarser than that)."""
+    from bevformer_amd import registry
+    enc, sd = build_pair(name, device=DEV)
+    registry.wrap_fp16_model(enc)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=True)
+
+    def r(t):
+        return t.half().float()
+    kwr = dict(kw, bev_pos=r(kw["bev_pos"]), prev_bev=r(kw["prev_bev"]))
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want = O.encoder_forward(sd, r(q), r(f), pc_range=S.PC_RANGE, **kwr)
+        kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        kwd["bev_pos"], kwd["prev_bev"] = kwd["bev_pos"].half(), kwd["prev_bev"].half()
+        got = enc(q.to(DEV), f.to(DEV), f.to(DEV), **kwd)                 # fp32 in: the decorator rounds to half
+        also = enc(q.to(DEV).half(), f.to(DEV).half(), f.to(DEV).half(), **kwd)
+    assert got.dtype == torch.float32 and torch.equal(got, also)
+    torch.testing.assert_close(got.cpu(), want, **ENC_TOL)
+    # ... and under autograd (the widening is differentiable; the per-op / chain path decides on the fp32 tensors)
+    qd = q.to(DEV).requires_grad_(True)
+    out = enc(qd, f.to(DEV), f.to(DEV), **kwd)
+    out.sum().backward()
+    assert out.dtype == torch.float32 and torch.isfinite(qd.grad).all()
+    torch.testing.assert_close(out.detach().cpu(), want, **ENC_TOL)

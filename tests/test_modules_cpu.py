@@ -126,3 +126,71 @@ def test_image_row_order_is_a_pure_permutation(name):
     assert pa == pb
     assert torch.equal(a.row_batch, b.row_batch)
     assert not torch.equal(a.row_query, b.row_query)
+
+
+def test_fp16_enabled_encoder_takes_half_inputs():
+    """The reference's fp16 wrapper (``@auto_fp16()`` at encoder.py:151, ``fp16_enabled`` set by ``wrap_fp16_model``,
+    tools/fp16/train.py:224-226): half ``bev_query`` / ``key`` / ``value`` (cast by the decorator) and half ``bev_pos`` /
+    ``prev_bev`` (handed over half by ``get_bev_features``, transformer.py:103) must run; the product widens the ROUNDED
+    inputs once and computes in fp32, so the result is the fp32 encoder's on the rounded inputs — bit for bit — and
+    comes back fp32 like the reference's last LayerNorm under autocast."""
+    from bevformer_amd import registry
+    enc, sd = build_pair("micro4")
+    registry.wrap_fp16_model(enc)
+    assert enc.fp16_enabled and enc.layers[0].attentions[1].fp16_enabled
+    q, f, kw = S.make_inputs("micro4", seed=0, temporal=True)
+    kwh = dict(kw, bev_pos=kw["bev_pos"].half(), prev_bev=kw["prev_bev"].half())
+    with torch.no_grad(), oracle_ops():
+        got = enc(q, f, f, **kwh)                       # fp32 positional inputs: the decorator rounds them to half
+        also = enc(q.half(), f.half(), f.half(), **kwh)
+    assert got.dtype == torch.float32 and torch.equal(got, also)
+    r = lambda t: t.half().float()                      # noqa: E731
+    kwr = dict(kw, bev_pos=r(kw["bev_pos"]), prev_bev=r(kw["prev_bev"]))
+    want = O.encoder_forward(sd, r(q), r(f), pc_range=S.PC_RANGE, **kwr)
+    torch.testing.assert_close(got, want, **TOL)
+    for m in enc.modules():
+        if hasattr(m, "fp16_enabled"):
+            m.fp16_enabled = False
+    with torch.no_grad(), oracle_ops():
+        plain = enc(r(q), r(f), r(f), **kwr)
+    assert torch.equal(plain, got)
+
+
+def test_precision_decorators_follow_mmcv():
+    """``auto_fp16`` / ``force_fp32`` of the stand-alone registry: identity while ``fp16_enabled`` is False; named
+    positional parameters (not keyword-only ones) cast when it is True; integer tensors untouched."""
+    from bevformer_amd import registry
+    if registry.HAVE_MMCV:
+        pytest.skip("a real mmcv provides the decorators")
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fp16_enabled = False
+
+        @registry.auto_fp16()
+        def f(self, a, b, *args, c=None, **kw):
+            return a.dtype, b.dtype, c.dtype
+
+        @registry.force_fp32(apply_to=("a", "d"))
+        def g(self, a, b=None, d=None):
+            return a.dtype, b.dtype, [t.dtype for t in d]
+
+    m, x, i = M(), torch.randn(2), torch.arange(2)
+    assert m.f(x, i, c=x) == (torch.float32, torch.int64, torch.float32)
+    m.fp16_enabled = True
+    assert m.f(x, i, c=x) == (torch.float16, torch.int64, torch.float32)
+    assert m.g(x.half(), b=x.half(), d=[x.half(), i]) == (torch.float32, torch.float16, [torch.float32, torch.int64])
+
+
+def test_training_fast_path_needs_fp32_parameters_and_inputs():
+    """a ``.half()`` / ``.double()`` model or input must not enter the chain-kernel training path."""
+    enc, _ = build_pair("micro")
+    q, f, kw = S.make_inputs("micro", seed=0, temporal=True)
+    with torch.enable_grad():
+        # (CPU: the device test fails first; the dtype tests are what this checks, so ask without a device)
+        assert enc._train_fast_path(None, (q, f))
+        assert not enc._train_fast_path(None, (q.double(), f))
+        assert not enc._train_fast_path(None, (q, f.half()))
+        enc.double()
+        assert not enc._train_fast_path(None, (q, f))

@@ -64,7 +64,9 @@ def _encoder_worker(rank, world, port, name, temporal, layout, ret):
 
 
 @pytest.mark.parametrize("name,temporal,layout,world", [("micro4", True, "rows", 2), ("micro4", False, "sectors", 2),
-                                                        ("tiny", True, "sectors", 3)])
+                                                        ("tiny", True, "sectors", 3),
+                                                        # BASELINE configs[3]'s size: 200 x 200 queries, 4 levels, 6 layers
+                                                        ("base", True, "rows", 2)])
 def test_tiled_encoder_on_ranks_sharing_one_gpu(name, temporal, layout, world):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_encoder_worker, args=(world, _free_port(), name, temporal, layout, ret), nprocs=world, join=True)
