@@ -527,6 +527,58 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
     return res
 
 
+def run_ddp_eager(args, dev, fence, gemm, steps=3, windows=3):
+    """The training step the reference's parallel strategy permits (``MMDistributedDataParallel`` = torch DDP, one process
+    per GPU: bevformer/apis/mmdet_train.py:75-79): the base encoder wrapped in ``DistributedDataParallel`` on a world-1 RCCL
+    group, forward + backward launched EAGERLY (the reducer's hooks and bucket all-reduces are host-driven: the step cannot
+    be one captured HIP graph), beside the same eager step without the wrapper.  The fast path's flattened parameters,
+    merged-gradient views and gradient arena run under the reducer here (gradient equality with two ranks:
+    tests/test_ddp_gpu.py)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    own = not dist.is_initialized()
+    backend = "nccl"
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        except Exception:       # noqa: BLE001
+            dist.init_process_group("gloo", rank=0, world_size=1)
+            backend = "gloo"
+    try:
+        cfg = Config(args, dev, "base", gemm, "fp32", True, args.first_frame, 1, False)
+        cfg.modes()
+
+        def timed(step):
+            for _ in range(2):
+                cfg.next_rig()
+                step()
+            fence()
+            ts = timed_windows(cfg, step, fence, steps, windows, None)
+            return statistics.median(ts) / steps * 1e3
+        plain = timed(cfg.encoder_step)
+        ddp = DDP(cfg.enc, device_ids=[dev.index], broadcast_buffers=False)
+
+        def ddp_step():
+            ddp.zero_grad(set_to_none=True)
+            cfg.qg.grad = cfg.fg.grad = None
+            out = ddp(cfg.qg, cfg.fg, cfg.fg, **cfg.kw)
+            out.backward(cfg.g_out)
+            return out.detach()
+        wrapped = timed(ddp_step)
+        ok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in cfg.enc.parameters())
+        return dict(workload="base", gemm=gemm, value_storage="fp32", direction="fwd+bwd",
+                    launch_mode="eager (DistributedDataParallel: reducer hooks + bucket all-reduce, world 1, %s)" % backend,
+                    ms_per_step=wrapped, ms_per_step_eager_without_ddp=plain, steps=steps, windows=windows,
+                    queries_per_s=cfg.Q / (wrapped * 1e-3), all_parameter_gradients_finite=ok,
+                    note="what the reference's training wrapper costs around the fast path: the same step as fwd_bwd_base, "
+                         "launched eagerly under DDP (no graph); gradient equality across 2 ranks: tests/test_ddp_gpu.py")
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def oracle_frame(workload, first_frame):
     """Oracle output of the synthetic frame of ``workload`` on the host (what the variants of other workloads are
     checked against)."""
@@ -865,6 +917,18 @@ def main():
                 v["fwd_bwd_base_train_mode"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3, train_mode=True)
                 v["fwd_bwd_small4"] = run_variant(args, dev, fence, "small4", gemm, "fp32", True, 5, 3, want4, ENC_TOL)
                 v["fwd_bwd_small4_bf16"] = run_variant(args, dev, fence, "small4", "bf16", "bf16", True, 5, 3, want4, 5e-2)
+                # the reference-true bevformer_small shape set (ONE level (23, 40), 3 layers, 150 x 150 queries:
+                # projects/configs/bevformer/bevformer_small.py:41-43,88) and BASELINE configs[1] (bevformer_tiny forward)
+                want_s = oracle_frame("small", args.first_frame)
+                v["fwd_bwd_small"] = run_variant(args, dev, fence, "small", gemm, "fp32", True, 5, 3, want_s, ENC_TOL)
+                v["fwd_bwd_small_bf16"] = run_variant(args, dev, fence, "small", "bf16", "bf16", True, 5, 3, want_s, 5e-2)
+                v["fwd_small"] = run_variant(args, dev, fence, "small", gemm, "fp32", False, 10, 3, want_s, ENC_TOL)
+                v["fwd_tiny"] = run_variant(args, dev, fence, "tiny", gemm, "fp32", False, 20, 3,
+                                            oracle_frame("tiny", args.first_frame), ENC_TOL)
+                try:
+                    v["fwd_bwd_base_ddp_eager"] = run_ddp_eager(args, dev, fence, gemm)
+                except Exception as e:      # noqa: BLE001 — never lose the line to the extra variant
+                    v["fwd_bwd_base_ddp_eager"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
                 v["queue4_bf16"] = run_variant(args, dev, fence, "base", "bf16", "bf16", False, 3, 3, tol=5e-2, queue=4)
                 # the same 4-frame queue in the headline arithmetic (fp32 storage, split-bf16 GEMMs) against the same
                 # oracle run, at twice the single-frame tolerance (four chained frames)
