@@ -302,6 +302,9 @@ int bevmsda_linear_panel_pack_weight_t_f32(const float *wt, int64_t ldwt, int N,
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+// phase skew of the plain row-panel projections, in units of 1024 clocks (0 = none; tools/gemm_epilogue_ab.py)
+static constexpr int kPanelSkewDefault = 0;
+
 static int panel_launch(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                         const float *scale, const uint16_t *wpanel, const float *bias,
                         const bevmsda_linear_desc *d, const bevmsda_layernorm_desc *ln, float *y, void *stream,
@@ -360,9 +363,43 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
-  // desc->reserved[3]: weight fragments in flight for shape 1 (0 = default, 2 or 6 k16 steps ahead)
-  if (d->reserved[3] != 0 && d->reserved[3] != 2 && d->reserved[3] != 6) return BEVMSDA_ERR_BAD_OPTION;
+  // desc->reserved[3]: weight fragments in flight for shape 1 (0 = default, 2 or 6 k16 steps ahead); 32 + bits: epilogue /
+  // prefetch variants of the plain projection (no prepass, no LayerNorm; tools/gemm_ab.py): bit 0 the finished tile's
+  // pieces stored one per k16 step of the next tile (DRIP), bit 1 weight fragments 4 steps ahead, bit 2 the round-4
+  // epilogue (bias loaded per piece: 16 waited store round trips per tile — the A/B record of its removal)
+  // 64 + n (n = 0 .. 31): phase skew of the column sweep, n x 1024 clocks (linear_panel.h; plain projections only);
+  // 0 (the default) = kPanelSkewDefault for the plain projections
+  int ev = d->reserved[3] >= 32 && d->reserved[3] < 64 ? d->reserved[3] - 32 : -1;
+  const bool plain = !idx && !a.a0 && !a.a1 && !ln;
+  a.skew = plain && d->reserved[3] == 0 ? kPanelSkewDefault : 0;
+  if (d->reserved[3] >= 64) {
+    if (d->reserved[3] >= 96 || !plain) return BEVMSDA_ERR_BAD_OPTION;
+    a.skew = d->reserved[3] - 64;
+  } else if (ev >= 0) {
+    if (ev > 4 || idx || a.a0 || a.a1 || ln) return BEVMSDA_ERR_BAD_OPTION;
+  } else if (d->reserved[3] != 0 && d->reserved[3] != 2 && d->reserved[3] != 6) {
+    return BEVMSDA_ERR_BAD_OPTION;
+  }
   const bool deep = d->reserved[3] == 6;       // (measured in one process: 616 vs 612 us, 272 vs 274 us — no default)
+  if (ev > 0) {
+#define BEVMSDA_PANEL_EV(NP_)                                                                                                  \
+    do {                                                                                                                       \
+      if (shape == 1) {                                                                                                        \
+        if (ev == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, false, 0, 0, 0, true, 2>), grid, dim3(256), 0, st, a);  \
+        else if (ev == 2) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, false, 0, 0, 0, false, 4>), grid, dim3(256), 0, st, a); \
+        else if (ev == 3) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, false, 0, 0, 0, true, 4>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 2, 2, 4, false, 0, 0, 0, false, 2, true>), grid, dim3(256), 0, st, a);    \
+      } else {                                                                                                                 \
+        if (ev == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, false, 0, 0, 0, true, 2>), grid, dim3(512), 0, st, a);  \
+        else if (ev == 2) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, false, 0, 0, 0, false, 4>), grid, dim3(512), 0, st, a); \
+        else if (ev == 3) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, false, 0, 0, 0, true, 4>), grid, dim3(512), 0, st, a);  \
+        else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<NP_, 4, 1, 8, false, 0, 0, 0, false, 2, true>), grid, dim3(512), 0, st, a);    \
+      }                                                                                                                        \
+    } while (0)
+    if (d->precision == 0) BEVMSDA_PANEL_EV(3); else BEVMSDA_PANEL_EV(1);
+#undef BEVMSDA_PANEL_EV
+    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  }
 #define BEVMSDA_PANEL2(NP_, LN_, PRE_)                                                                                   \
   do {                                                                                                                   \
     if (shape == 1 && deep && (PRE_) == 0)                                                                               \

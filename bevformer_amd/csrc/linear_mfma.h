@@ -443,7 +443,54 @@ linear_splitbf16_kernel(const LinArgs a) {
     // a 16-byte aligned y / bias: checked once, uniform)
     const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (a.group_cols & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0);
-    if (vec) {
+    if (vec && a.bias && !a.mask && !a.accum && !a.out_bf16) {
+      // The plain projection with a bias (optional ReLU, fp32 out; without a bias the loop below has no load either): NO load and no branch between the stores.  A load placed
+      // between two stores is followed by s_waitcnt vmcnt(0) — bias may alias y as far as the compiler knows, so it keeps
+      // program order — and that wait also covers the store in front of it: through round 4 every 16-byte piece sat
+      // through the previous piece's store round trip, 16 per workgroup (found in the ISA, round 5).  The tile's bias
+      // fragments are loaded up front; bias / ReLU are selects, not branches (a uniform branch between stores makes the
+      // wait-count pass merge paths and fall back to vmcnt(0) as well).
+      // ... and the arithmetic of ALL pieces comes first, in place, in straight-line code: the one wait for the bias
+      // fragments then sits in front of the first store instead of inside every piece's bounds-check block.
+      const bool rl = a.relu != 0;
+      constexpr bool hb = true;
+      const float *bsrc = a.bias;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (j) __builtin_amdgcn_sched_barrier(0);   // (one MFMA tile column's 4 fragments at a time: the 128-register variants)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * (BN / WNW) + j * 32 + 4 * (lane >> 5) + 8 * g;
+          const float4 b4 = *reinterpret_cast<const float4 *>(bsrc + ((hb && n < a.N) ? n : 0));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+            v0 = hb ? v0 + b4.x : v0; v1 = hb ? v1 + b4.y : v1; v2 = hb ? v2 + b4.z : v2; v3 = hb ? v3 + b4.w : v3;
+            acc[i][j][4 * g] = (rl && v0 < 0.f) ? 0.f : v0;          // NaN stays NaN, as torch.relu
+            acc[i][j][4 * g + 1] = (rl && v1 < 0.f) ? 0.f : v1;
+            acc[i][j][4 * g + 2] = (rl && v2 < 0.f) ? 0.f : v2;
+            acc[i][j][4 * g + 3] = (rl && v3 < 0.f) ? 0.f : v3;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + (lane & 31);
+        float *yrow = yg + (m < a.M ? m : 0) * a.ldy - ncol0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nb = n0 + wn * (BN / WNW) + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb + 8 * g;
+            const float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            if (LIN_DIAG(a, 1) && v.x != 1.2345e30f) continue;
+            if (m < a.M && n < a.N) *reinterpret_cast<float4 *>(yrow + n) = v;      // N % 4 == 0: n < N covers n .. n+3
+          }
+        }
+      }
+    } else if (vec) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);

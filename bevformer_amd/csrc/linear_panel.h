@@ -70,6 +70,12 @@ struct PanelArgs {
   // TSA's value [history BEV ; current queries] read from its two tensors instead of from a stacked copy
   const float *xb;
   long m_split;
+  // phase skew of the column sweep, in units of 1024 clocks (0 = none): the second wavefront of every SIMD (8-wavefront
+  // shape) / every second workgroup of a CU (4-wavefront shape, by the observed block placement) sleeps this long before
+  // its first column tile, so that one half of a CU's wavefronts stores while the other half issues MFMAs — left alone all
+  // wavefronts of a workgroup (and all workgroups of the launch) finish their tiles together and the chip alternates
+  // between an MFMA phase and a store phase
+  int skew;
 #ifdef BEVMSDA_PANEL_DIAG
   int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
                                     //   3 activation fragments of step 0 only, 4 no panel fetch / split
@@ -127,7 +133,14 @@ __device__ __forceinline__ void panel_store(uint16_t *p, const uint2 &v) {
 // DRIP: a finished column tile's accumulators move to a second register set and are stored ONE 16-byte piece per k16 step
 // of the next tile instead of as a burst of 16 stores at the tile's end.
 // WD: weight fragments in flight, in k16 steps ahead of the MFMAs that consume them (ring of WD + 1 stages).
-template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false, int WD = 2>
+// OLDEPI (A/B record only): the epilogue as it stood through round 4 — every 16-byte piece loaded its bias right before its
+// store, and since the bias pointer may alias y the loads could not move above the stores: load, s_waitcnt vmcnt(0), store,
+// 16 times per column tile, each wait covering the PREVIOUS piece's store (and the prefetched weight fragments): a
+// wavefront sat through 16 store round trips per tile, which is why the MFMA and the store phases added up instead of
+// overlapping (round 5: found in the ISA).  Now the tile's bias fragments are loaded at the top of the tile's k loop and the
+// epilogue is 16 stores back to back with no wait.
+template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false, int WD = 2,
+          bool OLDEPI = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_panel_kernel(const PanelArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
@@ -199,7 +212,23 @@ linear_panel_kernel(const PanelArgs a) {
   // MFMA D tile (W fragment as the A operand): lane holds output row m = lane & 31 and, in registers 4g .. 4g + 3,
   // columns nb + 8g .. + 3 with nb = 4 (lane >> 5)
   constexpr int NPIECE = MT * NT * 4;
-  auto store_piece = [&](const lin_f32x16 (&t)[MT][NT], int tct, int pc) {
+  // bias fragments of one column tile: the lane's 4 consecutive columns of register group g of MFMA tile j.  Loaded at the
+  // top of the tile's k loop (``bias_load``), long before the epilogue reads them: no load, and so no wait, between the
+  // epilogue's stores (see OLDEPI above)
+  float4 bfr[OLDEPI ? 1 : NT][OLDEPI ? 1 : 4];
+  auto bias_load = [&](int tct) {
+    if constexpr (!OLDEPI) {
+      if (a.bias == nullptr) return;           // (uniform)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = tct * TW + j * 32 + 4 * (lane >> 5) + 8 * g;
+          bfr[j][g] = *reinterpret_cast<const float4 *>(a.bias + (n < a.N ? n : 0));     // (columns >= N are never stored)
+        }
+    }
+  };
+  auto store_piece = [&](const lin_f32x16 (&t)[MT][NT], int tct, int pc, bool add_bias = true) {
     const int i = pc / (NT * 4), j = (pc / 4) % NT, g = pc % 4;
     const int n0 = tct * TW;
     const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
@@ -208,7 +237,11 @@ linear_panel_kernel(const PanelArgs a) {
     if (m >= a.M || n >= a.N) return;          // N % 4 == 0: n < N covers n .. n + 3
     float4 v = make_float4(t[i][j][4 * g], t[i][j][4 * g + 1], t[i][j][4 * g + 2], t[i][j][4 * g + 3]);
     if (PANEL_DIAG(a, 1) && v.x != 1.2345e30f) return;
-    if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+    if constexpr (OLDEPI) {
+      if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
+    } else {
+      if (a.bias && add_bias) v = lin_add4(v, bfr[j][g]);
+    }
     if (a.relu) {                              // NaN stays NaN, as torch.relu
       v.x = v.x < 0.f ? 0.f : v.x;
       v.y = v.y < 0.f ? 0.f : v.y;
@@ -228,6 +261,7 @@ linear_panel_kernel(const PanelArgs a) {
   lin_f32x16 prev[DRIP ? MT : 1][DRIP ? NT : 1];
   int prev_ct = 0;
   bool have_prev = false;
+  static_assert(!(DRIP && OLDEPI), "the dripping epilogue applies the bias when a tile retires");
 
   for (int half = 0; half < nhalf; ++half) {
     // ---------------------------------------------------------------- panel pass: fetch, split, one barrier
@@ -335,6 +369,9 @@ linear_panel_kernel(const PanelArgs a) {
 
     // ---------------------------------------------------------------- column sweep: no synchronisation
     const bool last_half = half == nhalf - 1;
+    if (a.skew > 0 && half == 0 && (NW == 8 ? wave >= 4 : ((blockIdx.x >> 8) & 1) != 0)) {
+      for (int z = 0; z < a.skew; ++z) __builtin_amdgcn_s_sleep(16);       // 16 x 64 clocks
+    }
     for (; ct < nct; ct += NW) {
       const int ct_next = ct + NW;
       lin_bf16x8 af[2][MT][NPL];               // activation fragments: step s in set s & 1
@@ -348,6 +385,7 @@ linear_panel_kernel(const PanelArgs a) {
             af[set][i][pl] = *reinterpret_cast<const lin_bf16x8 *>(lds + base + i * (4 * 4 * 2048) + pl * 1024);
       };
       aload(0, 0);
+      if (!LN && last_half) bias_load(ct);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         // weight fragments WD steps ahead (ring stage (s + WD) % RS); past the tile's end: the next tile's first WD
@@ -359,7 +397,7 @@ linear_panel_kernel(const PanelArgs a) {
         if (s + 1 < 16) aload((s + 1) & 1, s + 1);
         if constexpr (DRIP && !LN) {
           static_assert(!DRIP || 16 % NPIECE == 0, "pieces per tile must divide the 16 steps");
-          if ((s % (16 / NPIECE)) == 0 && have_prev) store_piece(prev, prev_ct, s / (16 / NPIECE));
+          if ((s % (16 / NPIECE)) == 0 && have_prev) store_piece(prev, prev_ct, s / (16 / NPIECE), false);
         }
         __builtin_amdgcn_sched_barrier(0);     // requests first: left alone, hipcc sinks them to the end of the step
 #pragma unroll
@@ -403,9 +441,14 @@ linear_panel_kernel(const PanelArgs a) {
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              prev[i][j] = acc[i][j];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+              for (int r = 0; r < 16; ++r) {
+                // (the tile retires with its bias: the dripped pieces of the next tile's loop are plain stores)
+                const float bb = a.bias ? (r & 3) == 0 ? bfr[j][r >> 2].x : (r & 3) == 1 ? bfr[j][r >> 2].y
+                                                   : (r & 3) == 2 ? bfr[j][r >> 2].z : bfr[j][r >> 2].w : 0.f;
+                prev[i][j][r] = a.bias ? acc[i][j][r] + bb : acc[i][j][r];
+                acc[i][j][r] = 0.f;
+              }
             }
           prev_ct = ct;
           have_prev = true;
@@ -425,7 +468,7 @@ linear_panel_kernel(const PanelArgs a) {
   if constexpr (DRIP && !LN) {
     if (have_prev) {
 #pragma unroll
-      for (int pc = 0; pc < NPIECE; ++pc) store_piece(prev, prev_ct, pc);
+      for (int pc = 0; pc < NPIECE; ++pc) store_piece(prev, prev_ct, pc, false);
     }
   }
 
@@ -489,12 +532,26 @@ linear_panel_kernel(const PanelArgs a) {
       for (int i = 0; i < MT; ++i) stat[wave * BM + i * 32 + lane] = rstd[i];
     }
     __syncthreads();
+    // gamma / beta fragments of this wavefront's columns: loaded once, in front of the first store (a load between two
+    // stores waits for the store in front of it: OLDEPI note above)
+    float4 gaf[NT][4], bef[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+        gaf[j][g] = *reinterpret_cast<const float4 *>(a.gamma + n);
+        bef[j][g] = *reinterpret_cast<const float4 *>(a.beta + n);
+      }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
       rstd[i] = rsqrtf(t * (1.0f / static_cast<float>(NW * TW)) + a.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
       const long m = m0 + i * 32 + (lane & 31);
       if (m >= a.M) continue;
       float *yrow = a.y + m * a.ldy;
@@ -504,8 +561,8 @@ linear_panel_kernel(const PanelArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nb + 8 * g;
-          const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + n);
-          const float4 be = *reinterpret_cast<const float4 *>(a.beta + n);
+          const float4 ga = gaf[j][g];
+          const float4 be = bef[j][g];
           float4 v;
           v.x = (acc[i][j][4 * g] - mean[i]) * rstd[i] * ga.x + be.x;
           v.y = (acc[i][j][4 * g + 1] - mean[i]) * rstd[i] * ga.y + be.y;

@@ -227,6 +227,21 @@ linear_pipe_kernel(const LinArgs a) {
   const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
   float *const yg = a.y + static_cast<long>(grp) * a.M * a.ldy;
   const int ncol0 = grp * a.group_cols;
+  // bias first, for the whole tile, in place and in straight-line code: a bias load between two stores draws s_waitcnt
+  // vmcnt(0) (the pointer may alias y), which also waits for the store in front of it (linear_mfma.h, round 5)
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + j * 32 + 4 * (lane >> 5) + 8 * q;
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + (n < a.N ? n : 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][j][4 * q] += b4.x; acc[i][j][4 * q + 1] += b4.y; acc[i][j][4 * q + 2] += b4.z; acc[i][j][4 * q + 3] += b4.w;
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const long m = m0 + wm * 64 + i * 32 + (lane & 31);
@@ -239,7 +254,6 @@ linear_pipe_kernel(const LinArgs a) {
         const int n = nb + 8 * q;
         if (m < a.M && n < a.N) {
           float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-          if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
           if (a.relu) {
             v.x = v.x < 0.f ? 0.f : v.x;
             v.y = v.y < 0.f ? 0.f : v.y;

@@ -837,9 +837,18 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
     if blob is None:
         return False
     # panel shape: 128-row panels (half the weight traffic per MFMA, one workgroup per CU) pay from ~128 k rows on
-    desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(_m().gemm_kernel) \
+    kern = _m().gemm_kernel or ""
+    knob = 0                                                                  # A/B knobs (modes.GEMM_KERNELS)
+    for base in ("panel64", "panel128"):
+        if kern.startswith(base + "e") and kern[len(base) + 1:].isdigit():
+            kern, knob = base, 32 + int(kern[len(base) + 1:])                 # epilogue variant
+        elif kern.startswith(base + "s") and kern[len(base) + 1:].isdigit():
+            kern, knob = base, 64 + int(kern[len(base) + 1:])                 # phase skew of the column sweep
+    if knob and (a0 is not None or x1 is not None or idx is not None or ln is not None):
+        knob = 0
+    desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(kern) \
         or (2 if desc.M >= _sel("panel_128_rows") and ln is None else 1)
-    desc.reserved[3] = {"panel64w2": 2, "panel64w6": 6}.get(_m().gemm_kernel, 0)      # benchmark knob: weight prefetch depth
+    desc.reserved[3] = knob or {"panel64w2": 2, "panel64w6": 6}.get(kern, 0)  # (w2 / w6: weight prefetch depth)
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()

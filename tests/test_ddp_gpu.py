@@ -30,6 +30,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
+LR = 1e-3       # small steps: after a large one the bilinear taps of many sampling points change cells and rounding-level
+                # differences (the order of the backward kernels' atomics) no longer stay rounding-level in the gradients
+
+
+def _rel_errors(got, want):
+    """Per-tensor L2 error relative to the tensor's own norm, floored at 1 % of the largest gradient norm of the model (a
+    parameter whose gradient is almost zero has no meaningful relative error) -> (worst, its name)."""
+    floor = 1e-2 * max(v.norm().item() for v in want.values())
+    worst, name = 0.0, None
+    for k, w in want.items():
+        e = ((got[k] - w).norm() / max(w.norm().item(), floor)).item()
+        if e > worst:
+            worst, name = e, k
+    return worst, name
+
+
 def _grads(enc, q, f, kw, gout):
     """Single-process forward + backward -> (output, {name: grad})."""
     enc.zero_grad(set_to_none=True)
@@ -61,12 +77,12 @@ def _worker(rank, world, port, name, bucket_view, ret):
         ins = []
         for r in range(world):                      # every rank builds every rank's inputs: the references need them
             q, f, kw = S.make_inputs(name, seed=10 + r, temporal=True, device=dev)
-            gout = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + r))
+            gout = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + r)) * 1e-2
             ins.append((q, f, kw, gout))
         ddp = DDP(enc, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=bucket_view)
         report = {}
-        opt = torch.optim.SGD(ddp.parameters(), lr=0.05)
-        opt_ref = torch.optim.SGD(ref.parameters(), lr=0.05)
+        opt = torch.optim.SGD(ddp.parameters(), lr=LR)
+        opt_ref = torch.optim.SGD(ref.parameters(), lr=LR)
         for it in range(2):
             want = None
             for r in range(world):
@@ -79,12 +95,11 @@ def _worker(rank, world, port, name, bucket_view, ret):
             out = ddp(q, f, f, **kw)
             out.backward(gout)
             after = train_ops.stats()
-            worst = 0.0
+            got = {}
             for k, p in ddp.module.named_parameters():
                 assert p.grad is not None, k
-                err = ((p.grad - want[k]).norm() / (want[k].norm() + 1e-30)).item()
-                worst = max(worst, err)
-            report[f"iter{it}_worst_rel_l2"] = worst
+                got[k] = p.grad
+            report[f"iter{it}_worst_rel_l2"], report[f"iter{it}_worst_tensor"] = _rel_errors(got, want)
             report[f"iter{it}_fast_path_seams"] = after["seam_s"] - before["seam_s"]
             # the same update on both sides (the reference model steps with the MEAN gradient it just computed)
             for k, p in ref.named_parameters():
@@ -94,7 +109,7 @@ def _worker(rank, world, port, name, bucket_view, ret):
             gmax = max(v.abs().max().item() for v in want.values())
             diff = max((a - b).abs().max().item()
                        for (_, a), (_, b) in zip(ddp.module.named_parameters(), ref.named_parameters()))
-            report[f"iter{it}_weights_equal_after_step"] = diff <= 0.05 * 1e-3 * gmax + 1e-6
+            report[f"iter{it}_weights_equal_after_step"] = diff <= LR * 1e-2 * gmax + 1e-7
         # state_dict round trip: the flattened (re-seated) parameters save and load like any others
         sd = {k: v.detach().cpu().clone() for k, v in ddp.module.state_dict().items()}
         fresh, _ = build_pair(name, device=dev)
@@ -111,8 +126,7 @@ def _worker(rank, world, port, name, bucket_view, ret):
             p.requires_grad_(True)
         _, g_old = _grads(ddp.module, *ins[rank])
         _, g_new = _grads(fresh, *ins[rank])
-        report["stale_cache_worst_rel_l2"] = max(
-            ((g_old[k] - g_new[k]).norm() / (g_new[k].norm() + 1e-30)).item() for k in g_new)
+        report["stale_cache_worst_rel_l2"], report["stale_cache_worst_tensor"] = _rel_errors(g_old, g_new)
         report["state_dict_keys"] = sorted(sd) == sorted(fresh.state_dict())
         ret[rank] = report
     finally:
