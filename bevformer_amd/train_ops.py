@@ -220,7 +220,7 @@ def _zeros(device, *shapes):
     sizes = [int(torch.Size(s).numel()) for s in shapes]
     total = sum(sizes)
     buf = None
-    arena = _m().grad_arena
+    arena = _m().grad_arena if _m().use_grad_arena else None
     if arena is not None and total % 4 == 0:
         buf = arena.carve(total, device)
     if buf is None:
