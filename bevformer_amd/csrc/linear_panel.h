@@ -158,7 +158,13 @@ linear_panel_kernel(const PanelArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA bases and buffer soffsets are scalar operands
-  const long m0 = static_cast<long>(blockIdx.x) * BM;
+  // The grid may be smaller than the number of row panels: a workgroup walks panels blockIdx.x, + gridDim.x, ...  The
+  // default launch has one workgroup per panel; a persistent grid (what is resident at once) was measured in round 5 and
+  // changed nothing (bevmsda_linear.hip, reserved[3] = 96).
+  const long nblk = (a.M + BM - 1) / BM;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  if (blk != static_cast<long>(blockIdx.x)) __syncthreads();     // every wavefront is done with the previous panel's planes
+  const long m0 = blk * BM;
   if (a.seg_start != nullptr) {                // unused row segments: nobody will read their outputs
     long halo = 0;
     for (int l = 0; l < a.num_levels; ++l) halo = a.level_shapes[2 * l + 1] > halo ? a.level_shapes[2 * l + 1] : halo;
@@ -168,7 +174,7 @@ linear_panel_kernel(const PanelArgs a) {
     const int s_lo = static_cast<int>(first / a.seg_len), s_hi = static_cast<int>(last / a.seg_len);
     int used = 0;
     for (int sg = s_lo; sg <= s_hi; ++sg) used |= a.seg_start[sg + 1] - a.seg_start[sg];
-    if (used == 0) return;                     // (uniform over the workgroup)
+    if (used == 0) continue;                   // (uniform over the workgroup)
   }
   const int K = a.K0 + a.K1;
   const int nhalf = K / kPanelK;
@@ -228,39 +234,133 @@ linear_panel_kernel(const PanelArgs a) {
         }
     }
   };
-  auto store_piece = [&](const lin_f32x16 (&t)[MT][NT], int tct, int pc, bool add_bias = true) {
-    const int i = pc / (NT * 4), j = (pc / 4) % NT, g = pc % 4;
+  // A piece's address: the output group (n0 / group_cols) is ONE raw buffer per column tile whose records end with the
+  // workgroup's last row — rows >= M are dropped by the bounds check, so no per-lane predicate and no 64-bit address
+  // arithmetic per piece: voffset = this lane's (row, 4 (lane >> 5)) element of row tile i (computed once per kernel),
+  // soffset = the tile's first column, the piece's own column offset (32 j + 8 g) an immediate.  Through round 4 the
+  // epilogue of a column tile was ~700 executed instructions (64-bit multiplies and a chain of uniform branches per
+  // piece) against the tile's 192 MFMAs — and a wavefront issues no MFMA while it walks them (found in the ISA, round 5).
+  const unsigned ldy_u = static_cast<unsigned>(a.ldy);
+  unsigned e_row[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) e_row[i] = (static_cast<unsigned>(i * 32 + (lane & 31)) * ldy_u + 4u * (lane >> 5));
+  const long rows_here = a.M - m0 < BM ? a.M - m0 : BM;
+  auto tile_rsrc = [&](int tct, int &soff_elems) {
     const int n0 = tct * TW;
     const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
-    const long m = m0 + i * 32 + (lane & 31);
-    const int n = n0 + j * 32 + 4 * (lane >> 5) + 8 * g;
-    if (m >= a.M || n >= a.N) return;          // N % 4 == 0: n < N covers n .. n + 3
-    float4 v = make_float4(t[i][j][4 * g], t[i][j][4 * g + 1], t[i][j][4 * g + 2], t[i][j][4 * g + 3]);
-    if (PANEL_DIAG(a, 1) && v.x != 1.2345e30f) return;
+    soff_elems = n0 - grp * a.group_cols;
+    const long first = (static_cast<long>(grp) * a.M + m0) * a.ldy;                 // element of (row m0, column 0) of the group
+    const int es = a.out_bf16 ? 2 : 4;
+    unsigned char *base = reinterpret_cast<unsigned char *>(a.y) + first * es;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>(rows_here * a.ldy * es), 0x00020000);
+  };
+  auto store_piece = [&](const lin_f32x16 (&t)[MT][NT], int tct, int pc, bool add_bias = true) {
+    const int i = pc / (NT * 4), j = (pc / 4) % NT, g = pc % 4;
     if constexpr (OLDEPI) {
+      const int n0 = tct * TW;
+      const int grp = a.group_cols > 0 ? n0 / a.group_cols : 0;
+      const long m = m0 + i * 32 + (lane & 31);
+      const int n = n0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+      if (m >= a.M || n >= a.N) return;          // N % 4 == 0: n < N covers n .. n + 3
+      float4 v = make_float4(t[i][j][4 * g], t[i][j][4 * g + 1], t[i][j][4 * g + 2], t[i][j][4 * g + 3]);
+      if (PANEL_DIAG(a, 1) && v.x != 1.2345e30f) return;
       if (a.bias) v = lin_add4(v, *reinterpret_cast<const float4 *>(a.bias + n));
-    } else {
-      if (a.bias && add_bias) v = lin_add4(v, bfr[j][g]);
+      if (a.relu) {                              // NaN stays NaN, as torch.relu
+        v.x = v.x < 0.f ? 0.f : v.x;
+        v.y = v.y < 0.f ? 0.f : v.y;
+        v.z = v.z < 0.f ? 0.f : v.z;
+        v.w = v.w < 0.f ? 0.f : v.w;
+      }
+      const long off = (static_cast<long>(grp) * a.M + m) * a.ldy + (n - grp * a.group_cols);
+      if (a.out_bf16) {
+        uint2 pk;
+        pk.x = lin_pack2(v.x, v.y);
+        pk.y = lin_pack2(v.z, v.w);
+        panel_store<STAUX>(reinterpret_cast<uint16_t *>(a.y) + off, pk);
+      } else {
+        panel_store<STAUX>(a.y + off, v);
+      }
     }
-    if (a.relu) {                              // NaN stays NaN, as torch.relu
-      v.x = v.x < 0.f ? 0.f : v.x;
-      v.y = v.y < 0.f ? 0.f : v.y;
-      v.z = v.z < 0.f ? 0.f : v.z;
-      v.w = v.w < 0.f ? 0.f : v.w;
-    }
-    const long off = (static_cast<long>(grp) * a.M + m) * a.ldy + (n - grp * a.group_cols);
+  };
+  // one piece of a tile whose bias / ReLU are already applied (the dripping epilogue), fp32 or bf16 by the uniform flag
+  auto store_one = [&](const lin_f32x16 (&t)[MT][NT], __amdgpu_buffer_rsrc_t yr, int soff_e, int pc) {
+    const int i = pc / (NT * 4), j = (pc / 4) % NT, g = pc % 4;
     if (a.out_bf16) {
-      uint2 pk;
-      pk.x = lin_pack2(v.x, v.y);
-      pk.y = lin_pack2(v.z, v.w);
-      panel_store<STAUX>(reinterpret_cast<uint16_t *>(a.y) + off, pk);
+      const panel_u32x2 d = {lin_pack2(t[i][j][4 * g], t[i][j][4 * g + 1]), lin_pack2(t[i][j][4 * g + 2], t[i][j][4 * g + 3])};
+      __builtin_amdgcn_raw_buffer_store_b64(d, yr, static_cast<int>(e_row[i] * 2u) + (j * 32 + 8 * g) * 2, soff_e * 2, STAUX);
     } else {
-      panel_store<STAUX>(a.y + off, v);
+      const panel_u32x4 d = {__float_as_uint(t[i][j][4 * g]), __float_as_uint(t[i][j][4 * g + 1]),
+                             __float_as_uint(t[i][j][4 * g + 2]), __float_as_uint(t[i][j][4 * g + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(d, yr, static_cast<int>(e_row[i] * 4u) + (j * 32 + 8 * g) * 4, soff_e * 4, STAUX);
+    }
+  };
+  // the lean epilogue of one column tile (all NPIECE pieces): uniform decisions once per tile, straight-line pieces
+  auto store_tile = [&](lin_f32x16 (&t)[MT][NT], int tct, bool add_bias) {
+    int soff_e;
+    __amdgpu_buffer_rsrc_t yr = tile_rsrc(tct, soff_e);
+    const bool jok[2] = {tct * TW < a.N, tct * TW + 32 < a.N};     // (N % 32 == 0 is not required: a half tile may hang over)
+    if (a.bias && add_bias) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            t[i][j][4 * g] += bfr[j][g].x; t[i][j][4 * g + 1] += bfr[j][g].y;
+            t[i][j][4 * g + 2] += bfr[j][g].z; t[i][j][4 * g + 3] += bfr[j][g].w;
+          }
+    }
+    if (a.relu) {                                // NaN stays NaN, as torch.relu
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[i][j][r] = t[i][j][r] < 0.f ? 0.f : t[i][j][r];
+    }
+    if (PANEL_DIAG(a, 1)) return;
+    if (tct * TW + TW > a.N) {
+      // the last column tile of an N that is not a multiple of the tile width: per-lane column checks (N % 4 == 0, so a
+      // piece is in or out as a whole); rare (N = 100 in the tests), kept off the straight-line path below
+#pragma unroll
+      for (int pc = 0; pc < NPIECE; ++pc) {
+        const int j = (pc / 4) % NT, g = pc % 4;
+        if (tct * TW + j * 32 + 4 * (lane >> 5) + 8 * g < a.N) store_one(t, yr, soff_e, pc);
+      }
+      return;
+    }
+    if (a.out_bf16) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (!jok[j]) continue;                 // (uniform)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const panel_u32x2 d = {lin_pack2(t[i][j][4 * g], t[i][j][4 * g + 1]), lin_pack2(t[i][j][4 * g + 2], t[i][j][4 * g + 3])};
+            __builtin_amdgcn_raw_buffer_store_b64(d, yr, static_cast<int>(e_row[i] * 2u) + (j * 32 + 8 * g) * 2, soff_e * 2, STAUX);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (!jok[j]) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const panel_u32x4 d = {__float_as_uint(t[i][j][4 * g]), __float_as_uint(t[i][j][4 * g + 1]),
+                                   __float_as_uint(t[i][j][4 * g + 2]), __float_as_uint(t[i][j][4 * g + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(d, yr, static_cast<int>(e_row[i] * 4u) + (j * 32 + 8 * g) * 4, soff_e * 4, STAUX);
+          }
+        }
     }
   };
   lin_f32x16 prev[DRIP ? MT : 1][DRIP ? NT : 1];
   int prev_ct = 0;
   bool have_prev = false;
+  int prev_soff = 0;
+  __amdgpu_buffer_rsrc_t prev_rs = tile_rsrc(0, prev_soff);
   static_assert(!(DRIP && OLDEPI), "the dripping epilogue applies the bias when a tile retires");
 
   for (int half = 0; half < nhalf; ++half) {
@@ -397,7 +497,7 @@ linear_panel_kernel(const PanelArgs a) {
         if (s + 1 < 16) aload((s + 1) & 1, s + 1);
         if constexpr (DRIP && !LN) {
           static_assert(!DRIP || 16 % NPIECE == 0, "pieces per tile must divide the 16 steps");
-          if ((s % (16 / NPIECE)) == 0 && have_prev) store_piece(prev, prev_ct, s / (16 / NPIECE), false);
+          if ((s % (16 / NPIECE)) == 0 && have_prev) store_one(prev, prev_rs, prev_soff, s / (16 / NPIECE));
         }
         __builtin_amdgcn_sched_barrier(0);     // requests first: left alone, hipcc sinks them to the end of the step
 #pragma unroll
@@ -446,15 +546,21 @@ linear_panel_kernel(const PanelArgs a) {
                 // (the tile retires with its bias: the dripped pieces of the next tile's loop are plain stores)
                 const float bb = a.bias ? (r & 3) == 0 ? bfr[j][r >> 2].x : (r & 3) == 1 ? bfr[j][r >> 2].y
                                                    : (r & 3) == 2 ? bfr[j][r >> 2].z : bfr[j][r >> 2].w : 0.f;
-                prev[i][j][r] = a.bias ? acc[i][j][r] + bb : acc[i][j][r];
+                const float pv = a.bias ? acc[i][j][r] + bb : acc[i][j][r];
+                prev[i][j][r] = (a.relu && pv < 0.f) ? 0.f : pv;
                 acc[i][j][r] = 0.f;
               }
             }
           prev_ct = ct;
           have_prev = true;
+          prev_rs = tile_rsrc(ct, prev_soff);
         } else {
+          if constexpr (OLDEPI) {
 #pragma unroll
-          for (int pc = 0; pc < NPIECE; ++pc) store_piece(acc, ct, pc);
+            for (int pc = 0; pc < NPIECE; ++pc) store_piece(acc, ct, pc);
+          } else {
+            store_tile(acc, ct, true);
+          }
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -468,7 +574,7 @@ linear_panel_kernel(const PanelArgs a) {
   if constexpr (DRIP && !LN) {
     if (have_prev) {
 #pragma unroll
-      for (int pc = 0; pc < NPIECE; ++pc) store_piece(prev, prev_ct, pc, false);
+      for (int pc = 0; pc < NPIECE; ++pc) store_one(prev, prev_rs, prev_soff, pc);
     }
   }
 
@@ -573,6 +679,7 @@ linear_panel_kernel(const PanelArgs a) {
       }
     }
   }
+  }     // panels of this workgroup
 }
 
 // Weight image of the row-panel kernel: for every 32-row tile T of w (N, K), k16 step sg and plane (hi, lo) the

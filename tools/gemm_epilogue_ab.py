@@ -18,8 +18,8 @@ from kbench import timeit  # noqa: E402
 
 DEV = "cuda:0"
 # "" = the default build; e4 = the round-4 epilogue (bias loaded per piece); e2 = weight fragments 4 steps ahead;
-# sN = phase skew of the column sweep, N x 1024 clocks (linear_panel.h)
-VARIANTS = ("", "e4", "e2", "s1", "s2", "s3", "s4", "s6", "s8", "s12")
+# sN = phase skew of the column sweep, N x 1024 clocks (linear_panel.h); p = persistent grid
+VARIANTS = ("", "p", "e4", "e2")
 
 
 def med(v):
