@@ -819,8 +819,15 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                traffic = dict(bytes_per_launch=tj.get(args.workload, {}).get("sca_fwd"), source=tj.get("_source"),
-                               note="rocprofv3 PMC passes of an EARLIER run of this bench (not this run)")
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from profile_traffic import kernel_sources_sha
+                sha = kernel_sources_sha()
+                fresh = tj.get("_kernel_sources_sha") == sha
+                traffic = dict(bytes_per_launch=tj.get(args.workload, {}).get("sca_fwd") if fresh else None,
+                               source=tj.get("_source"), kernel_sources_sha=sha, profile_kernel_sources_sha=tj.get("_kernel_sources_sha"),
+                               note="rocprofv3 PMC passes of an EARLIER run of this bench (not this run)" if fresh else
+                                    "STALE: the sampling kernels' sources changed since the profile was collected "
+                                    "(python tools/profile_traffic.py --config base_fwd on the GPU box, then --install)")
             except Exception:       # noqa: BLE001
                 traffic = None
         with torch.set_grad_enabled(args.backward):

@@ -93,6 +93,16 @@ def collect(config, out):
         print("".join(open(os.path.join(out, "kernel_stats.csv")).readlines()[:16]))
 
 
+def kernel_sources_sha():
+    """Hash of the sampling kernels' sources: ``bench.py`` quotes ``profiles/traffic.json`` only while it matches the tree
+    (a changed kernel makes ``roofline.traffic`` null instead of silently stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("msda_d32.h", "msda_kernels.h"):
+        h.update(open(os.path.join(ROOT, "bevformer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def install(tag):
     base = os.path.join(ROOT, "gpurun_out", "profile_traffic")
     dst = os.path.join(ROOT, "profiles", tag)
@@ -114,6 +124,8 @@ def install(tag):
                     entry[k] = t["kernels"][k]["hbm_bytes_per_launch"]
             tj["_source"] = f"profiles/{tag}/{tag}_traffic_{config}_pmc.json (python tools/profile_traffic.py --config {config})"
             tj["_comment"] = t["method"]
+            # (the profile was collected on the snapshot gpurun sent: the tree at install time, if nothing was edited between)
+            tj["_kernel_sources_sha"] = kernel_sources_sha()
         print("installed", config, "->", dst)
     json.dump(tj, open(tj_path, "w"), indent=1)
 
