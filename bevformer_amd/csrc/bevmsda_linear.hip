@@ -385,10 +385,10 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   int ev = d->reserved[3] >= 32 && d->reserved[3] < 64 ? d->reserved[3] - 32 : -1;
   const bool plain = !idx && !a.a0 && !a.a1 && !ln;
   a.skew = plain && d->reserved[3] == 0 ? kPanelSkewDefault : 0;
-  if (d->reserved[3] == 96) {
-    // persistent walk over the row panels
+  if (d->reserved[3] >= 96 && d->reserved[3] <= 98) {
+    // 96: persistent walk over the row panels; 97 / 98: the one-wavefront-per-SIMD dripping form (below)
   } else if (d->reserved[3] >= 64) {
-    if (d->reserved[3] > 96 || !plain) return BEVMSDA_ERR_BAD_OPTION;
+    if (d->reserved[3] > 98 || !plain) return BEVMSDA_ERR_BAD_OPTION;
     a.skew = d->reserved[3] - 64;
   } else if (ev >= 0) {
     if (ev > 4 || idx || a.a0 || a.a1 || ln) return BEVMSDA_ERR_BAD_OPTION;
@@ -396,6 +396,20 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
     return BEVMSDA_ERR_BAD_OPTION;
   }
   const bool deep = d->reserved[3] == 6;       // (measured in one process: 616 vs 612 us, 272 vs 274 us — no default)
+  if (d->reserved[3] == 97 || d->reserved[3] == 98) {
+    // 97 / 98: the dripping-store form on 128-row panels, 4 wavefronts of 128 x 64 tiles, one wavefront per SIMD (weight
+    // fragments 2 / 4 steps ahead): plain projections only
+    if (!plain) return BEVMSDA_ERR_BAD_OPTION;
+    const dim3 g128(static_cast<unsigned>((d->M + 127) / 128));
+    if (d->precision == 0) {
+      if (d->reserved[3] == 97) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 4, 2, 4, false, 0, 0, 0, true, 2>), g128, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 4, 2, 4, false, 0, 0, 0, true, 4>), g128, dim3(256), 0, st, a);
+    } else {
+      if (d->reserved[3] == 97) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 4, 2, 4, false, 0, 0, 0, true, 2>), g128, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 4, 2, 4, false, 0, 0, 0, true, 4>), g128, dim3(256), 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  }
   if (ev > 0) {
 #define BEVMSDA_PANEL_EV(NP_)                                                                                                  \
     do {                                                                                                                       \

@@ -79,12 +79,25 @@ struct PanelArgs {
 #ifdef BEVMSDA_PANEL_DIAG
   int diag;                         // tools/gemm_diag only: bit 0 no MFMA, 1 no stores, 2 weight fragments of step 0 only,
                                     //   3 activation fragments of step 0 only, 4 no panel fetch / split
+  unsigned long long *prof;         // tools/gemm_diag only: per-phase shader clocks summed over the wavefronts (PANEL_CLK)
 #endif
 };
 #ifdef BEVMSDA_PANEL_DIAG
 #define PANEL_DIAG(a, bit) (((a).diag >> (bit)) & 1)
+// phase clocks: [0] panel DMA issue (+ address set-up), [1] wait for the DMA, [2] split + barrier, [3] k loops of the column
+// tiles, [4] tile epilogues (bias, stores issued), [5] everything else, [7] wavefronts counted
+// (sampled: wavefront 0 and wavefront NW - 1 of every 64th workgroup — stamps on every wavefront serialise on the counters)
+#define PANEL_CLK(k)                                                                        \
+  do {                                                                                      \
+    if (stamping_) {                                                                        \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
+      if (lane == 0) atomicAdd(a.prof + (k), now_ - t_prev_);                               \
+      t_prev_ = now_;                                                                       \
+    }                                                                                       \
+  } while (0)
 #else
 #define PANEL_DIAG(a, bit) 0
+#define PANEL_CLK(k) do { } while (0)
 #endif
 
 constexpr int kPanelK = 256;        // k per panel pass (8 lines of 128 bytes per row)
@@ -141,7 +154,9 @@ __device__ __forceinline__ void panel_store(uint16_t *p, const uint2 &v) {
 // epilogue is 16 stores back to back with no wait.
 template <int NPROD, int MT, int NT, int NW, bool LN, int PRE, int STAUX = 0, int LDAUX = 0, bool DRIP = false, int WD = 2,
           bool OLDEPI = false>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// (MT x NT = 4 x 2 with 4 wavefronts: ONE wavefront per SIMD with the whole register file — the dripping-store form, whose
+// second accumulator set does not fit 256 registers)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((MT * NT == 8 && NW == 4) ? 1 : 2, (MT * NT == 8 && NW == 4) ? 1 : 2)))
 linear_panel_kernel(const PanelArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
   static_assert((MT == 2 || MT == 4) && (NT == 1 || NT == 2), "wavefront tile");
@@ -158,6 +173,11 @@ linear_panel_kernel(const PanelArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA bases and buffer soffsets are scalar operands
+#ifdef BEVMSDA_PANEL_DIAG
+  const bool stamping_ = a.prof != nullptr && (blockIdx.x & 63) == 0 && (wave == 0 || wave == NW - 1);
+  unsigned long long t_prev_ = stamping_ ? __builtin_amdgcn_s_memtime() : 0ULL;
+  if (stamping_ && lane == 0) atomicAdd(a.prof + 7, 1ULL);
+#endif
   // The grid may be smaller than the number of row panels: a workgroup walks panels blockIdx.x, + gridDim.x, ...  The
   // default launch has one workgroup per panel; a persistent grid (what is resident at once) was measured in round 5 and
   // changed nothing (bevmsda_linear.hip, reserved[3] = 96).
@@ -444,7 +464,9 @@ linear_panel_kernel(const PanelArgs a) {
 #pragma unroll
       for (int k = 0; k < WD; ++k) wload(k, ct, half * 16 + k);
     }
+    PANEL_CLK(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my own DMA slots have landed (no other lane reads them yet)
+    PANEL_CLK(1);
 #pragma unroll
     for (int u = 0; u < QPW; ++u)
 #pragma unroll
@@ -466,6 +488,7 @@ linear_panel_kernel(const PanelArgs a) {
         if (LO) *reinterpret_cast<uint4 *>(slot + 1024) = lo;
       }
     __syncthreads();                           // planes complete
+    PANEL_CLK(2);
 
     // ---------------------------------------------------------------- column sweep: no synchronisation
     const bool last_half = half == nhalf - 1;
@@ -496,8 +519,15 @@ linear_panel_kernel(const PanelArgs a) {
         }
         if (s + 1 < 16) aload((s + 1) & 1, s + 1);
         if constexpr (DRIP && !LN) {
-          static_assert(!DRIP || 16 % NPIECE == 0, "pieces per tile must divide the 16 steps");
-          if ((s % (16 / NPIECE)) == 0 && have_prev) store_one(prev, prev_rs, prev_soff, s / (16 / NPIECE));
+          static_assert(!DRIP || 16 % NPIECE == 0 || NPIECE % 16 == 0, "pieces per tile and the 16 steps must divide one another");
+          if constexpr (NPIECE >= 16) {
+            if (have_prev) {
+#pragma unroll
+              for (int u = 0; u < NPIECE / 16; ++u) store_one(prev, prev_rs, prev_soff, s * (NPIECE / 16) + u);
+            }
+          } else {
+            if ((s % (16 / NPIECE)) == 0 && have_prev) store_one(prev, prev_rs, prev_soff, s / (16 / NPIECE));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);     // requests first: left alone, hipcc sinks them to the end of the step
 #pragma unroll
@@ -518,6 +548,7 @@ linear_panel_kernel(const PanelArgs a) {
           }
         __builtin_amdgcn_sched_barrier(0);     // ... and hoists every fragment read of the tile to its top
       }
+      PANEL_CLK(3);
       // the next tile's steps 0 .. WD - 1 sit in ring stages (16 + k) % RS: rotate them to stages 0 .. WD - 1
       if (ct_next < nct && (16 % RS) != 0) {
         lin_bf16x8 tmp[WD][NT][NPL];
@@ -561,6 +592,7 @@ linear_panel_kernel(const PanelArgs a) {
           } else {
             store_tile(acc, ct, true);
           }
+          PANEL_CLK(4);
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -74,3 +74,22 @@ extern "C" int diag_panel(const float *x, long ldx, const uint16_t *wp, unsigned
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// per-phase clocks of the production instantiation (PANEL_CLK): prof = 8 zeroed 64-bit counters on the device
+extern "C" int diag_panel_phases(const float *x, long ldx, const uint16_t *wp, unsigned wp_bytes, const float *bias, float *y, long ldy,
+                                 long M, int N, int K, int group_cols, int nprod, int shape, unsigned long long *prof, void *stream) {
+  bevmsda::PanelArgs a{};
+  a.x0 = x; a.ldx0 = ldx; a.wp = wp; a.wp_bytes = wp_bytes; a.bias = bias; a.y = y; a.ldy = ldy; a.M = M; a.N = N;
+  a.K0 = K; a.K1 = 0; a.group_cols = group_cols; a.diag = 0; a.prof = prof;
+  const int bm = shape == 2 ? 128 : 64;
+  const dim3 grid(static_cast<unsigned>((M + bm - 1) / bm));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nprod == 3) {
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 2, 2, 4, false, 0>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<3, 4, 1, 8, false, 0>), grid, dim3(512), 0, st, a);
+  } else {
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 2, 2, 4, false, 0>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::linear_panel_kernel<1, 4, 1, 8, false, 0>), grid, dim3(512), 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

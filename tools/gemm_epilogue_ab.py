@@ -19,7 +19,7 @@ from kbench import timeit  # noqa: E402
 DEV = "cuda:0"
 # "" = the default build; e4 = the round-4 epilogue (bias loaded per piece); e2 = weight fragments 4 steps ahead;
 # sN = phase skew of the column sweep, N x 1024 clocks (linear_panel.h); p = persistent grid
-VARIANTS = ("", "p", "e4", "e2")
+VARIANTS = ("", "e4")
 
 
 def med(v):
@@ -42,7 +42,7 @@ def main():
             w = torch.randn(N, 256, device=DEV, generator=g) * 0.05
             b = torch.randn(N, device=DEV, generator=g)
             for store in (torch.float32, torch.bfloat16):
-                kernels = [f"panel{bm}{sfx}" for bm in (128, 64) for sfx in VARIANTS]
+                kernels = [f"panel{bm}{sfx}" for bm in (128, 64) for sfx in VARIANTS] + ["panel128d2", "panel128d4"]
                 ts = {k: [] for k in kernels}
                 outs = {}
                 with torch.no_grad():
