@@ -362,20 +362,8 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // one workgroup per row panel; reserved[3] = 96: a persistent grid instead — what is resident at once, the kernel walking
-  // the remaining panels itself (measured, no gain: 488.7 vs 480.6 us and 240.6 vs 240.4 us on the hoisted projections,
-  // profiles/r5/r5g_persistent_panels_ab.txt — workgroup turnover is not where the time goes)
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n_cu = v;
-    else
-      n_cu = 256;
-  }
-  const bool persist = d->reserved[3] == 96;
-  const long long resident = static_cast<long long>(n_cu) * (shape == 1 ? 2 : 1);
-  const dim3 grid(static_cast<unsigned>(persist && nb > resident ? resident : nb));
+  // one workgroup per row panel (a persistent grid was measured in round 5 and changed nothing: linear_panel.h)
+  const dim3 grid(static_cast<unsigned>(nb));
   // desc->reserved[3]: weight fragments in flight for shape 1 (0 = default, 2 or 6 k16 steps ahead); 32 + bits: epilogue /
   // prefetch variants of the plain projection (no prepass, no LayerNorm; tools/gemm_ab.py): bit 0 the finished tile's
   // pieces stored one per k16 step of the next tile (DRIP), bit 1 weight fragments 4 steps ahead, bit 2 the round-4
@@ -385,8 +373,8 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
   int ev = d->reserved[3] >= 32 && d->reserved[3] < 64 ? d->reserved[3] - 32 : -1;
   const bool plain = !idx && !a.a0 && !a.a1 && !ln;
   a.skew = plain && d->reserved[3] == 0 ? kPanelSkewDefault : 0;
-  if (d->reserved[3] >= 96 && d->reserved[3] <= 98) {
-    // 96: persistent walk over the row panels; 97 / 98: the one-wavefront-per-SIMD dripping form (below)
+  if (d->reserved[3] == 97 || d->reserved[3] == 98) {
+    // 97 / 98: the one-wavefront-per-SIMD dripping form (below)
   } else if (d->reserved[3] >= 64) {
     if (d->reserved[3] > 98 || !plain) return BEVMSDA_ERR_BAD_OPTION;
     a.skew = d->reserved[3] - 64;

@@ -138,6 +138,16 @@ __device__ __forceinline__ void panel_store(uint16_t *p, const uint2 &v) {
   }
 }
 
+// The two LDS-DMA requests of line pair P of a row block: global source = src + P * 256 (+ 128) bytes as the instruction's
+// immediate offset — which the hardware adds to the LDS address too, hence the "- offset" on the destination.
+template <int P, int AUX>
+__device__ __forceinline__ void panel_dma_pair(const float *src, unsigned char *dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                   (__attribute__((address_space(3))) void *)(dst - P * 256), 16, P * 256, AUX);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                   (__attribute__((address_space(3))) void *)(dst + 1024 - (P * 256 + 128)), 16, P * 256 + 128, AUX);
+}
+
 // MT x NT MFMA tiles of 32 x 32 per wavefront tile, NW wavefronts, BM = 32 MT rows per workgroup.
 // PRE: what the split pass adds to the fetched rows: 0 nothing, 1 an addend matrix (a0 / a1, each optional), 2 gather mode.
 // STAUX / LDAUX: cache policy bits of the epilogue stores / the panel fetch (0 = default, 2 = nt, 16 = sc1, 18 = both).  The
@@ -178,13 +188,10 @@ linear_panel_kernel(const PanelArgs a) {
   unsigned long long t_prev_ = stamping_ ? __builtin_amdgcn_s_memtime() : 0ULL;
   if (stamping_ && lane == 0) atomicAdd(a.prof + 7, 1ULL);
 #endif
-  // The grid may be smaller than the number of row panels: a workgroup walks panels blockIdx.x, + gridDim.x, ...  The
-  // default launch has one workgroup per panel; a persistent grid (what is resident at once) was measured in round 5 and
-  // changed nothing (bevmsda_linear.hip, reserved[3] = 96).
-  const long nblk = (a.M + BM - 1) / BM;
-  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-  if (blk != static_cast<long>(blockIdx.x)) __syncthreads();     // every wavefront is done with the previous panel's planes
-  const long m0 = blk * BM;
+  // (one workgroup per row panel.  A persistent grid — what is resident at once, a workgroup walking panels blockIdx.x,
+  // + gridDim.x, ... — was measured in round 5 and changed nothing: 488.7 vs 480.6 us and 240.6 vs 240.4 us on the hoisted
+  // projections, profiles/r5/r5g_persistent_panels_ab.txt; its loop also cost the prologue its registers.)
+  const long m0 = static_cast<long>(blockIdx.x) * BM;
   if (a.seg_start != nullptr) {                // unused row segments: nobody will read their outputs
     long halo = 0;
     for (int l = 0; l < a.num_levels; ++l) halo = a.level_shapes[2 * l + 1] > halo ? a.level_shapes[2 * l + 1] : halo;
@@ -194,7 +201,7 @@ linear_panel_kernel(const PanelArgs a) {
     const int s_lo = static_cast<int>(first / a.seg_len), s_hi = static_cast<int>(last / a.seg_len);
     int used = 0;
     for (int sg = s_lo; sg <= s_hi; ++sg) used |= a.seg_start[sg + 1] - a.seg_start[sg];
-    if (used == 0) continue;                   // (uniform over the workgroup)
+    if (used == 0) return;                     // (uniform over the workgroup)
   }
   const int K = a.K0 + a.K1;
   const int nhalf = K / kPanelK;
@@ -210,9 +217,19 @@ linear_panel_kernel(const PanelArgs a) {
   const int f_rl = ((f_r & 3) << 1) | ((f_r >> 3) & 1);
   const int f_x = f_r & 7;
   unsigned f_addr[4];                          // per (s & 3): base of tile 0, pair p = 0, hi plane
+  // (f_addr / e_row are FILLED behind the panel pass, from a laundered lane id: computed up front they stay live across the
+  // DMA section, whose 64-bit source addresses then spill — and a scratch reload between the two batches of eight DMAs is
+  // followed by s_waitcnt vmcnt(0): the second batch went out only after the first had landed, two HBM round trips in a
+  // row at the head of every workgroup, 8 % of its clocks (tools/gemm_diag/panel_phases.py, round 5))
+  auto fill_lane_tables = [&](int ll, unsigned (&fa)[4]) {
+    const int r_ = ll & 31, h_ = ll >> 5;
+    const int q0_ = ((r_ >> 2) & 1) | ((r_ >> 4) << 1);
+    const int rl_ = ((r_ & 3) << 1) | ((r_ >> 3) & 1);
 #pragma unroll
-  for (int sc = 0; sc < 4; ++sc)
-    f_addr[sc] = static_cast<unsigned>(f_q0 * 4 * 2048 + (f_rl * 8 + (((2 * sc + f_h) ^ f_x))) * 16);
+    for (int sc = 0; sc < 4; ++sc)
+      fa[sc] = static_cast<unsigned>(q0_ * 4 * 2048 + (rl_ * 8 + (((2 * sc + h_) ^ (r_ & 7)))) * 16);
+  };
+  (void)f_q0; (void)f_rl; (void)f_x; (void)f_h;
 
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.wp), 0,
                                                                    static_cast<int>(a.wp_bytes), 0x00020000);
@@ -262,8 +279,6 @@ linear_panel_kernel(const PanelArgs a) {
   // piece) against the tile's 192 MFMAs — and a wavefront issues no MFMA while it walks them (found in the ISA, round 5).
   const unsigned ldy_u = static_cast<unsigned>(a.ldy);
   unsigned e_row[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) e_row[i] = (static_cast<unsigned>(i * 32 + (lane & 31)) * ldy_u + 4u * (lane >> 5));
   const long rows_here = a.M - m0 < BM ? a.M - m0 : BM;
   auto tile_rsrc = [&](int tct, int &soff_elems) {
     const int n0 = tct * TW;
@@ -403,6 +418,7 @@ linear_panel_kernel(const PanelArgs a) {
     int cx[QPW];                               // 16-byte column of this lane's slot: c = d_cc ^ (row & 7)
 #pragma unroll
     for (int u = 0; u < QPW; ++u) {
+      if constexpr (PRE == 0) break;             // (the plain projection forms its addresses inside the DMA loop below)
       const int row = panel_row_of(wave * QPW + u, d_rl);
       cx[u] = d_cc ^ (row & 7);
       long gm = m0 + row;
@@ -427,18 +443,32 @@ linear_panel_kernel(const PanelArgs a) {
         arow[u] = g1[u] < 0 ? 0 : g1[u];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);         // (nothing of the later set-up is to be scheduled into the DMA section)
 #pragma unroll
-    for (int u = 0; u < QPW; ++u)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        if (PANEL_DIAG(a, 4)) break;
-        const float *src = xsu[u] + srow[u] * ldx + (2 * p) * 32 + cx[u] * 4;
-        unsigned char *dst = lds + ((wave * QPW + u) * 4 + p) * 2048;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
-                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, LDAUX);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32),
-                                         (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, LDAUX);
+    for (int u = 0; u < QPW; ++u) {
+      if (PANEL_DIAG(a, 4)) break;
+      // ONE 64-bit source address per row block; the line pair and the half travel as the instruction's immediate
+      // offset (p * 256 + {0, 128} bytes).  The immediate is added to the LDS address as well, so the destination
+      // handed over is the real one minus that offset (panel_dma_pair).
+      const float *src;
+      if constexpr (PRE == 0) {
+        // (nothing of this survives the loop: the split pass below works on LDS slots only — kept in arrays, the 64-bit
+        // row addresses of both row blocks were spilled around the DMA section)
+        const int row = panel_row_of(wave * QPW + u, d_rl);
+        long gm = m0 + row;
+        if (gm >= a.M) gm = a.M - 1;             // clamped rows are computed and never stored
+        const bool second_block = a.xb != nullptr && gm >= a.m_split;
+        src = (second_block ? a.xb + kb + (gm - a.m_split) * ldx : xs + gm * ldx) + (d_cc ^ (row & 7)) * 4;
+      } else {
+        src = xsu[u] + srow[u] * ldx + cx[u] * 4;
       }
+      unsigned char *dst = lds + ((wave * QPW + u) * 4) * 2048;
+      panel_dma_pair<0, LDAUX>(src, dst);
+      panel_dma_pair<1, LDAUX>(src, dst + 2048);
+      panel_dma_pair<2, LDAUX>(src, dst + 2 * 2048);
+      panel_dma_pair<3, LDAUX>(src, dst + 3 * 2048);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float4 ad[PRE ? PPW : 1][2];               // addend / second gathered row: plain loads, under the DMA
     if (PRE == 2 || add) {
 #pragma unroll
@@ -489,6 +519,13 @@ linear_panel_kernel(const PanelArgs a) {
       }
     __syncthreads();                           // planes complete
     PANEL_CLK(2);
+    {
+      int ll = lane;
+      asm volatile("" : "+v"(ll));              // (keeps the two tables out of the DMA section's live set: see f_addr)
+      fill_lane_tables(ll, f_addr);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) e_row[i] = (static_cast<unsigned>(i * 32 + (ll & 31)) * ldy_u + 4u * (ll >> 5));
+    }
 
     // ---------------------------------------------------------------- column sweep: no synchronisation
     const bool last_half = half == nhalf - 1;
@@ -711,7 +748,6 @@ linear_panel_kernel(const PanelArgs a) {
       }
     }
   }
-  }     // panels of this workgroup
 }
 
 // Weight image of the row-panel kernel: for every 32-row tile T of w (N, K), k16 step sg and plane (hi, lo) the

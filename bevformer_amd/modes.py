@@ -19,7 +19,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
     # ahead, e3 both, e4 the round-4 epilogue (bias loaded per piece)
     f"panel{bm}e{v}" for bm in (64, 128) for v in (1, 2, 3, 4)) + tuple(
     # ... and of the phase skew of its column sweep (n x 1024 clocks)
-    f"panel{bm}s{n}" for bm in (64, 128) for n in (0, 1, 2, 3, 4, 6, 8, 12)) + ("panel64p", "panel128p", "panel128d2", "panel128d4")    # p: persistent grid; d2 / d4: one wavefront per SIMD, dripping stores
+    f"panel{bm}s{n}" for bm in (64, 128) for n in (0, 1, 2, 3, 4, 6, 8, 12)) + ("panel128d2", "panel128d4")    # d2 / d4: one wavefront per SIMD, dripping stores
 
 
 class Modes:

@@ -844,11 +844,9 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
             kern, knob = base, 32 + int(kern[len(base) + 1:])                 # epilogue variant
         elif kern.startswith(base + "s") and kern[len(base) + 1:].isdigit():
             kern, knob = base, 64 + int(kern[len(base) + 1:])                 # phase skew of the column sweep
-        elif kern == base + "p":
-            kern, knob = base, 96                                             # persistent grid (walks the row panels)
         elif kern in (base + "d2", base + "d4"):
             kern, knob = base, 97 if kern.endswith("d2") else 98              # one wavefront per SIMD, dripping stores
-    if knob and knob not in (96,) and (a0 is not None or x1 is not None or idx is not None or ln is not None):
+    if knob and (a0 is not None or x1 is not None or idx is not None or ln is not None):
         knob = 0
     desc.reserved[2] = {"panel64": 1, "panel128": 2, "panel64w2": 1, "panel64w6": 1}.get(kern) \
         or (2 if desc.M >= _sel("panel_128_rows") and ln is None else 1)
