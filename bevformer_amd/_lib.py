@@ -73,6 +73,7 @@ class PlanDesc(ctypes.Structure):
 
 ERR_UNSUPPORTED = -7
 ERR_MISALIGNED = -4
+ERR_TOO_LARGE = -3
 _DIMS = [_c_int] * 7
 # name -> argtypes; every symbol the header declares is listed (tests check it)
 SIGNATURES = {

@@ -867,8 +867,8 @@ def _panel_call(desc, x0, a0, x1, a1, idx, scale, w, b, ln, y, tag, flops, nbyte
             rc = lib.bevmsda_linear_panel_f32(p(x0), p(a0), p(x1), p(a1), p(idx), p(scale), _ptr(blob), p(b),
                                               ctypes.byref(desc), ctypes.byref(ln) if ln is not None else None, _ptr(y),
                                               torch.cuda.current_stream().cuda_stream)
-    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
-        return False
+    if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED, getattr(_lib, "ERR_TOO_LARGE", -999)):
+        return False                    # (TOO_LARGE: an output group beyond the epilogue's 32-bit buffer: the first kernel takes it)
     _lib.check(rc, "linear_panel")
     return True
 

@@ -475,7 +475,11 @@ typedef struct bevmsda_layernorm_desc {
  * K = 512 and ln need N <= 256; N % 4 == 0, group_cols % 64 == 0, all pointers 16-byte aligned, row strides
  * multiples of 4; anything else returns BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and the caller uses the entry
  * points above.  The k order inside an MFMA differs from the first kernel's: results agree to fp32 summation
- * order, not bit for bit. */
+ * order, not bit for bit.  The epilogue addresses one output group (M, ldy) through a 32-bit raw buffer: M * ldy * 4 must
+ * stay below 2 GiB per group (BEVMSDA_ERR_TOO_LARGE otherwise).  desc->reserved[3] is a BENCHMARK knob (0 in
+ * production; tools/gemm_epilogue_ab.py, profiles/r5): 2 / 6 weight-fragment prefetch depth of the 64-row shape;
+ * 32 + {1: finished tile stored one piece per k16 step, 2: prefetch depth 4, 3: both, 4: the round-4 epilogue};
+ * 64 + n: phase skew of the column sweep (n x 1024 clocks); 97 / 98: one wavefront per SIMD with dripping stores. */
 int64_t bevmsda_linear_panel_packed_bytes(int N, int K);
 int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream);
 /* ... of the (N, K) weight whose transpose lies in memory: wt (K, ldwt), element (n, k) = wt[k * ldwt + n] (backward GEMMs). */
