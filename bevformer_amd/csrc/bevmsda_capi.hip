@@ -420,7 +420,16 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
       else BEVMSDA_DYN((bevmsda::msda_fused_d32_bf16x8_head_kernel<4, 1, 4>), (bevmsda::msda_fused_d32_bf16x8_dyn_kernel<4, 1, 4>));
     } else {
       if (d->reserved[0] != 0) return BEVMSDA_ERR_BAD_OPTION;
-      if (d->P == 8) {
+      // compile-time head / level counts (msda_d32.h: LC / MC): the encoder's two shapes; desc->reserved[5] = 1 keeps the
+      // generic kernels (tools/fwd_knob_ab.sh)
+      // (measured, round 5: the specialised SCA body — 312 instead of 552 instructions per level — runs at the generic
+      // body's speed, 239-241 us: the kernel is bound by the L1 / TA path, not by instruction issue; A/B knob only)
+      const bool spec = sizeof(T) == 4 && d->M == 8 && a.qtile == 8 && d->reserved[5] == 3;
+      if (spec && d->P == 8 && d->L == 4 && d->K == 1 && !save) {
+        BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4, false, 4, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>));
+      } else if (spec && d->P == 8 && d->L == 4 && d->K == 1 && save) {
+        BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4, true, 4, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4, true>));
+      } else if (d->P == 8) {
         if (d->L > 1 && save) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4, true>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4, true>));
         else if (d->L > 1) BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 4>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 4>));
         else BEVMSDA_DYN((bevmsda::msda_fused_d32_head_kernel<T, 8, 1, 8>), (bevmsda::msda_fused_d32_dyn_kernel<T, 8, 1, 8>));
@@ -460,7 +469,20 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   // experiments (tools/overlap_probe.py): 54 -> at most two workgroups of this kernel per CU, 80 -> one
   if (d->reserved[4] < 0 || d->reserved[4] > 64) return BEVMSDA_ERR_BAD_OPTION;
   const size_t pad = static_cast<size_t>(d->reserved[4]) * 1024;
-  if (d->P == 8) {
+  // desc->reserved[5] (msda_d32.h LC / MC: compile-time head / level counts; tools A/B, profiles/r5): 0 = the default —
+  // TemporalSelfAttention's shape (8 heads, one level, two queue entries) on the specialised body at 128 registers
+  // (70 vs 72.4 us; at 64 registers it spills: 131 us); 1 = generic kernels only; 2 = that body at 64 registers;
+  // 3 = SpatialCrossAttention's shape specialised too (no gain: the kernel is bound by the L1 / TA path)
+  if (d->reserved[5] < 0 || d->reserved[5] > 3) return BEVMSDA_ERR_BAD_OPTION;
+  const bool specable = sizeof(T) == 4 && d->M == 8 && a.qtile == 8 && d->reserved[0] == 0;
+  const bool spec = specable && d->reserved[5] == 3;
+  if (specable && d->reserved[5] == 2 && d->P == 4 && d->K == 2 && d->L == 1) {
+    hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 8, 1, 8>), grid, dim3(256), 0, st, f);
+  } else if (specable && d->reserved[5] != 1 && d->P == 4 && d->K == 2 && d->L == 1) {
+    hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4, 1, 8>), grid, dim3(256), 0, st, f);
+  } else if (spec && d->P == 8 && d->K == 1 && d->L == 4) {
+    hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4, 4, 8>), grid, dim3(256), pad, st, f);
+  } else if (d->P == 8) {
     if (wide) hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 4>), grid, dim3(256), pad, st, f);
     else hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 8, 1, 8>), grid, dim3(256), 0, st, f);
   } else if (d->K == 2) {

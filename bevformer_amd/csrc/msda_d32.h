@@ -275,22 +275,36 @@ __device__ __forceinline__ float lanes_sum(float v) {
 // owned by the lanes of the group: lane j -> queue entry j / PT, point j % PT.  With
 // KT = 2 (TemporalSelfAttention: PT = 4) both queue entries are sampled in the same
 // round and summed into the same accumulator (their mean is the output).
-template <typename T, int PT, int KT, bool SAVE = false>
+// LC / MC > 0: the level count / the head count as COMPILE-TIME constants (the launcher checks the descriptor: 8 heads, query
+// tiles of 8 rows, LC levels): the group -> (row, head) map is shifts, a pixel is 1 KiB (the x-adjacent tap is an immediate
+// offset of its load), the level loop unrolls — round 5: the generic body spends 552 instructions per level of 32 tap
+// loads (1,169 per row for TemporalSelfAttention's single level), much of it 64-bit address and division arithmetic on
+// runtime strides.  0 = the generic body.
+template <typename T, int PT, int KT, bool SAVE = false, int LC = 0, int MC = 0>
 __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblock, long NQ, int tid, long row0 = 0) {
   static_assert(!SAVE || KT == 1, "SAVE: one queue entry");
   constexpr int D = 32, LPG = 8, GPB = 256 / LPG, NP = PT * KT;
   static_assert((PT == 4 || PT == 8) && (KT == 1 || KT == 2) && NP <= 8, "PT/KT");
+  static_assert(MC == 0 || MC == 8, "MC");
   const KArgs &a = f.k;
   const int lig = tid & 7;
   const long G = static_cast<long>(lblock) * GPB + (tid >> 3);
   long r; int m;
-  map_group(G, a, r, m);
+  if constexpr (MC == 8) {                              // M = 8 heads, qtile = 8 rows: 64 groups per tile
+    const long tile = G >> 6;
+    const int rr = static_cast<int>(G & 63);
+    m = rr >> 3;
+    r = (tile << 3) + (rr & 7);
+  } else {
+    map_group(G, a, r, m);
+  }
   r += row0;
   const bool active = r < NQ;
   if (!active) r = NQ - 1;
-  const int L = a.L;                                    // 1..4 (host-checked)
+  const int L = LC > 0 ? LC : a.L;                      // 1..4 (host-checked)
+  const int Mh = MC > 0 ? MC : a.M;
   const long base = a.row_batch ? static_cast<long>(a.row_batch[r]) : r / a.Q;
-  const uint32_t pix_bytes = static_cast<uint32_t>(a.M) * D * sizeof(T);
+  const uint32_t pix_bytes = static_cast<uint32_t>(Mh) * D * sizeof(T);
   const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
   const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
@@ -300,7 +314,7 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
   const int q = owner ? lig / PT : 0;                    // my queue entry
   const int pj = owner ? lig % PT : 0;                   // my point
   const long n = base * f.vmul + static_cast<long>(q) * f.vadd;
-  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * a.M + m) * D * sizeof(T));
+  const uint32_t head_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * Mh + m) * D * sizeof(T));
   const long rs = f.row_src ? static_cast<long>(f.row_src[r]) : r;
   const float *__restrict__ lgp = f.logits + rs * f.proj_row + m * f.lg_head + q * f.lg_k + pj;
   const float2 *__restrict__ ofp =
@@ -320,7 +334,9 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
   const float sum = lanes_sum<PT>((e0 + e1) + (e2 + e3));
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int l = 0; l < L; ++l) {
+  // (a known level count is NOT unrolled: four levels' taps in one body spill at 128 registers — 1.6 KB of scratch, measured)
+#pragma nounroll
+  for (int l = 0; l < (LC > 0 ? LC : L); ++l) {
     const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
     const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
     const float lx = rf.x + of.x / static_cast<float>(W);
@@ -330,7 +346,7 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
     const PointParams p = point_params(lx, ly, aw, H, W, head_base + lbytes, pix_bytes);
     if constexpr (SAVE) {
       if (live) {                   // (r, m, l, pj): 64 + 32 contiguous bytes per (row, head, level)
-        const long o = ((r * a.M + m) * L + l) * PT + pj;
+        const long o = ((r * Mh + m) * L + l) * PT + pj;
         reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);
         f.save_attn[o] = aw;
       }
@@ -342,7 +358,7 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
     sample_points<0, NP, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
   }
   if (active) {
-    T *op = static_cast<T *>(a.out) + (r * a.M + m) * D + lig * 4;
+    T *op = static_cast<T *>(a.out) + (r * Mh + m) * D + lig * 4;
     const float sc = f.out_scale;
     if constexpr (sizeof(T) == 4) {
       *reinterpret_cast<float4 *>(op) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
@@ -355,21 +371,21 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
   }
 }
 
-template <typename T, int PT, int KT, int WPE>
+template <typename T, int PT, int KT, int WPE, int LC = 0, int MC = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_kernel(const FusedArgs f) {
-  msda_fused_d32_body<T, PT, KT>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
+  msda_fused_d32_body<T, PT, KT, false, LC, MC>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
 }
 
 // The same kernel over a device-side row count (DynRows): head = one workgroup per logical block of
 // the hinted count, tail = a small strided grid for rows beyond the hint.
-template <typename T, int PT, int KT, int WPE, bool SAVE = false>
+template <typename T, int PT, int KT, int WPE, bool SAVE = false, int LC = 0, int MC = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 msda_fused_d32_head_kernel(const FusedArgs f) {
   const DynRows d = dyn_rows(f, false);
   const int b = blockIdx.x;
   if ((b >> 3) >= d.per) return;
-  msda_fused_d32_body<T, PT, KT, SAVE>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
+  msda_fused_d32_body<T, PT, KT, SAVE, LC, MC>(f, (b & 7) * d.per + (b >> 3), d.NQ, threadIdx.x);
 }
 
 template <typename T, int PT, int KT, int WPE, bool SAVE = false>

@@ -24,7 +24,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec")
 
     def __init__(self):
         env = os.environ.get
@@ -41,6 +41,10 @@ class Modes:
         self.wgrad = env("BEVMSDA_WGRAD", "1") == "1"               # weight gradients on the TN MFMA kernel
         self.bf16_lanes8 = env("BEVMSDA_BF16_LANES8") is not None   # benchmark knob: 8-byte-lane bf16 kernels
         self.fused_wpe = int(env("BEVMSDA_FUSED_WPE", "0"))         # benchmark knob: register budget of the fused kernel
+        # fused sampling kernels with compile-time head / level counts (msda_d32.h LC / MC), the library's reserved[5]: 0 =
+        # default (TemporalSelfAttention's shape specialised at 128 registers), 1 = generic kernels only, 2 = TSA's at 64
+        # registers, 3 = SpatialCrossAttention's shape specialised too (A/B knobs; profiles/r5)
+        self.fused_spec = int(env("BEVMSDA_FUSED_SPEC", "0"))
         self.fused_lds_pad_kb = int(env("BEVMSDA_FUSED_LDS_PAD", "0"))                                    # co-scheduling probe: occupancy cap of the sampling kernel
         self.stack_free = env("BEVMSDA_STACK_FREE", "1") == "1"      # inference: TSA's [history ; queries] value projected without forming the stack
         self.weight_views = env("BEVMSDA_WEIGHT_VIEWS", "1") == "1"  # training: W^T images packed from W (no transposed copies)

@@ -249,6 +249,8 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     desc = _lib.FusedDesc(R=R, proj_row=proj.stride(0), N=N, S=S, M=M, D=D, L=L, P=P, Q=Q, K=K, A=A,
                           ref_mode=ref_mode, off_head=off_head, off_k=off_k, lg_head=lg_head,
                           lg_k=lg_k, vmul=vmul, vadd=vadd)
+    if _m().fused_spec:                     # A/B knob of the specialised bodies (modes.Modes.fused_spec)
+        desc.reserved[5] = _m().fused_spec
     if _m().fused_wpe and nrows is None:   # benchmark sweeps: register budget of the kernel
         desc.reserved[0] = _m().fused_wpe
     if _m().fused_lds_pad_kb and L > 1:    # occupancy cap of the multi-level (SCA) launch

@@ -200,7 +200,11 @@ typedef struct bevmsda_fused_desc {
   int32_t vmul, vadd;
   int32_t reserved[6];   /* [0]: 0 = default, 4 / 8 = kernel sized for 4 / 8 waves per SIMD; bf16 entry point
                             only: [1] = 1 selects the 8-byte-lane kernel instead of the 16-byte-lane one,
-                            [2] = 1 (16-byte-lane kernel) makes `out` an fp32 (R, M*D) matrix */
+                            [2] = 1 (16-byte-lane kernel) makes `out` an fp32 (R, M*D) matrix;
+                            [5] (fp32 entry points, benchmark knob): bodies with compile-time head / level counts —
+                            0 = default (the 8-head, one-level, two-entry shape of TemporalSelfAttention at 128
+                            registers), 1 = generic kernels only, 2 = that body at 64 registers, 3 = the 8-head,
+                            4-level shape of SpatialCrossAttention specialised too (no gain: profiles/r5) */
 } bevmsda_fused_desc;
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
