@@ -71,3 +71,25 @@ def test_hf_deformable_detr_cross_check():
     except Exception:  # signature drift between transformers versions
         pytest.skip("HF MultiScaleDeformableAttention signature differs")
     torch.testing.assert_close(hf, O.msda_gridsample(value, sh, loc, attn), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["micro4", "tiny"])
+def test_oracle_rows_helper_equals_the_full_oracle(name):
+    """tests/helpers.py::oracle_encoder_rows (the oracle on a subset of BEV queries: what the base-size gradient check
+    differentiates) against ``O.encoder_forward`` on the same rows; and EdgeRecorder leaves the operator's output alone."""
+    from helpers import EdgeRecorder, build_pair, camera_rows, oracle_encoder_rows
+    from bevformer_amd import synthetic as S
+    _, sd = build_pair(name)
+    q, f, kw = S.make_inputs(name, seed=0, temporal=True)
+    rows = torch.randperm(q.shape[0], generator=torch.Generator().manual_seed(3))[: q.shape[0] // 3].sort().values
+    with torch.no_grad():
+        want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+        rec = EdgeRecorder(q.shape[0], camera_rows(name, rows), eps=1e-3, query_ids=rows)
+        got = oracle_encoder_rows(sd, q, f, rows, pc_range=S.PC_RANGE, msda=rec, **kw)
+        full = EdgeRecorder(q.shape[0], camera_rows(name), eps=1e-3)
+        again = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, msda=full, **kw)
+    torch.testing.assert_close(got, want[:, rows], rtol=1e-5, atol=1e-5)
+    assert torch.equal(again, want)
+    # the subset run flags exactly the subset's share of the full run's edge-adjacent queries
+    assert torch.equal(rec.fragile[rows], full.fragile[rows]) and not rec.fragile[~torch.isin(torch.arange(q.shape[0]), rows)].any()
+    assert 0 < int(full.fragile.sum()) < q.shape[0]
