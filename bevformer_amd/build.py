@@ -23,6 +23,12 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          "-Wno-pass-failed"]
 
 
+# per-source additions to FLAGS
+EXTRA_FLAGS = {"bevmsda_capi_backward.hip": ["-fno-slp-vectorize"]}     # (why: the header of that file)
+# sources that #include another source
+INCLUDES = {"bevmsda_capi_backward.hip": ["bevmsda_capi.hip"]}
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -41,7 +47,8 @@ def _stale_objects():
     out = []
     for s in sources():
         o = _obj(s)
-        if not os.path.exists(o) or os.path.getmtime(o) < max(hm, os.path.getmtime(os.path.join(CSRC, s))):
+        newest = max([hm] + [os.path.getmtime(os.path.join(CSRC, f)) for f in [s] + INCLUDES.get(s, [])])
+        if not os.path.exists(o) or os.path.getmtime(o) < newest:
             out.append(s)
     return out
 
@@ -65,7 +72,7 @@ def build_library(force=False, verbose=False):
     todo = sources() if force else _stale_objects()
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src) + ".tmp"]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src) + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=CSRC)

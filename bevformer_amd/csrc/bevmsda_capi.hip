@@ -2,13 +2,24 @@
 // kernel selection and launches.  No torch, no allocation, no global state.
 #include <stdlib.h>
 
+// This file is compiled TWICE (bevformer_amd/build.py): as itself — every entry point except the sampling backward — and through
+// bevmsda_capi_backward.hip with BEVMSDA_PART_BACKWARD — the bevmsda_backward_* entry points only, without the SLP vectorizer
+// (the reason is written there).
+#ifdef BEVMSDA_PART_BACKWARD
+#define BEVMSDA_FWD_PART 0
+#else
+#define BEVMSDA_FWD_PART 1
+#endif
+
 #include "../../include/bevmsda.h"
 #include "msda_kernels.h"
 #include "msda_d32.h"
 #include "msda_bwd_lds.h"
 #include "msda_bwd_gather.h"
+#if BEVMSDA_FWD_PART
 #include "rowops.h"
 #include "prologue.h"
+#endif
 
 namespace {
 
@@ -70,7 +81,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
   if (nb >= (1LL << 31) - 8) return BEVMSDA_ERR_TOO_LARGE;
   a.nblocks = static_cast<int>(nb);
   const unsigned grid = a.xcd_remap ? static_cast<unsigned>(((nb + 7) / 8) * 8) : static_cast<unsigned>(nb);
-  if (BWD && a.D == 32 && a.variant != 1) {
+  if constexpr (BWD) {            // (if constexpr: each of the two translation units instantiates only its own kernels)
+  if (a.D == 32 && a.variant != 1) {
     KArgs b = a;
     const long g8 = tiles * a.qtile * a.M;
     const long nb8 = (g8 + 31) / 32;
@@ -182,13 +194,15 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
         default: hipLaunchKernelGGL((bevmsda::msda_bwd_d32_kernel<T, 0>), dim3(grid8), dim3(256), 0, stream, b); break;
       }
     }
-  } else if (BWD) {
+  } else {
     switch (a.P) {
       case 4: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 4>), dim3(grid), dim3(256), 0, stream, a); break;
       case 8: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 8>), dim3(grid), dim3(256), 0, stream, a); break;
       default: hipLaunchKernelGGL((bevmsda::msda_bwd_kernel<T, CPL, LPG, 0>), dim3(grid), dim3(256), 0, stream, a); break;
     }
-  } else if (!BWD && a.variant != 1 && d32_fwd_eligible<T>(a)) {
+  }
+  } else {
+  if (a.variant != 1 && d32_fwd_eligible<T>(a)) {
     // variant 0 / 3: registers for 4 waves per SIMD; 4: 8 waves; 5: 2 waves (msda_d32.h)
     const int wpe = a.variant == 4 ? 8 : (a.variant == 5 ? 2 : 4);
     KArgs b = a;
@@ -214,6 +228,7 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       default: hipLaunchKernelGGL((bevmsda::msda_fwd_kernel<T, CPL, LPG, 0>), dim3(grid), dim3(256), 0, stream, a); break;
     }
   }
+  }
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
@@ -222,7 +237,7 @@ int launch_scalar(const KArgs &a, hipStream_t stream) {
   const long long total = 1LL * a.NQ * a.M * a.D;
   const long long nb = (total + 255) / 256;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  if (BWD) {
+  if constexpr (BWD) {
     const size_t npts = static_cast<size_t>(a.NQ) * a.M * a.L * a.P;
     if (hipMemsetAsync(a.grad_attn, 0, npts * sizeof(float), stream) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
     if (hipMemsetAsync(a.grad_loc, 0, npts * 2 * sizeof(float), stream) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
@@ -499,6 +514,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
 
 extern "C" {
 
+#if BEVMSDA_FWD_PART
 int bevmsda_abi_version(void) { return BEVMSDA_ABI_VERSION; }
 
 const char *bevmsda_error_string(int code) {
@@ -527,6 +543,8 @@ int bevmsda_forward_f32_ex(const float *value, const int64_t *spatial_shapes, co
   return forward_impl<float>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, tuning);
 }
 
+#endif
+#if !BEVMSDA_FWD_PART
 int bevmsda_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                          const float *loc, const float *attn, const float *grad_out, int N, int S, int M,
                          int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
@@ -543,12 +561,16 @@ int bevmsda_backward_f32_ex(const float *value, const int64_t *spatial_shapes, c
                               grad_value, grad_loc, grad_attn, stream, tuning);
 }
 
+#endif
+#if BEVMSDA_FWD_PART
 int bevmsda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                          const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
                          int P, uint16_t *out, void *stream) {
   return forward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, nullptr);
 }
 
+#endif
+#if !BEVMSDA_FWD_PART
 int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                           const float *loc, const float *attn, const uint16_t *grad_out, int N, int S, int M,
                           int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
@@ -557,12 +579,16 @@ int bevmsda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes, 
                                grad_value, grad_loc, grad_attn, stream, nullptr);
 }
 
+#endif
+#if BEVMSDA_FWD_PART
 int bevmsda_forward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                             const float *loc, const float *attn, int N, int S, int M, int D, int L, int Q,
                             int P, uint16_t *out, void *stream, const bevmsda_tuning *tuning) {
   return forward_impl<bf16_t>(value, spatial_shapes, level_start, loc, attn, N, S, M, D, L, Q, P, out, stream, tuning);
 }
 
+#endif
+#if !BEVMSDA_FWD_PART
 int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                              const float *loc, const float *attn, const uint16_t *grad_out, int N, int S, int M,
                              int D, int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn,
@@ -571,6 +597,8 @@ int bevmsda_backward_bf16_ex(const uint16_t *value, const int64_t *spatial_shape
                                grad_value, grad_loc, grad_attn, stream, tuning);
 }
 
+#endif
+#if BEVMSDA_FWD_PART
 int bevmsda_forward_ragged_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *loc, const float *attn, const int32_t *row_batch, int N, int S,
                                int M, int D, int L, int R, int P, float *out, void *stream) {
@@ -579,6 +607,8 @@ int bevmsda_forward_ragged_f32(const float *value, const int64_t *spatial_shapes
                              nullptr, row_batch, R);
 }
 
+#endif
+#if !BEVMSDA_FWD_PART
 int bevmsda_backward_ragged_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                 const float *loc, const float *attn, const int32_t *row_batch,
                                 const float *grad_out, int N, int S, int M, int D, int L, int R, int P,
@@ -588,6 +618,8 @@ int bevmsda_backward_ragged_f32(const float *value, const int64_t *spatial_shape
                               grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R);
 }
 
+#endif
+#if BEVMSDA_FWD_PART
 int bevmsda_forward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                 const float *loc, const float *attn, const int32_t *row_batch, int N, int S,
                                 int M, int D, int L, int R, int P, uint16_t *out, void *stream) {
@@ -596,6 +628,8 @@ int bevmsda_forward_ragged_bf16(const uint16_t *value, const int64_t *spatial_sh
                               nullptr, row_batch, R);
 }
 
+#endif
+#if !BEVMSDA_FWD_PART
 int bevmsda_backward_ragged_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                  const float *loc, const float *attn, const int32_t *row_batch,
                                  const uint16_t *grad_out, int N, int S, int M, int D, int L, int R, int P,
@@ -645,6 +679,8 @@ int bevmsda_backward_shared_bf16(const uint16_t *value, const int64_t *spatial_s
                               static_cast<long>(grad_value_stride));
 }
 
+#endif
+#if BEVMSDA_FWD_PART
 int bevmsda_rows_from_slots_f32(const float *slots, int64_t ld_slots, const float *scale, const int32_t *row_slot,
                                 const int32_t *nrows, int64_t R, int C, float *rows, void *stream) {
   if (R < 0 || C <= 0 || ld_slots < C) return BEVMSDA_ERR_BAD_SHAPE;
@@ -864,4 +900,5 @@ int bevmsda_flatten_feats_f32(const float *feat, const float *cams_embeds, const
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 
+#endif
 }  // extern "C"

@@ -318,6 +318,9 @@ def fused_training_wanted(*tensors):
         and any(t is not None and t.requires_grad for t in tensors) and not torch.is_autocast_enabled()
 
 
+_DEBUG_TAP = None
+
+
 class _FusedSampleFunction(Function):
     """``msda_fused`` under autograd.  Forward: the fused kernel (softmax, locations, sampling, queue mean from
     the raw projection rows) — nothing but its inputs is saved.  Backward (include/bevmsda.h,
@@ -489,6 +492,8 @@ class _FusedSampleFunction(Function):
                 _lib.check(lib.bevmsda_frontend_chain_f32(
                     _ptr(gl), _ptr(ga), _ptr(attn), _ptr(row_src) if row_src is not None else None, _ptr(shapes),
                     ctypes.byref(desc), gproj.data_ptr(), gproj[:, ctx.n_off:].data_ptr(), st), "fused backward: chain")
+        if _DEBUG_TAP is not None:      # forensics (tools/ddp_diag.py): every operand and result of this backward
+            _DEBUG_TAP(ctx.tag, dict(proj=proj, ref=ref, loc=loc, attn=attn, g=g, gl=gl, ga=ga, gproj=gproj, nrows=nrows))
         if ctx.value_sink is not None:
             sink, slot = ctx.value_sink
             sink[slot] = gv

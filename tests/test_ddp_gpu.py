@@ -108,11 +108,10 @@ def _worker(rank, world, port, name, bucket_view, ret):
                     assert p.grad is not None, k
                     got[k] = p.grad
                 err, where = _rel_errors(got, want)
-                # A pass of a DDP-wrapped encoder next to a second process on the same GPU shows, about once in sixteen
-                # passes, ONE wrong element of ONE sampling-offset gradient column (1e-3 .. 1e-2 of that tensor; forward
-                # bit-equal, the next pass right again; never without the DDP pass, never in one process:
-                # profiles/r5/r5_ddp_forensics.txt).  Unexplained and recorded; a pass that disagrees is repeated on both
-                # ranks and must agree then — a systematic error (averaging, hooks, stale weight images) fails all attempts.
+                # (Round 5 found this scenario — a second process on the same GPU — computing, about once in fifty passes, ONE
+                # wrong grad_loc_y in msda_gradloc_d32_kernel: packed fp32 math in that kernel, profiles/r5/r5_ddp_forensics.txt;
+                # the sampling-backward unit is built without it since.  The loop that repeats a disagreeing pass on both
+                # ranks stays as the detector: the test now demands that NO pass disagrees.)
                 if not agree(err > 2e-4):
                     break
                 glitches.append((attempt, err, where))
@@ -128,6 +127,13 @@ def _worker(rank, world, port, name, bucket_view, ret):
             diff = max((a - b).abs().max().item()
                        for (_, a), (_, b) in zip(ddp.module.named_parameters(), ref.named_parameters()))
             report[f"iter{it}_weights_equal_after_step"] = diff <= LR * 1e-2 * gmax + 1e-7
+            # ... and from here on bit-equal: the two updates differ by the rounding of their mean gradients, and a weight
+            # difference of 1e-9 is enough to move a sampling point of `tiny` across a pixel boundary (its grad_loc_y then takes
+            # the neighbouring cell's slope: 3e-3 of the offset-bias gradient, seen twice at iter 1) — a property of bilinear
+            # sampling, not of the reducer under test
+            with torch.no_grad():
+                for (_, a), (_, b) in zip(ddp.module.named_parameters(), ref.named_parameters()):
+                    b.copy_(a)
         # state_dict round trip: the flattened (re-seated) parameters save and load like any others
         sd = {k: v.detach().cpu().clone() for k, v in ddp.module.state_dict().items()}
         fresh, _ = build_pair(name, device=dev)
@@ -170,8 +176,8 @@ def test_ddp_gradients_are_the_mean_of_the_single_process_gradients(name, bucket
         for it in (0, 1):
             # the summation order of the backward kernels' atomics is not fixed: rounding-level agreement
             assert rep[f"iter{it}_worst_rel_l2"] < 2e-4, (r, rep)
-            assert len(rep[f"iter{it}_glitched_passes"]) <= 2, (r, rep)
+            assert not rep[f"iter{it}_glitched_passes"], (r, rep)
             assert rep[f"iter{it}_fast_path_seams"] > 0, "the training fast path did not run under DDP"
             assert rep[f"iter{it}_weights_equal_after_step"], (r, rep)
         assert rep["state_dict_round_trip_max_abs"] < 1e-5 and rep["state_dict_keys"], (r, rep)
-        assert rep["stale_cache_worst_rel_l2"] < 2e-4 and len(rep["stale_cache_glitched_passes"]) <= 2, (r, rep)
+        assert rep["stale_cache_worst_rel_l2"] < 2e-4 and not rep["stale_cache_glitched_passes"], (r, rep)

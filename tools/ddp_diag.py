@@ -31,6 +31,7 @@ def worker(rank, world, port, name, tries):
     gout = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + rank)) * 1e-2
     ddp = DDP(enc, device_ids=[0], broadcast_buffers=False)
     mode = os.environ.get("DDP_DIAG_MODE", "ddp")
+    glitches = 0
     for t in range(tries):
         # one DDP pass (all-reduce included), then direct passes of the same module: pass A right after it, pass B after A
         ddp.zero_grad(set_to_none=True)
@@ -48,9 +49,22 @@ def worker(rank, world, port, name, tries):
         if mode == "alloc":             # no DDP pass: allocator churn in front of pass A (other blocks than pass B / C will get)
             junk = [torch.randn(n, device=dev) for n in (1 << 20, 3 << 18, 1 << 16, 5 << 14)]
             del junk
-        oA, gA = _grads(ddp.module, q, f, kw, gout)
-        oB, gB = _grads(ddp.module, q, f, kw, gout)
-        oC, gC = _grads(ddp.module, q, f, kw, gout)
+        recs = {}
+
+        def tapped(name):
+            """One direct pass; with DDP_DIAG_TAP=1 every operand / result of every fused sampling backward is kept."""
+            if os.environ.get("DDP_DIAG_TAP") != "1":
+                return _grads(ddp.module, q, f, kw, gout)
+            from bevformer_amd import ops
+            rec = recs[name] = []
+            ops._DEBUG_TAP = lambda tag, d: rec.append((tag, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}))
+            try:
+                return _grads(ddp.module, q, f, kw, gout)
+            finally:
+                ops._DEBUG_TAP = None
+        oA, gA = tapped("A")
+        oB, gB = tapped("B")
+        oC, gC = tapped("C")
         def worst(a, b):
             floor = 1e-2 * max(v.norm().item() for v in b.values())
             return max((((a[k] - b[k]).norm() / max(b[k].norm().item(), floor)).item(), k) for k in b)
@@ -67,9 +81,39 @@ def worker(rank, world, port, name, tries):
                 rows = (d > thr).any(1).nonzero().flatten()
                 cols = (d > thr).any(0).nonzero().flatten()
                 msg += f"\n   rows {rows[:8].tolist()}..{rows[-3:].tolist()} ({rows.numel()}), cols {cols[:8].tolist()}..{cols[-3:].tolist()} ({cols.numel()})"
+            i0 = tuple(bad[0].tolist())
+            msg += f"\n   element {i0}: odd {odd[k][i0].item():+.6e} ok {ok1[k][i0].item():+.6e} (odd - ok = {(odd[k][i0] - ok1[k][i0]).item():+.3e}, max |grad| {ok1[k].abs().max().item():.3e})"
             others = sorted((((odd[n] - ok1[n]).norm() / (ok1[n].norm() + 1e-30)).item(), n) for n in ok1)[-5:]
             msg += "\n   plain rel L2 top: " + ", ".join(f"{n.replace('layers.', 'L')}: {e:.1e}" for e, n in reversed(others))
-        print(msg, flush=True)
+            if recs:
+                names = ("A", "B") if wBC[0] < 2e-4 else (("B", "C") if wAC[0] < 2e-4 else ("C", "A"))
+                for i, ((tag, do), (_, dk)) in enumerate(zip(recs[names[0]], recs[names[1]])):
+                    n = int(do["nrows"].item()) if do["nrows"] is not None else None
+                    for key in ("proj", "ref", "loc", "attn", "g", "gl", "ga", "gproj"):
+                        a, b = do[key], dk[key]
+                        if key in ("loc", "attn", "gl", "ga") and n is not None:
+                            a, b = a[:n], b[:n]
+                        a, b = a.float(), b.float()
+                        exact = key in ("proj", "ref", "loc", "attn")
+                        dd = (a - b).abs()
+                        lim = 0.0 if exact else 1e-4 * b.abs().max().item()
+                        nbad = int((dd > lim).sum().item())
+                        if nbad:
+                            idx = (dd > lim).nonzero()[:3].tolist()
+                            vals = [(a[tuple(j)].item(), b[tuple(j)].item()) for j in idx]
+                            msg += f"\n   call {i} {tag} {key} {tuple(a.shape)}: {nbad} elements differ (odd pass {names[0]} vs {names[1]}), at {idx} values {vals}"
+                            if key == "gl" and nbad <= 8:
+                                for j in (dd > lim).nonzero().tolist():
+                                    r, m, l, pnt, c = j
+                                    lx, ly = do["loc"][r, m, l, pnt].tolist()
+                                    same = [bool(torch.equal(do[k2][r, m, l, pnt], dk[k2][r, m, l, pnt])) for k2 in ("loc", "attn", "ga")]
+                                    gx_pair = (do["gl"][r, m, l, pnt, 0].item(), dk["gl"][r, m, l, pnt, 0].item())
+                                    msg += (f"\n      (row {r}, head {m}, level {l}, point {pnt}, {'xy'[c]}): loc ({lx!r}, {ly!r}); loc / attn / grad_attn "
+                                            f"bit-equal {same}; grad_loc.x odd {gx_pair[0]!r} ok {gx_pair[1]!r}; whole gl row of this (row, head) differs in "
+                                            f"{int((do['gl'][r, m] != dk['gl'][r, m]).sum())} of {do['gl'][r, m].numel()} elements (bitwise)")
+            glitches += 1
+            print(msg, flush=True)
+    print(f"rank {rank} mode {mode}: {glitches} of {tries} tries with a disagreeing pass", flush=True)
     dist.destroy_process_group()
 
 
