@@ -780,8 +780,15 @@ def main():
     ts = timed_windows(cfg, step, fence, args.steps, 1, graph)       # window 0 carries the in-region events
     timer.enabled = False
     ts += timed_windows(cfg, step, fence, args.steps, max(0, args.windows - 1), graph)
+    rank_ms = None
     if world > 1:
         t = torch.tensor(ts, device=dev, dtype=torch.float64)
+        try:            # every rank's own clock around the same windows -> per-rank step time and skew on the line
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            rank_ms = [statistics.median(x.tolist()) / args.steps * 1e3 for x in allt]
+        except Exception:       # noqa: BLE001
+            rank_ms = None
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ts = [float(v) for v in t.tolist()]
     dt = statistics.median(ts)
@@ -1012,6 +1019,9 @@ def main():
             collective = dict(error=f"{type(e).__name__}: {str(e)[:160]}")
     if line is not None:
         line["ranks"] = world
+        if rank_ms is not None:
+            line["rank_skew"] = dict(per_rank_ms_per_step=rank_ms, max_minus_min_ms=max(rank_ms) - min(rank_ms),
+                                     note="each rank's median over the same barrier-bracketed windows; ms_per_step is the MAX")
         if collective is not None:
             line["collective"] = collective
     if line is not None and replicas is not None:

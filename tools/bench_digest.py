@@ -24,7 +24,7 @@ if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print(f"cpu {c['value']:.0f} q/s on {c['cores']} threads, runs {c.get('runs_s')}; vs_cpu {d.get('vs_cpu_baseline'):.0f}x")
 for k, v in (d.get("variants") or {}).items():
-    print(f"  variant {k}: {v['ms_per_step']:.3f} ms (min {v['ms_per_step_min']:.3f}) {v['launch_mode']} parity {v.get('parity')}")
+    print(f"  variant {k}: {v['ms_per_step']:.3f} ms (min {v.get('ms_per_step_min', float('nan')):.3f}) {v['launch_mode']} parity {v.get('parity')}")
 for key in ("multi_gpu_model", "multi_gpu_model_bf16"):
     m = d.get(key)
     if m:
