@@ -327,6 +327,7 @@ class Config:
             plan = self.enc.frame_plan(self.w["bev_h"], self.w["bev_w"], 1, self.kw["img_metas"], self.dev,
                                        torch.float32)
         if plan.dynamic:
+            assert plan.dropped_rows() == 0, "frame plan: rows dropped (row capacity too small)"
             return int(plan.nrows_dev.item())
         return int(plan.row_batch.numel())
 

@@ -111,6 +111,14 @@ class FramePlan:
     def dynamic(self):
         return self.nrows_dev is not None
 
+    def dropped_rows(self):
+        """Rows of this frame that did not fit the planner's ``row_capacity`` (ONE device -> host read).  0 by default — the
+        default capacity is every (camera, query) pair —; a user-sized capacity that is too small makes the plan kernels
+        count the overflow here instead of writing past the arrays.  ``materialize()`` raises on it; the paths that never
+        materialise (HIP-graph replay, ``snapshot()`` of the training fast path) cannot read the host inside the step, so a
+        caller that sizes the capacity itself checks this once per sequence, outside the captured region."""
+        return int(self.counters[1].item()) if self.counters is not None else 0
+
     def snapshot(self):
         """A private copy of a device-side plan that STAYS device-side: the planner's buffers are rewritten in place by
         its next ``plan()`` (raw pointers, no version counter moves) and the autograd Functions of the training path

@@ -712,6 +712,24 @@ def _zero_scalar(dtype, device):
     return z
 
 
+def clear_weight_caches(module):
+    """Drop every derived weight image (packed / panel / transposed copies, cached on the parameters per version) of
+    ``module``'s parameters.  Needed in ONE situation: parameters that are inference tensors (a model built or loaded
+    under ``torch.inference_mode``) track no version, so an in-place write to them (``load_state_dict`` under
+    ``inference_mode``) cannot invalidate the images — call this after such a write.  Returns the number dropped."""
+    n = 0
+    for p in module.parameters():
+        for name in ("_bevmsda_pack", "_bevmsda_panel", "_bevmsda_wt"):
+            if hasattr(p, name):
+                delattr(p, name)
+                n += 1
+    for m in module.modules():          # merged-projection views cached on the owning modules (merged_linear_params)
+        for name in [k for k in vars(m) if k.startswith("_merged_")]:
+            delattr(m, name)
+            n += 1
+    return n
+
+
 def _is_transposed_view(w):
     """(N, K) tensor whose memory is the row-major (K, N) matrix (``m.t()`` of a matrix with unit column stride)."""
     return w.dim() == 2 and w.shape[0] > 1 and w.shape[1] > 1 and w.stride(0) == 1 and w.stride(1) >= w.shape[0]

@@ -113,6 +113,7 @@ def test_row_capacity_overflow_is_counted_not_written():
     pl, dyn = _device_plan("tiny", 1, metas, cap=R - 7)
     c = dyn.counters.cpu().tolist()
     assert c[0] == R - 7 and c[1] == 7 and c[3] == R
+    assert dyn.dropped_rows() == 7 and dyn.snapshot().dropped_rows() == 7      # (the check of the paths that never materialise)
     with pytest.raises(RuntimeError, match="row capacity"):
         dyn.materialize()
 

@@ -230,3 +230,19 @@ def test_kernel_selection_table_names_existing_profiles_and_matches_the_library_
     assert int(re.search(r"kLinearPipeMaxRows\s*=\s*(\d+)", src).group(1)) == ops.KERNEL_SELECTION["pipe_max_rows"][0]
     assert int(re.search(r"kChainSmallRows\s*=\s*(\d+)", src).group(1)) == ops.KERNEL_SELECTION["chain_small_rows"][0]
     assert "256LL * 64" in src and ops.KERNEL_SELECTION["chain_mixed_rows"][0] == 256 * 64
+
+
+def test_clear_weight_caches_drops_every_derived_image():
+    """``ops.clear_weight_caches``: the escape hatch for parameters that are inference tensors (no version counter)."""
+    import torch
+    from bevformer_amd import ops
+    lin = torch.nn.Linear(8, 4)
+    lin.weight._bevmsda_pack = ("k", torch.zeros(1))
+    lin.weight._bevmsda_wt = ("k", torch.zeros(1))
+    holder = torch.nn.Module()
+    holder.lin = lin
+    holder.__dict__["_merged_linear"] = ("k", None, None)
+    assert ops.clear_weight_caches(holder) == 3
+    assert not hasattr(lin.weight, "_bevmsda_pack") and not hasattr(lin.weight, "_bevmsda_wt")
+    assert "_merged_linear" not in holder.__dict__
+    assert ops.clear_weight_caches(holder) == 0
