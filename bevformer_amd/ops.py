@@ -690,11 +690,28 @@ def set_gemm_variant(variant=None, pack=None):
         _modes.process_defaults().gemm_pack = variant >= 4
 
 
+_REPACK_IN_EVERY_GRAPH = os.environ.get("BEVMSDA_GRAPH_REPACK", "0") == "1"      # A/B knob: round 4's behaviour
+
+
 def _cache_ok(weight):
-    """Derived images of a weight (packed / transposed copies) are cached per version — except while a HIP graph is being
-    captured over a TRAINABLE weight: the replayed graph must rebuild them from the weight's current values (an optimizer
-    step between replays changes them without the capture noticing), so the conversion kernels are captured too."""
-    return not (weight.requires_grad and weight.is_cuda and torch.cuda.is_current_stream_capturing())
+    """Derived images of a weight (packed / transposed copies) are cached per version — except while a HIP graph of a
+    TRAINING step is being captured over a trainable weight (grad mode on): the replayed graph must rebuild them from
+    the weight's current values (an optimizer step between replays changes them without the capture noticing), so the
+    conversion kernels are captured too.  A graph captured under ``torch.no_grad()`` is an inference graph: it freezes
+    the images it was captured with, exactly as it freezes the merged (concatenated) projection weights — change the
+    weights, capture again (round 5: the 24 re-packing launches per replayed forward step were 2.8 % of it)."""
+    return not (weight.requires_grad and (torch.is_grad_enabled() or _REPACK_IN_EVERY_GRAPH) and weight.is_cuda
+                and torch.cuda.is_current_stream_capturing())
+
+
+_CAPTURED_IMAGES = []       # images a capture handed to a graph: kept alive for the process (a later re-pack of the same
+                            # weight replaces the cache entry; the graph still holds the old address)
+
+
+def _cached_image(hit):
+    if torch.cuda.is_current_stream_capturing() and not any(hit[1] is t for t in _CAPTURED_IMAGES):
+        _CAPTURED_IMAGES.append(hit[1])
+    return hit[1]
 
 
 _ZERO_SCALARS = {}
@@ -742,7 +759,7 @@ def packed_weight(weight):
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_pack", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
-        return hit[1]
+        return _cached_image(hit)
     lib = _lib.load()
     N, K = weight.shape
     nbytes = lib.bevmsda_linear_packed_bytes(N, K)
@@ -772,7 +789,7 @@ def panel_weight(weight):
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_panel", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
-        return hit[1]
+        return _cached_image(hit)
     lib = _lib.load()
     N, K = weight.shape
     nbytes = lib.bevmsda_linear_panel_packed_bytes(N, K)
@@ -1363,7 +1380,7 @@ def transposed_weight(weight):
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape))
     hit = getattr(weight, "_bevmsda_wt", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
-        return hit[1]
+        return _cached_image(hit)
     with torch.no_grad():
         wt = weight.detach().t().contiguous()
     try:

@@ -276,3 +276,49 @@ def test_value_projection_without_the_stacked_history_tensor(name, storage):
     with torch.no_grad(), ops.using(value_storage=storage):
         default = enc(q, f, f, **kw)
     torch.testing.assert_close(default, stacked, rtol=0, atol=5e-2 if storage == torch.bfloat16 else 2e-4)
+
+
+def test_inference_graph_replays_without_repacking_trainable_weights():
+    """A forward step captured under ``torch.no_grad()`` over TRAINABLE parameters uses the cached weight images (round 5:
+    the 24 ``lin_panel_pack_weight`` launches of every replayed step were 2.8 % of it); a capture with grad mode on
+    still re-packs (an optimizer step between replays must be seen).  Counted at the library boundary."""
+    from bevformer_amd import _lib
+    enc, _ = build_pair("micro4", device=DEV)
+    assert all(p.requires_grad for p in enc.parameters())
+    q, f, kw = S.make_inputs("micro4", seed=0, temporal=True, device=DEV)
+    lib = _lib.load()
+    names = ("bevmsda_linear_panel_pack_weight_f32", "bevmsda_linear_pack_weight_f32", "bevmsda_linear_panel_pack_weight_t_f32",
+             "bevmsda_linear_pack_weight_t_f32")
+    real = {n: getattr(lib, n) for n in names}
+    calls = []
+
+    def spy(n):
+        def f_(*a):
+            calls.append(n)
+            return real[n](*a)
+        return f_
+    with torch.no_grad():
+        want = enc(q, f, f, **kw).clone()           # eager: fills the caches
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            enc(q, f, f, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        for n in names:
+            setattr(lib, n, spy(n))
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = enc(q, f, f, **kw)
+            assert calls == [], calls
+            p = next(enc.parameters())
+            with torch.cuda.graph(torch.cuda.CUDAGraph()):
+                assert ops._cache_ok(p)
+                with torch.enable_grad():
+                    assert not ops._cache_ok(p)
+        finally:
+            for n in names:
+                setattr(lib, n, real[n])
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
