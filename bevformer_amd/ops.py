@@ -277,7 +277,7 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
             if nrows is not None:
                 _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
                      "bevmsda: nrows must be an int32 device tensor")
-                desc.reserved[3] = int(max(0, min(launch_rows, R)))
+                desc.reserved[3] = R if _m().fused_capacity_launch else int(max(0, min(launch_rows, R)))
                 extra = ()
                 if save is not None:
                     sl, sa = save
