@@ -57,11 +57,11 @@ def worker(rank, world, port, name, tries):
                 return _grads(ddp.module, q, f, kw, gout)
             from bevformer_amd import ops
             rec = recs[name] = []
-            ops._DEBUG_TAP = lambda tag, d: rec.append((tag, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}))
+            ops._DEBUG["tap"] = lambda tag, d: rec.append((tag, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}))
             try:
                 return _grads(ddp.module, q, f, kw, gout)
             finally:
-                ops._DEBUG_TAP = None
+                ops._DEBUG["tap"] = None
         oA, gA = tapped("A")
         oB, gB = tapped("B")
         oC, gC = tapped("C")
