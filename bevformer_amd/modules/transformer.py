@@ -371,15 +371,18 @@ class PerceptionTransformerV2(PerceptionTransformerBEVEncoder):
     def fuse_frames(self, bev_embed, prev_bev, bev_h, bev_w):
         """transformerV2.py:296-313: slot of frame 0 takes the current BEV, missing earlier frames copy
         their successor and missing later frames their predecessor (detached), then ``fusion``."""
-        cur_ind = list(self.frames).index(0)
-        assert prev_bev[cur_ind] is None and len(prev_bev) == len(self.frames)
-        prev_bev[cur_ind] = bev_embed
-        for i in range(1, cur_ind + 1):
-            if prev_bev[cur_ind - i] is None:
-                prev_bev[cur_ind - i] = prev_bev[cur_ind - i + 1].detach()
-        for i in range(cur_ind + 1, len(self.frames)):
-            if prev_bev[i] is None:
-                prev_bev[i] = prev_bev[i - 1].detach()
+        n, cur = len(self.frames), list(self.frames).index(0)
+        assert len(prev_bev) == n and prev_bev[cur] is None
+        slots = list(prev_bev)
+        slots[cur] = bev_embed
+
+        def known(i, neighbour):
+            return slots[i] if slots[i] is not None else slots[neighbour].detach()
+        for i in reversed(range(cur)):          # before the current frame: a hole repeats the frame after it
+            slots[i] = known(i, i + 1)
+        for i in range(cur + 1, n):             # after it: a hole repeats the frame before it
+            slots[i] = known(i, i - 1)
+        prev_bev[:] = slots                      # (the reference fills the caller's list in place)
         maps = [x.reshape(x.shape[0], bev_h, bev_w, x.shape[-1]).permute(0, 3, 1, 2).contiguous() for x in prev_bev]
         return self.fusion(maps)
 
