@@ -24,7 +24,7 @@ GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch", "graph_repack")
 
     def __init__(self):
         env = os.environ.get
@@ -48,6 +48,9 @@ class Modes:
         # sampling launches over a device-side row count: 1 = ONE launch sized by the row CAPACITY (surplus workgroups return on
         # their first instruction), 0 = a launch sized by the host's hint + a small strided tail launch for rows beyond it
         self.fused_capacity_launch = env("BEVMSDA_FUSED_CAPACITY", "0") == "1"
+        # A/B knob: re-pack the weight images of trainable parameters inside EVERY captured graph (round 4's behaviour; the
+        # default re-packs only in graphs captured with grad mode on: ops.gemm._cache_ok)
+        self.graph_repack = env("BEVMSDA_GRAPH_REPACK", "0") == "1"
         self.fused_lds_pad_kb = int(env("BEVMSDA_FUSED_LDS_PAD", "0"))                                    # co-scheduling probe: occupancy cap of the sampling kernel
         self.stack_free = env("BEVMSDA_STACK_FREE", "1") == "1"      # inference: TSA's [history ; queries] value projected without forming the stack
         self.weight_views = env("BEVMSDA_WEIGHT_VIEWS", "1") == "1"  # training: W^T images packed from W (no transposed copies)

@@ -60,9 +60,6 @@ def set_gemm_variant(variant=None, pack=None):
         _modes.process_defaults().gemm_pack = variant >= 4
 
 
-_REPACK_IN_EVERY_GRAPH = os.environ.get("BEVMSDA_GRAPH_REPACK", "0") == "1"      # A/B knob: round 4's behaviour
-
-
 def _cache_ok(weight):
     """Derived images of a weight (packed / transposed copies) are cached per version — except while a HIP graph of a
     TRAINING step is being captured over a trainable weight (grad mode on): the replayed graph must rebuild them from
@@ -70,7 +67,7 @@ def _cache_ok(weight):
     conversion kernels are captured too.  A graph captured under ``torch.no_grad()`` is an inference graph: it freezes
     the images it was captured with, exactly as it freezes the merged (concatenated) projection weights — change the
     weights, capture again (round 5: the 24 re-packing launches per replayed forward step were 2.8 % of it)."""
-    return not (weight.requires_grad and (torch.is_grad_enabled() or _REPACK_IN_EVERY_GRAPH) and weight.is_cuda
+    return not (weight.requires_grad and (torch.is_grad_enabled() or _m().graph_repack) and weight.is_cuda
                 and torch.cuda.is_current_stream_capturing())
 
 
