@@ -29,6 +29,10 @@ def worker(rank, world, port, name, tries):
         p.requires_grad_(True)
     q, f, kw = S.make_inputs(name, seed=10 + rank, temporal=True, device=dev)
     gout = torch.randn(1, Q, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + rank)) * 1e-2
+    if os.environ.get("DDP_DIAG_BF16") == "1":      # BASELINE configs[2]'s arithmetic: bf16 value storage, bf16 GEMM operands
+        from bevformer_amd import ops as _ops
+        _ops.set_value_storage(torch.bfloat16)
+        _ops.set_gemm_mode("bf16")
     ddp = DDP(enc, device_ids=[0], broadcast_buffers=False)
     mode = os.environ.get("DDP_DIAG_MODE", "ddp")
     glitches = 0
