@@ -106,6 +106,8 @@ class FramePlan:
     q_rows_all: Optional[torch.Tensor] = None    # (bs*Q, Nc) int32 (q_rows holds the first two columns)
     counters: Optional[torch.Tensor] = None
     ref_2d_full: Optional[torch.Tensor] = None   # tiles: ref_2d of the whole grid (TSA's hybrid reference)
+    blob: Optional[torch.Tensor] = None          # device-side plans: the ONE int32 block the per-frame arrays below are views of
+    blob_spec: Optional[tuple] = None            # ... and its layout ((name, shape, is_float, first word), ...): snapshot() = one copy
 
     @property
     def dynamic(self):
@@ -127,6 +129,13 @@ class FramePlan:
         if not self.dynamic:
             return self
         from dataclasses import replace
+        if self.blob is not None:               # ONE device-to-device copy instead of seven (round 5)
+            blob = self.blob.clone()
+            v = carve_plan_blob(blob, self.blob_spec)
+            c = v["counters"]
+            return replace(self, blob=blob, counters=c, nrows_dev=c[0:1], n_extra_dev=c[2:3], cam_start=c[4:],
+                           row_query32=v["row_query"], row_batch=v["row_batch"], row_ref=v["row_ref"], q_rows=v["q_rows2"],
+                           q_rows_all=v["q_rows"], inv_count=v["inv_count"])
         counters = self.counters.clone()
         return replace(self, counters=counters, nrows_dev=counters[0:1], n_extra_dev=counters[2:3], cam_start=counters[4:],
                        row_query32=self.row_query32.clone(), row_batch=self.row_batch.clone(), row_ref=self.row_ref.clone(),
@@ -167,6 +176,31 @@ class FramePlan:
                        nrows_dev=None, n_extra_dev=None)
         self._materialized = plan
         return plan
+
+
+def plan_blob_spec(pieces):
+    """Layout of the per-frame plan arrays inside one int32 block: ((name, shape, is_float, first word), ...), every piece
+    on a 256-byte boundary -> (spec, words)."""
+    spec, o = [], 0
+    for name, shape, is_float in pieces:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        spec.append((name, tuple(int(d) for d in shape), bool(is_float), o))
+        o += (n + 63) // 64 * 64
+    return tuple(spec), o
+
+
+def carve_plan_blob(blob, spec):
+    """name -> view of ``blob`` (int32, or float32 over the same words) with the piece's shape."""
+    out = {}
+    for name, shape, is_float, o in spec:
+        n = 1
+        for d in shape:
+            n *= d
+        t = blob[o:o + n]
+        out[name] = (t.view(torch.float32) if is_float else t).view(shape)
+    return out
 
 
 def _morton_key(u, v, bits=7):
@@ -390,15 +424,19 @@ class DevicePlanner:
         self.l2i = torch.zeros(bs, num_cams, 4, 4, dtype=f32, device=device)
         self.ref_cam = torch.empty(num_cams, bs, Q, self.D, 2, dtype=f32, device=device)
         self.bev_mask = torch.empty(num_cams, bs, Q, self.D, dtype=torch.bool, device=device)
-        self.inv_count = torch.empty(bs, Q, 1, dtype=f32, device=device)
+        # the arrays a differentiable frame keeps for its backward (FramePlan.snapshot) live in ONE block: one copy per frame
+        n_cnt = int(_lib.load().bevmsda_frame_plan_counters(bs, num_cams))
+        self._blob_spec, words = plan_blob_spec([
+            ("counters", (n_cnt,), False), ("row_query", (self.cap,), False), ("row_batch", (self.cap,), False),
+            ("row_ref", (self.cap, self.D, 2), True), ("q_rows", (bs * Qt, num_cams), False), ("q_rows2", (bs * Qt, 2), False),
+            ("inv_count", (bs, Q, 1), True)])
+        self._blob = torch.zeros(words, dtype=i32, device=device)
+        v = carve_plan_blob(self._blob, self._blob_spec)
+        self.inv_count = v["inv_count"]
         self.slot = torch.empty(num_cams, Q, dtype=u8, device=device)
-        self.row_query = torch.zeros(self.cap, dtype=i32, device=device)
-        self.row_batch = torch.zeros(self.cap, dtype=i32, device=device)
-        self.row_ref = torch.zeros(self.cap, self.D, 2, dtype=f32, device=device)
-        self.q_rows = torch.empty(bs * Qt, num_cams, dtype=i32, device=device)
-        self.q_rows2 = torch.empty(bs * Qt, 2, dtype=i32, device=device)
-        n = int(_lib.load().bevmsda_frame_plan_counters(bs, num_cams))
-        self.counters = torch.zeros(n, dtype=i32, device=device)
+        self.row_query, self.row_batch, self.row_ref = v["row_query"], v["row_batch"], v["row_ref"]
+        self.q_rows, self.q_rows2 = v["q_rows"], v["q_rows2"]
+        self.counters = v["counters"]
         self.block_scratch = torch.zeros(int(_lib.load().bevmsda_frame_plan_scratch(num_cams, Q)), dtype=i32,
                                          device=device)
         self.bev_shapes = torch.tensor([[bev_h, bev_w]], device=device)
@@ -464,7 +502,7 @@ class DevicePlanner:
             row_query32=self.row_query, q_rows=self.q_rows2, q_rows_all=self.q_rows, hits=None,
             cam_start=self.counters[4:], max_cam_rows=0, nrows_dev=self.counters[0:1],
             n_extra_dev=self.counters[2:3], counters=self.counters, ref_2d_full=self.ref_2d,
-            launch_rows=self.launch_rows)
+            launch_rows=self.launch_rows, blob=None if tiled else self._blob, blob_spec=None if tiled else self._blob_spec)
         if not torch.is_tensor(first):
             self._last = (pending_key, plan)
         return plan
