@@ -295,3 +295,24 @@ def test_ops_package_has_no_dangling_globals_and_keeps_its_substitution_points()
     finally:
         ops.linear = real
     assert seen == ["spy"]
+
+
+def test_plan_blob_layout_and_views():
+    """``geometry.plan_blob_spec`` / ``carve_plan_blob``: the per-frame plan arrays as views of ONE int32 block (so that a
+    training step's ``FramePlan.snapshot()`` is one copy): pieces on 256-byte boundaries, disjoint, shaped and typed as asked,
+    a clone of the block carved the same way is an independent copy of every piece."""
+    import torch
+    from bevformer_amd.modules.geometry import carve_plan_blob, plan_blob_spec
+    pieces = [("counters", (10,), False), ("row_query", (1000,), False), ("row_ref", (1000, 4, 2), True), ("inv", (2, 50, 1), True)]
+    spec, words = plan_blob_spec(pieces)
+    assert all(o % 64 == 0 for _, _, _, o in spec) and words % 64 == 0
+    blob = torch.zeros(words, dtype=torch.int32)
+    v = carve_plan_blob(blob, spec)
+    assert v["row_ref"].dtype == torch.float32 and v["row_ref"].shape == (1000, 4, 2) and v["counters"].dtype == torch.int32
+    for i, (name, _, _, _) in enumerate(spec):            # disjoint: a write to one piece shows in no other
+        v[name].fill_(i + 1)
+    for i, (name, _, _, _) in enumerate(spec):
+        assert bool((v[name] == i + 1).all()), name
+    copy = carve_plan_blob(blob.clone(), spec)
+    v["row_ref"].zero_()
+    assert bool((copy["row_ref"] == 3).all()) and copy["row_ref"].data_ptr() != v["row_ref"].data_ptr()
