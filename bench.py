@@ -14,7 +14,10 @@ matrices (a seeded ego-pose jitter of the synthetic rig, as nuScenes rebuilds
 N GPUs by BEV rows (strong scaling) and reassembled with an RCCL all-gather inside the
 timed step.
 
-Prints one JSON line on rank 0.  Besides the contract keys it carries
+Rank 0 prints TWO JSON lines: first ``{"bench_detail": {...}}`` — the full record with every table (also written to
+``gpurun_out/bench_detail.json``) — and LAST the compact record (< 4 KB: contract keys, ``roofline``, ``cpu_baseline``,
+``parity`` and the headline number of every table; ``compact_line``), which is what the driver parses.  No process group
+is created in the default N = 1 run.  Besides the contract keys the full record carries
   ``roofline``      the dominant hand-written HBM-bound kernel (SCA deformable-sampling
                     forward), timed live with HIP events on its launch stream;
   ``cpu_baseline``  the oracle's pure-PyTorch CPU port of the same encoder on the host
@@ -31,6 +34,11 @@ import os
 import statistics
 import sys
 import time
+
+# c10d / RCCL warnings go to stderr as lines starting with "[": keep the captured stream free of anything a JSON
+# scanner could mistake for a record (set BEFORE torch is imported)
+os.environ.setdefault("TORCH_CPP_LOG_LEVEL", "ERROR")
+os.environ.setdefault("NCCL_DEBUG", "WARN")
 
 import numpy as np
 import torch
@@ -73,6 +81,12 @@ def parse():
                     help="frame plans from the torch-op builder with its host syncs instead of the HIP kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra configurations (variants)")
+    ap.add_argument("--ddp-eager", action="store_true",
+                    help="also time the base training step under DistributedDataParallel on a world-1 process group "
+                         "(off by default: the default N = 1 run creates no process group)")
+    ap.add_argument("--detail-json", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the full record (variants, per-kernel / per-GEMM tables, multi-GPU model) is also written; "
+                         "it is printed as an EARLIER stdout line {\"bench_detail\": ...}; the LAST line is the compact record")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph in the timed region "
                          "(auto = on, falling back to eager launches if the capture fails; the "
@@ -686,6 +700,110 @@ def l1_path(w, rows, avg_us, storage):
     return dict(gather_bytes=gather, achieved_TBs=gather / (avg_us * 1e-6) / 1e12, peak_TBs=peak / 1e12,
                 frac=gather / (avg_us * 1e-6) / peak)
 
+COMPACT_LIMIT = 4000        # bytes: the driver keeps an 8,191-byte tail of the stream; the record must sit well inside it
+
+
+def _r(x, sig=6):
+    """Floats to ``sig`` significant digits (the compact record), containers recursively."""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(line):
+    """The driver's record: the contract keys + ``roofline`` + ``cpu_baseline`` + ``parity`` + a few scalars, every
+    table (variants, kernels, gemms, multi-GPU model) reduced to its headline numbers.  Always < COMPACT_LIMIT bytes:
+    optional keys are dropped from the end of ``optional`` until it fits."""
+    c = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    cfg = line.get("config") or {}
+    c["config"] = {k: cfg.get(k) for k in ("workload", "global_batch", "parallelism", "value_storage", "sca_row_order",
+                                           "sca_rows_per_frame")}
+    c["config"]["geometry"] = "frame plan rebuilt every step" if str(cfg.get("geometry", "")).startswith("new") else "static rig"
+    r = line.get("roofline") or {}
+    c["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us",
+                                           "alg_bytes", "launches_timed")}
+    if "cpu_baseline" in line:
+        cb = line["cpu_baseline"]
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "seconds", "host_cpus")}
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        c["vs_cpu_baseline"] = line.get("vs_cpu_baseline")
+    if "parity" in line:
+        p = line["parity"]
+        c["parity"] = {k: p.get(k) for k in ("ok", "max_abs", "worst_ratio", "rtol", "atol", "graph_replay_equals_eager")}
+    c["launch_mode"] = line.get("launch_mode")
+    c["ranks"] = line.get("ranks")
+    w = line.get("windows") or {}
+    c["windows"] = {k: w.get(k) for k in ("min", "median", "n")}
+    optional = []
+    if line.get("variants"):
+        v = {}
+        for name, x in line["variants"].items():
+            e = {"ms": x.get("ms_per_step")}
+            if "parity" in x:
+                e["ok"] = x["parity"].get("ok")
+            if "roofline_bwd" in x:
+                e["bwd_frac"] = x["roofline_bwd"].get("frac")
+            if "error" in x:
+                e["error"] = str(x["error"])[:60]
+            v[name] = e
+        optional.append(("variants", v))
+    for key in ("frames_in_parallel", "collective"):
+        if line.get(key):
+            x = line[key]
+            optional.append((key, {k: x[k] for k in ("ms_per_step", "value", "scaling", "us_per_call_max_over_ranks",
+                                                     "shard_bytes", "backend", "error") if k in x}))
+    if line.get("strong_scaling"):
+        x = line["strong_scaling"]
+        optional.append(("strong_scaling", {k: x[k] for k in ("north_star_target", "t1_ms_one_untiled_frame_per_gpu",
+                                                              "efficiency_t1_over_N_TN", "amdahl_bound_efficiency") if k in x}))
+    if line.get("rank_skew"):
+        optional.append(("rank_skew_ms", line["rank_skew"].get("max_minus_min_ms")))
+    for key in ("multi_gpu_model", "multi_gpu_model_bf16"):
+        m = line.get(key)
+        if m:
+            optional.append((key, {"status": "per-rank times on ONE GPU + modelled all-gather; not a multi-GPU measurement",
+                                   **{g: {"layout": m[g].get("layout"), "per_rank_max_ms": max(m[g]["per_rank_ms"]),
+                                          "step_ms": m[g]["step_ms"], "efficiency": m[g]["efficiency"]}
+                                      for g in ("2", "4", "8") if g in m}}))
+    g = line.get("gemms")
+    if g:
+        optional.append(("gemms", {"total_us_per_step": g.get("total_us_per_step"), "TFLOPs": g.get("TFLOPs"),
+                                   "per_tag_avg_us": {t: x["avg_us"] for t, x in g.get("per_tag", {}).items()}}))
+    k = line.get("kernels")
+    if k:
+        optional.append(("kernels_avg_us", {t: x["avg_us"] for t, x in k.items()}))
+    if line.get("smoke"):
+        optional.insert(0, ("smoke", line["smoke"][:120]))
+    c["detail"] = "full record: the stdout line {\"bench_detail\": ...} printed before this one"
+    for key, val in optional:
+        c[key] = val
+    c = _r(c, 5)
+    drop = [key for key, _ in optional]
+    while len(json.dumps(c, separators=(",", ":"))) > COMPACT_LIMIT and drop:
+        c.pop(drop.pop(), None)
+    return c
+
+
+def emit(line, detail_path=None):
+    """Full record first (one stdout line, also a file when the directory is writable), the compact record LAST."""
+    detail = json.dumps({"bench_detail": line})
+    print(detail, flush=True)
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as fh:
+                fh.write(json.dumps(line, indent=1))
+        except OSError:
+            pass
+    out = json.dumps(compact_line(line), separators=(",", ":"))
+    assert len(out) <= COMPACT_LIMIT and "\n" not in out
+    print(out, flush=True)
+
 
 def main():
     args = parse()
@@ -940,10 +1058,11 @@ def main():
                 v["fwd_small"] = run_variant(args, dev, fence, "small", gemm, "fp32", False, 10, 3, want_s, ENC_TOL)
                 v["fwd_tiny"] = run_variant(args, dev, fence, "tiny", gemm, "fp32", False, 20, 3,
                                             oracle_frame("tiny", args.first_frame), ENC_TOL)
-                try:
-                    v["fwd_bwd_base_ddp_eager"] = run_ddp_eager(args, dev, fence, gemm)
-                except Exception as e:      # noqa: BLE001 — never lose the line to the extra variant
-                    v["fwd_bwd_base_ddp_eager"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+                if args.ddp_eager:
+                    try:
+                        v["fwd_bwd_base_ddp_eager"] = run_ddp_eager(args, dev, fence, gemm)
+                    except Exception as e:      # noqa: BLE001 — never lose the line to the extra variant
+                        v["fwd_bwd_base_ddp_eager"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
                 v["queue4_bf16"] = run_variant(args, dev, fence, "base", "bf16", "bf16", False, 3, 3, tol=5e-2, queue=4)
                 # the same 4-frame queue in the headline arithmetic (fp32 storage, split-bf16 GEMMs) against the same
                 # oracle run, at twice the single-frame tolerance (four chained frames)
@@ -1044,7 +1163,7 @@ def main():
         except Exception:       # noqa: BLE001
             pass
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        emit(line, args.detail_json)
     if not ok:
         raise SystemExit("bench: parity check against the oracle FAILED (see the `parity` objects)")
 

@@ -431,6 +431,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
     def _run_layers(self, bev_query, key, value, args, kwargs, plan, bev_pos, hybird_ref_2d, bev_h, bev_w, spatial_shapes,
                     level_start_index, prev_bev, history, share, fast_train, sca_vals, tsa_vals):
         """The layer loop of ``forward`` (encoder.py:211-233)."""
+        output = bev_query          # (zero layers: the queries come back unchanged, encoder.py:211)
         intermediate = []
         for li, layer in enumerate(self.layers):
             hoisted = {}

@@ -6,7 +6,9 @@ line = [l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")]
 if not line:
     print("no JSON line in", sys.argv[1])
     sys.exit(0)
-d = json.loads(line[-1])
+# round 6: the full record is the {"bench_detail": ...} line printed BEFORE the compact final record
+full = [json.loads(l) for l in line if l.startswith('{"bench_detail"')]
+d = full[-1]["bench_detail"] if full else json.loads(line[-1])
 print(f"value {d['value']:.4g} {d['unit']}  ms/step {d['ms_per_step']:.3f}  mode {d.get('launch_mode')}  dtype {d.get('dtype')}")
 print("windows", d.get("windows", {}).get("ms_per_step"), "geometry_ms", d.get("geometry_ms"))
 r = d.get("roofline", {})
