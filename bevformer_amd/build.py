@@ -24,7 +24,7 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 
 
 # per-source additions to FLAGS
-EXTRA_FLAGS = {"bevmsda_capi_backward.hip": ["-fno-slp-vectorize"]}     # (why: the header of that file)
+EXTRA_FLAGS = {}
 # sources that #include another source
 INCLUDES = {"bevmsda_capi_backward.hip": ["bevmsda_capi.hip"]}
 

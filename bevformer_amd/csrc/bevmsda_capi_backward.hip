@@ -1,16 +1,9 @@
 // The bevmsda_backward_* entry points of bevmsda_capi.hip (sampling backward: grad_loc / grad_attn gather, grad_value sort,
-// first-generation kernels), compiled WITHOUT the SLP vectorizer (-fno-slp-vectorize: bevformer_amd/build.py EXTRA_FLAGS),
-// i.e. without packed fp32 math (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
+// first-generation kernels) as a translation unit of their own: `if constexpr (BWD)` in the launchers keeps each unit's
+// kernels out of the other, so the two code objects can be inspected — and were, in rounds 5 and 6 — separately.
 //
-// Why (round 5, profiles/r5/r5_ddp_forensics.txt): with the packed instructions the SLP vectorizer forms out of the
-// (grad_loc_x, grad_loc_y) pairs of msda_gradloc_d32_kernel, about one training pass in fifty computed ONE wrong
-// grad_loc_y — bit-identical inputs, grad_attn and grad_loc_x of the same point bit-identical, the y value of the same
-// point of two neighbouring rows (the two lane groups of one 16-lane pass) off by 2 .. 400 % — and only with a second
-// process keeping the GPU busy: 40 events in ~2,700 passes with the packed code (ds_swizzle or DPP reduction, kernels
-// serialised or not), 0 in 768 without it.  The signature (the high half of a packed pair, one 16-lane pass, back-to-back
-// issue of one wavefront) is that of a VALU forwarding hazard of the packed fp32 path that the compiler's hazard
-// recogniser does not cover on gfx950; the forward kernels (packed FMAs without source op_sel) never showed it (forward
-// outputs bit-equal over all those passes), so only this translation unit gives the packed instructions up
-// (tests/test_build_flags.py checks its ISA).  Cost: none measurable on the training step.
+// Round 5 compiled this unit with -fno-slp-vectorize because of one sporadic wrong grad_loc_y; round 6 isolated the cause to
+// ONE instruction form (packed fp32 add with an op_sel bit set: profiles/r6/r6_pk_forensics.txt) and removed it in the source
+// (scalar_ops.h), so the unit is built like every other one again and tests/test_build_flags.py checks all five code objects.
 #define BEVMSDA_PART_BACKWARD 1
 #include "bevmsda_capi.hip"

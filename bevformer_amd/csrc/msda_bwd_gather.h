@@ -16,6 +16,7 @@
 // 8 x 3 x 3): lane j ends up with the channel sums of point j and writes one coalesced record.
 #pragma once
 #include "msda_d32.h"
+#include "scalar_ops.h"
 
 namespace bevmsda {
 
@@ -44,6 +45,7 @@ __device__ __forceinline__ GradPointParams grad_point_params(float lx, float ly,
   return p;
 }
 
+// (the differences of a point go through sub_scalar: scalar_ops.h says why)
 __device__ __forceinline__ float dot4(const f32x4 &a, const f32x4 &b) {
   return fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])));
 }
@@ -73,10 +75,10 @@ __device__ __forceinline__ void grad_points(const GradPointParams &p, __amdgpu_b
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const float s00 = dot4(g, v[j][0]), s01 = dot4(g, v[j][1]), s10 = dot4(g, v[j][2]), s11 = dot4(g, v[j][3]);
-    const float gx = 1.f - fx[j], gy = 1.f - fy[j];
+    const float gx = sub_scalar(1.f, fx[j]), gy = sub_scalar(1.f, fy[j]);
     pa[J0 + j] = gy * (gx * s00 + fx[j] * s01) + fy[j] * (gx * s10 + fx[j] * s11);
-    px[J0 + j] = gy * (s01 - s00) + fy[j] * (s11 - s10);
-    py[J0 + j] = gx * (s10 - s00) + fx[j] * (s11 - s01);
+    px[J0 + j] = gy * sub_scalar(s01, s00) + fy[j] * sub_scalar(s11, s10);
+    py[J0 + j] = gx * sub_scalar(s10, s00) + fx[j] * sub_scalar(s11, s01);
   }
 }
 
@@ -213,12 +215,12 @@ __device__ __forceinline__ void grad_points_b8(const GradPointParams &p, __amdgp
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const float t = dot8_bf16(g, v[j][0]), b = dot8_bf16(g, v[j][1]);
-    const float gy = 1.f - fy[j];
-    const float wx = upper ? fx[j] : 1.f - fx[j];          // my x weight
+    const float gy = sub_scalar(1.f, fy[j]);
+    const float wx = upper ? fx[j] : sub_scalar(1.f, fx[j]);   // my x weight
     const float col = gy * t + fy[j] * b;                   // my column of the footprint, y-interpolated
     pa[J0 + j] = wx * col;
     px[J0 + j] = upper ? col : -col;
-    py[J0 + j] = wx * (b - t);
+    py[J0 + j] = wx * sub_scalar(b, t);
   }
 }
 

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "scalar_ops.h"
+
 namespace bevmsda {
 
 struct KArgs {
@@ -189,7 +191,7 @@ struct Tap {
 // Returns false when the point contributes nothing (outside (-1,W)x(-1,H)).
 __device__ __forceinline__ bool make_tap(float lx, float ly, int H, int W, int pix_stride, Tap &t) {
   const float Wf = static_cast<float>(W), Hf = static_cast<float>(H);
-  const float x = lx * Wf - 0.5f, y = ly * Hf - 0.5f;
+  const float x = lx * Wf - 0.5f, y = fma_scalar(ly, Hf, -0.5f);   // (scalar_ops.h: no (x, y) pair with swapped halves)
   if (!(x > -1.f && y > -1.f && x < Wf && y < Hf)) return false;
   const float xf = floorf(x), yf = floorf(y);
   const int x0 = static_cast<int>(xf), y0 = static_cast<int>(yf);
@@ -343,11 +345,11 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const KArgs a) {
           for (int c = 0; c < CPL; ++c) {
             const float gc = g[c];
             ga = fmaf(gc, t.w00 * v00[c] + t.w01 * v01[c] + t.w10 * v10[c] + t.w11 * v11[c], ga);
-            gx = fmaf(gc, hy * (v01[c] - v00[c]) + t.fy * (v11[c] - v10[c]), gx);
-            gy = fmaf(gc, hx * (v10[c] - v00[c]) + t.fx * (v11[c] - v01[c]), gy);
+            gx = fmaf(gc, hy * sub_scalar(v01[c], v00[c]) + t.fy * sub_scalar(v11[c], v10[c]), gx);
+            gy = fmaf(gc, hx * sub_scalar(v10[c], v00[c]) + t.fx * sub_scalar(v11[c], v01[c]), gy);
           }
           gx *= aw * static_cast<float>(W);
-          gy *= aw * static_cast<float>(H);
+          gy = mul_scalar(gy, aw * static_cast<float>(H));     // (scalar_ops.h)
           if (t.ok00) {
             const float w = t.w00 * aw;
 #pragma unroll
@@ -483,11 +485,11 @@ __global__ void __launch_bounds__(256) msda_bwd_d32_kernel(const KArgs a) {
           for (int c = 0; c < CPL; ++c) {
             const float gc = g[c];
             ga = fmaf(gc, t.w00 * v00[c] + t.w01 * v01[c] + t.w10 * v10[c] + t.w11 * v11[c], ga);
-            gx = fmaf(gc, hy * (v01[c] - v00[c]) + t.fy * (v11[c] - v10[c]), gx);
-            gy = fmaf(gc, hx * (v10[c] - v00[c]) + t.fx * (v11[c] - v01[c]), gy);
+            gx = fmaf(gc, hy * sub_scalar(v01[c], v00[c]) + t.fy * sub_scalar(v11[c], v10[c]), gx);
+            gy = fmaf(gc, hx * sub_scalar(v10[c], v00[c]) + t.fx * sub_scalar(v11[c], v01[c]), gy);
           }
           gx *= aw * static_cast<float>(W);
-          gy *= aw * static_cast<float>(H);
+          gy = mul_scalar(gy, aw * static_cast<float>(H));     // (scalar_ops.h)
           if (t.ok00) c00 = t.w00 * aw;
           if (t.ok01) c01 = t.w01 * aw;
           if (t.ok10) c10 = t.w10 * aw;
@@ -586,8 +588,8 @@ __global__ void __launch_bounds__(256) msda_bwd_scalar_kernel(const KArgs a) {
       if (t.ok11) { Io<T, 1>::load(vb + lo + t.o00 + t.dy + t.dx, v11); unsafeAtomicAdd(gvb + lo + t.o00 + t.dy + t.dx, t.w11 * aw * g[0]); }
       const float hx = 1.f - t.fx, hy = 1.f - t.fy;
       unsafeAtomicAdd(a.grad_attn + pi, g[0] * (t.w00 * v00[0] + t.w01 * v01[0] + t.w10 * v10[0] + t.w11 * v11[0]));
-      unsafeAtomicAdd(a.grad_loc + 2 * pi, g[0] * aw * W * (hy * (v01[0] - v00[0]) + t.fy * (v11[0] - v10[0])));
-      unsafeAtomicAdd(a.grad_loc + 2 * pi + 1, g[0] * aw * H * (hx * (v10[0] - v00[0]) + t.fx * (v11[0] - v01[0])));
+      unsafeAtomicAdd(a.grad_loc + 2 * pi, g[0] * aw * W * (hy * sub_scalar(v01[0], v00[0]) + t.fy * sub_scalar(v11[0], v10[0])));
+      unsafeAtomicAdd(a.grad_loc + 2 * pi + 1, g[0] * aw * H * (hx * sub_scalar(v10[0], v00[0]) + t.fx * sub_scalar(v11[0], v01[0])));
     }
   }
 }

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "scalar_ops.h"
 
 namespace bevmsda {
 
@@ -45,14 +46,14 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const float *__restr
       const float4 t = rp[lane + 64 * i];
       v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
     }
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    s += add_scalar(v[i].x, v[i].y) + add_scalar(v[i].z, v[i].w);     // (scalar_ops.h: no packed add of swapped halves)
   }
   const float mean = wave_sum(s) * (1.0f / C);
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-    ss += (a * a + b * b) + (c * c + d * d);
+    ss += add_scalar(a * a + b * b, c * c + d * d);
   }
   const float rstd = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
   const float4 *gp = reinterpret_cast<const float4 *>(gamma);
