@@ -491,8 +491,8 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
                queries_per_s=cfg.Q * max(1, queue) / (statistics.median(per) * 1e-3), launch_mode=note)
     if train_mode:
         res["mode"] = ("train(): dropout p = 0.1 active in TemporalSelfAttention, SpatialCrossAttention and the FFN (masks drawn "
-                       "by torch's generator inside the captured step); output parity of this mode with shared deterministic "
-                       "masks: tests/test_encoder_gpu.py::test_train_mode_with_active_dropout_on_the_gpu")
+                       "by torch's generator inside the captured step); `parity`: one eager step against the oracle's "
+                       "train() mode fed the same scale tensors")
     if queue:
         res["launch_mode"] = step.launch_mode
         res["frames_per_step"] = queue
@@ -517,6 +517,8 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
             fence()
             res["parity"]["graph_replay_equals_eager"] = bool(torch.equal(g_out, eager))
             res["parity"]["ok"] = res["parity"]["ok"] and res["parity"]["graph_replay_equals_eager"]
+    if train_mode:
+        res["parity"] = train_mode_parity(cfg, workload, tol if tol is not None else ENC_TOL)
     if backward:
         from bevformer_amd import ops
         kt = KernelTimer()
@@ -540,6 +542,41 @@ def run_variant(args, dev, fence, workload, gemm, storage, backward, steps, wind
     del cfg, graph
     torch.cuda.empty_cache()
     return res
+
+
+def train_mode_parity(cfg, workload, tol):
+    """Parity object of a train() mode step (round 6): ONE eager step on rig 0 with ``train_ops.dropout_scale`` — the one
+    place the fast path draws its dropout scale tensors (TSA output, SCA output, FFN hidden, FFN output per layer, in that
+    order) — recording what it hands out, then the oracle's train() mode on the host with exactly those tensors
+    (``O.encoder_forward(dropout_scales=...)``, pinned bit-exact against the reference's own files in train():
+    tests/test_oracle_vs_reference.py::test_restatement_in_train_mode_is_bit_exact)."""
+    from bevformer_amd import synthetic as S
+    from bevformer_amd import train_ops
+    from oracle import bevformer_cpu as O
+    drawn, real = [], train_ops.dropout_scale
+
+    def recording(shape, p, device):
+        t = real(shape, p, device)
+        drawn.append(t)
+        return t
+    train_ops.dropout_scale = recording
+    try:
+        cfg.set_rig(0)
+        got = cfg.encoder_step()
+    finally:
+        train_ops.dropout_scale = real
+    L = cfg.w["layers"]
+    if len(drawn) != 4 * L:
+        return dict(ok=False, error=f"{len(drawn)} dropout draws in the step, expected {4 * L} (4 sites x {L} layers): "
+                                    "the step did not take the chain kernels")
+    sd = {k: v.detach().float().cpu() for k, v in cfg.sd.items()}
+    q, f, kw = S.make_inputs(workload, seed=0, temporal=not cfg.args.first_frame)
+    with torch.no_grad():
+        want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, dropout_scales=[t.cpu() for t in drawn], **kw)
+    rep = parity_report(got, want, tol)
+    rep["against"] = ("oracle/bevformer_cpu.py in train() mode with the step's own dropout scale tensors "
+                      f"({len(drawn)} draws, {sum(float((t == 0).float().mean()) for t in drawn) / len(drawn):.3f} of the elements dropped)")
+    return rep
 
 
 def run_ddp_eager(args, dev, fence, gemm, steps=3, windows=3):
@@ -1046,8 +1083,9 @@ def main():
                 v["bf16"] = run_variant(args, dev, fence, "base", "bf16", "bf16", False, 10, 3, want, 5e-2)
                 want4 = oracle_frame("small4", args.first_frame)
                 v["fwd_bwd_base"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3, want, ENC_TOL)
-                # the same step in train() mode (random dropout masks: no oracle output to compare with)
-                v["fwd_bwd_base_train_mode"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3, train_mode=True)
+                # the same step in train() mode: parity against the oracle's train() mode fed the step's own dropout scale tensors
+                v["fwd_bwd_base_train_mode"] = run_variant(args, dev, fence, "base", gemm, "fp32", True, 3, 3, tol=ENC_TOL,
+                                                           train_mode=True)
                 v["fwd_bwd_small4"] = run_variant(args, dev, fence, "small4", gemm, "fp32", True, 5, 3, want4, ENC_TOL)
                 v["fwd_bwd_small4_bf16"] = run_variant(args, dev, fence, "small4", "bf16", "bf16", True, 5, 3, want4, 5e-2)
                 # the reference-true bevformer_small shape set (ONE level (23, 40), 3 layers, 150 x 150 queries:

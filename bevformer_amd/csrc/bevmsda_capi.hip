@@ -378,6 +378,12 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
       (reinterpret_cast<uintptr_t>(ref) & 7u) || (reinterpret_cast<uintptr_t>(logits) & 3u))
     return BEVMSDA_ERR_MISALIGNED;
   if (d->R * static_cast<long long>(d->M) >= (1LL << 36)) return BEVMSDA_ERR_TOO_LARGE;
+  // desc->reserved[5] (kernel-body selection, A/B knob: values below) is validated HERE, for every path: it only acts on
+  // the static-row fp32 launches, and the other paths (device-side row count: values 0, 1, 3; bf16 storage: 0, 1) must
+  // not accept a value they would silently ignore — an A/B run would then report the knob as set and measure the default
+  if (d->reserved[5] < 0 || d->reserved[5] > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (sizeof(T) == 2 && d->reserved[5] > 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (nrows && d->reserved[5] == 2) return BEVMSDA_ERR_BAD_OPTION;
   bevmsda::FusedArgs f{};
   KArgs &a = f.k;
   a.value = value; a.shapes = shapes; a.lstart = lstart; a.out = out; a.row_batch = row_batch;

@@ -332,8 +332,9 @@ static int panel_launch(const float *x0, const float *a0, const float *x1, const
     return BEVMSDA_ERR_MISALIGNED;
   const int64_t wbytes = bevmsda_linear_panel_packed_bytes(d->N, K);
   if (wbytes >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-  // (the epilogue's raw buffer over one output group has 32-bit record counts and offsets)
-  if (!ln && static_cast<long long>(d->M) * d->ldy * 4 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  // (the epilogue's raw buffer covers ONE row panel of one output group — 64-bit base, 32-bit record count and offsets
+  // inside it: at most 128 rows x ldy elements of 2 or 4 bytes have to fit)
+  if (!ln && 128LL * d->ldy * (d->out_bf16 ? 2 : 4) >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::PanelArgs a;
   a.x0 = x0; a.a0 = a0; a.x1 = d->K1 > 0 ? x1 : nullptr; a.a1 = d->K1 > 0 ? a1 : nullptr;
   a.ldx0 = d->ldx0; a.lda0 = d->lda0; a.ldx1 = d->ldx1; a.lda1 = d->lda1;

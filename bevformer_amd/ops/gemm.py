@@ -71,14 +71,59 @@ def _cache_ok(weight):
                 and torch.cuda.is_current_stream_capturing())
 
 
-_CAPTURED_IMAGES = []       # images a capture handed to a graph: kept alive for the process (a later re-pack of the same
-                            # weight replaces the cache entry; the graph still holds the old address)
+# Weight images a stream capture handed to a graph, by id(image): {image (kept alive: the graph holds its address), a weak
+# reference to the weight it was made from, the weight's version and address at capture}.  A graph captured under
+# torch.no_grad() FREEZES these images (and the merged projection weights): an in-place weight update between replays
+# (load_state_dict, EMA, an optimizer step between periodic graphed evaluations) replays the old weights —
+# ``graph_weights_stale()`` / ``assert_graph_weights_fresh()`` say so, ``release_captured_images()`` drops the registry
+# once the graphs are gone.
+_CAPTURED_IMAGES = {}
 
 
-def _cached_image(hit):
-    if torch.cuda.is_current_stream_capturing() and not any(hit[1] is t for t in _CAPTURED_IMAGES):
-        _CAPTURED_IMAGES.append(hit[1])
+def _cached_image(hit, weight=None):
+    if torch.cuda.is_current_stream_capturing() and id(hit[1]) not in _CAPTURED_IMAGES:
+        import weakref
+        try:
+            ref = weakref.ref(weight) if weight is not None else None
+        except TypeError:
+            ref = None
+        _CAPTURED_IMAGES[id(hit[1])] = dict(image=hit[1], weight=ref, version=_ver(weight) if weight is not None else None,
+                                            data_ptr=weight.data_ptr() if weight is not None else None,
+                                            shape=tuple(weight.shape) if weight is not None else None)
     return hit[1]
+
+
+def graph_weights_stale():
+    """Weights whose packed / panel / transposed images were frozen into a captured HIP graph and that have been written
+    to (or moved, or freed) since: list of ``(shape, reason)``.  Empty = every captured graph still replays current weights."""
+    out = []
+    for rec in _CAPTURED_IMAGES.values():
+        if rec["weight"] is None:
+            continue
+        w = rec["weight"]()
+        if w is None:
+            out.append((rec["shape"], "the weight tensor was freed"))
+        elif w.data_ptr() != rec["data_ptr"]:
+            out.append((rec["shape"], "the weight tensor was moved / reallocated"))
+        elif _ver(w) != rec["version"]:
+            out.append((rec["shape"], "the weight was written to after the capture"))
+    return out
+
+
+def assert_graph_weights_fresh():
+    """Raise when a captured inference graph would replay weights that have changed since its capture (call before
+    ``graph.replay()`` wherever weights can change between replays; re-capture to pick the new values up)."""
+    stale = graph_weights_stale()
+    if stale:
+        raise RuntimeError("bevmsda: %d weight image(s) frozen into a captured HIP graph are stale (%s ...): the weights "
+                           "changed after the capture — capture the graph again" % (len(stale), stale[:3]))
+
+
+def release_captured_images():
+    """Forget the images captured graphs hold (call after destroying those graphs: the registry keeps the images alive)."""
+    n = len(_CAPTURED_IMAGES)
+    _CAPTURED_IMAGES.clear()
+    return n
 
 
 def clear_weight_caches(module):
@@ -111,7 +156,7 @@ def packed_weight(weight):
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_pack", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
-        return _cached_image(hit)
+        return _cached_image(hit, weight)
     lib = _lib.load()
     N, K = weight.shape
     nbytes = lib.bevmsda_linear_packed_bytes(N, K)
@@ -141,7 +186,7 @@ def panel_weight(weight):
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_panel", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
-        return _cached_image(hit)
+        return _cached_image(hit, weight)
     lib = _lib.load()
     N, K = weight.shape
     nbytes = lib.bevmsda_linear_panel_packed_bytes(N, K)

@@ -233,6 +233,12 @@ def _zeros(device, *shapes):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _is_placeholder(g):
+    """The autograd return of a consumer that deposited its gradient in a sink: ``_zero_scalar(...).expand(shape)`` — every
+    stride 0 (a sum autograd forms with another consumer's gradient is a dense tensor)."""
+    return g is None or (g.numel() > 1 and all(st == 0 for st in g.stride()))
+
+
 class _GroupedLinearFunction(Function):
     """y_l = x w_l^T + b_l for the L row blocks of ``wcat`` — the hoisted value projections — from ONE pass over x
     (``ops.linear(groups=L)``); x = the row-wise concatenation of ``xs``."""
@@ -295,6 +301,10 @@ class _GroupedLinearFunction(Function):
                 dep, sink[i] = sink[i], None
                 col = arena[:, i * ncol:(i + 1) * ncol]
                 if dep is not None and dep.data_ptr() == col.data_ptr():
+                    if not _is_placeholder(g):
+                        # a SECOND consumer of this output (an auxiliary loss on the hoisted values): autograd summed its
+                        # gradient with the depositing consumer's zero placeholder — it belongs to the column too
+                        col.add_(g.reshape(M, ncol))
                     continue
                 src = dep if dep is not None else g         # (a consumer that took another path: its own array)
                 if src is not None:
@@ -306,7 +316,12 @@ class _GroupedLinearFunction(Function):
             gys = ()
         for i, g in enumerate(gys):
             if sink is not None and sink[i] is not None:
-                g, sink[i] = sink[i], None          # the consumer's fp32 gradient (its autograd return is a placeholder)
+                # the consumer's fp32 gradient (its autograd return is a placeholder; anything autograd added to the
+                # placeholder is a second consumer's gradient)
+                extra = None if _is_placeholder(g) else g
+                g, sink[i] = sink[i], None
+                if extra is not None:
+                    g = g.reshape(M, ncol).float() + extra.reshape(M, ncol).float()
             if g is None:
                 continue
             g2 = g.reshape(M, ncol).float()
@@ -337,7 +352,9 @@ class ValueGradSink(list):
     return of such a consumer is a zero-stride placeholder).  ``arena=True``: the slots are the column blocks of ONE
     zero-filled (rows, L * width) array allocated on first use in a backward pass — ``buffer(slot, shape, device)`` hands
     out block ``slot`` as a strided (N, S, M, D) view (pixel stride L * M * D) that the grad_value kernels accumulate
-    into (``grad_value_stride`` of ``bevmsda_backward_rows_*`` / ``_shared_*``)."""
+    into (``grad_value_stride`` of ``bevmsda_backward_rows_*`` / ``_shared_*``).  A SECOND consumer of an output (an
+    auxiliary loss on the hoisted values) is supported: its gradient reaches the projection's backward through autograd, summed
+    with the placeholder, and is added to the deposited one there (``_is_placeholder``)."""
 
     def __init__(self, L, arena=True):
         super().__init__([None] * L)

@@ -164,9 +164,15 @@ def _lin(sd, key, x):
     return F.linear(x, sd[key + ".weight"], sd[key + ".bias"])
 
 
+def _drop(drop, x):
+    """An nn.Dropout site of the reference in train() mode: ``drop`` yields the scale tensor (0 or 1 / (1 - p) per element)
+    of each site in the order the reference executes them; None = eval mode (identity)."""
+    return x if drop is None else x * next(drop).to(x.dtype).reshape(x.shape)
+
+
 def temporal_self_attention(sd, pre, query, value, bev_pos, ref_2d, bev_h, bev_w,
-                            num_heads=8, num_points=4, msda=msda_gridsample):
-    """temporal_self_attention.py:177-272 (eval mode: dropout is identity)."""
+                            num_heads=8, num_points=4, msda=msda_gridsample, drop=None):
+    """temporal_self_attention.py:177-272 (``drop``: the scale tensors of ``self.dropout`` at :272 in train() mode)."""
     bs, Q, C = query.shape
     if value is None:
         value = torch.stack([query, query], 1).reshape(bs * 2, Q, C)
@@ -185,7 +191,7 @@ def temporal_self_attention(sd, pre, query, value, bev_pos, ref_2d, bev_h, bev_w
     loc = ref_2d[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
     out = msda(v, shapes, loc, att)                                     # (bs*2,Q,C)
     out = out.permute(1, 2, 0).view(Q, C, bs, 2).mean(-1).permute(2, 0, 1)
-    return _lin(sd, pre + "output_proj", out) + identity
+    return _drop(drop, _lin(sd, pre + "output_proj", out)) + identity
 
 
 def deformable_attention_3d(sd, pre, query, value, ref_cam, shapes, num_heads=8,
@@ -206,9 +212,9 @@ def deformable_attention_3d(sd, pre, query, value, ref_cam, shapes, num_heads=8,
 
 
 def spatial_cross_attention(sd, pre, query, feats, ref_cam, bev_mask, shapes,
-                            msda=msda_gridsample):
-    """spatial_cross_attention.py:123-175 (eval mode), padded per-camera rebatch
-    exactly as the reference does it, visibility taken from batch element 0."""
+                            msda=msda_gridsample, drop=None):
+    """spatial_cross_attention.py:123-175 (``drop``: ``self.dropout`` at :175 in train() mode), padded per-camera
+    rebatch exactly as the reference does it, visibility taken from batch element 0."""
     bs, Q, C = query.shape
     Nc = feats.shape[0]
     Dz = ref_cam.size(3)
@@ -232,13 +238,13 @@ def spatial_cross_attention(sd, pre, query, feats, ref_cam, bev_mask, shapes,
             slots[j, idx[i]] += out[j, i, :len(idx[i])]
     count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
     slots = slots / torch.clamp(count, min=1.0)[..., None]
-    return _lin(sd, pre + "output_proj", slots) + residual
+    return _drop(drop, _lin(sd, pre + "output_proj", slots)) + residual
 
 
-def ffn(sd, pre, x):
-    """mmcv FFN (add_identity=True), keys layers.0.0 / layers.1."""
-    h = F.relu(_lin(sd, pre + "layers.0.0", x))
-    return x + _lin(sd, pre + "layers.1", h)
+def ffn(sd, pre, x, drop=None):
+    """mmcv FFN (add_identity=True), keys layers.0.0 / layers.1: Linear, ReLU, Dropout, Linear, Dropout."""
+    h = _drop(drop, F.relu(_lin(sd, pre + "layers.0.0", x)))
+    return x + _drop(drop, _lin(sd, pre + "layers.1", h))
 
 
 def layer_norm(sd, pre, x):
@@ -246,25 +252,27 @@ def layer_norm(sd, pre, x):
 
 
 def encoder_layer(sd, pre, query, feats, bev_pos, ref_2d, ref_cam, bev_mask, bev_h, bev_w,
-                  shapes, prev_bev, msda=msda_gridsample):
+                  shapes, prev_bev, msda=msda_gridsample, drop=None):
     """encoder.py:356-406 with operation_order
     ('self_attn','norm','cross_attn','norm','ffn','norm')."""
     x = temporal_self_attention(sd, pre + "attentions.0.", query, prev_bev, bev_pos, ref_2d,
-                                bev_h, bev_w, msda=msda)
+                                bev_h, bev_w, msda=msda, drop=drop)
     x = layer_norm(sd, pre + "norms.0", x)
     x = spatial_cross_attention(sd, pre + "attentions.1.", x, feats, ref_cam, bev_mask, shapes,
-                                msda=msda)
+                                msda=msda, drop=drop)
     x = layer_norm(sd, pre + "norms.1", x)
-    x = ffn(sd, pre + "ffns.0.", x)
+    x = ffn(sd, pre + "ffns.0.", x, drop=drop)
     return layer_norm(sd, pre + "norms.2", x)
 
 
 def encoder_forward(sd, bev_query, feats, *, bev_h, bev_w, bev_pos, spatial_shapes,
                     level_start_index=None, prev_bev=None, shift=None, img_metas=None,
                     num_layers=None, pc_range=None, num_points_in_pillar=4,
-                    msda=msda_gridsample, return_intermediate=False, **_):
+                    msda=msda_gridsample, return_intermediate=False, dropout_scales=None, **_):
     """encoder.py:185-239.  ``bev_query``/``bev_pos``/``prev_bev`` are (Q,bs,C),
-    ``feats`` is (Nc,S,bs,C); returns (bs,Q,C)."""
+    ``feats`` is (Nc,S,bs,C); returns (bs,Q,C).  ``dropout_scales``: train() mode — the scale tensors of the four
+    nn.Dropout sites of every layer in execution order (TSA output, SCA output, FFN hidden, FFN output)."""
+    drop = iter(dropout_scales) if dropout_scales is not None else None
     if num_layers is None:
         num_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
     bs = bev_query.size(1)
@@ -285,7 +293,7 @@ def encoder_forward(sd, bev_query, feats, *, bev_h, bev_w, bev_pos, spatial_shap
     inter = []
     for i in range(num_layers):
         x = encoder_layer(sd, f"layers.{i}.", x, feats, pos, hybrid, ref_cam, bev_mask,
-                          bev_h, bev_w, spatial_shapes, prev, msda=msda)
+                          bev_h, bev_w, spatial_shapes, prev, msda=msda, drop=drop)
         inter.append(x)
     return torch.stack(inter) if return_intermediate else x
 

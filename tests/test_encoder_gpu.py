@@ -322,3 +322,41 @@ def test_inference_graph_replays_without_repacking_trainable_weights():
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("name", ["micro4", "small4"])
+def test_train_mode_step_against_the_oracle_fed_its_own_dropout_scales(name):
+    """What bench.py's ``fwd_bwd_base_train_mode.parity`` does, as a test: a train() mode step of the fast path with the
+    scale tensors ``train_ops.dropout_scale`` hands out recorded, against ``O.encoder_forward(dropout_scales=...)`` (pinned
+    bit-exact against the reference's files in train() mode) — output, and the gradient of the queries against autograd
+    through the oracle."""
+    from bevformer_amd import train_ops
+    from oracle import bevformer_cpu as O
+    enc, sd = build_pair(name)
+    q, f, kw = S.make_inputs(name, seed=2, temporal=True)
+    enc = enc.to(DEV).train()
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    drawn, real = [], train_ops.dropout_scale
+
+    def recording(shape, p, device):
+        t = real(shape, p, device)
+        drawn.append(t)
+        return t
+    train_ops.dropout_scale = recording
+    try:
+        qd = q.to(DEV).requires_grad_(True)
+        got = enc(qd, f.to(DEV), f.to(DEV), **_to_dev(kw))
+    finally:
+        train_ops.dropout_scale = real
+    L = len(enc.layers)
+    assert len(drawn) == 4 * L, "the train() step did not take the chain kernels"
+    assert 0.05 < float((drawn[0] == 0).float().mean()) < 0.15
+    qc = q.clone().requires_grad_(True)
+    want = O.encoder_forward(sd, qc, f, pc_range=S.PC_RANGE, dropout_scales=[t.cpu() for t in drawn], **kw)
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), **TOL)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    want.backward(gout)
+    got.backward(gout.to(DEV))
+    rel = ((qd.grad.cpu() - qc.grad).norm() / qc.grad.norm()).item()
+    assert rel < 1e-2, rel

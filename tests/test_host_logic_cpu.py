@@ -316,3 +316,33 @@ def test_plan_blob_layout_and_views():
     copy = carve_plan_blob(blob.clone(), spec)
     v["row_ref"].zero_()
     assert bool((copy["row_ref"] == 3).all()) and copy["row_ref"].data_ptr() != v["row_ref"].data_ptr()
+
+
+def test_captured_weight_images_report_stale_weights(monkeypatch):
+    """a graph captured under no_grad freezes the weight images it was captured with; the registry records
+    (weight, version, address) at capture so that ``ops.assert_graph_weights_fresh`` can tell a changed weight."""
+    import torch
+    from bevformer_amd import ops
+    from bevformer_amd.ops import gemm
+    ops.release_captured_images()
+    w = torch.nn.Parameter(torch.randn(8, 4))
+    image = torch.zeros(16, dtype=torch.int16)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    assert gemm._cached_image(("key", image), w) is image
+    assert gemm._cached_image(("key", image), w) is image          # same image again: one record
+    assert len(gemm._CAPTURED_IMAGES) == 1
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    assert ops.graph_weights_stale() == []
+    ops.assert_graph_weights_fresh()
+    with torch.no_grad():
+        w.add_(1.0)                                                # an optimizer step / load_state_dict between replays
+    stale = ops.graph_weights_stale()
+    assert len(stale) == 1 and stale[0][0] == (8, 4) and "written" in stale[0][1]
+    import pytest
+    with pytest.raises(RuntimeError, match="stale"):
+        ops.assert_graph_weights_fresh()
+    del w
+    import gc
+    gc.collect()
+    assert "freed" in ops.graph_weights_stale()[0][1]
+    assert ops.release_captured_images() == 1 and ops.graph_weights_stale() == []

@@ -206,3 +206,35 @@ def test_train_mode_with_active_dropout_matches_the_reference(temporal, monkeypa
     assert ref_calls["shapes"] == calls["shapes"]
     assert (want - plain).abs().max() > 1e-2                                        # dropout really was active
     torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("temporal", [False, True])
+def test_restatement_in_train_mode_is_bit_exact(temporal, monkeypatch):
+    """The oracle's train() mode (``encoder_forward(dropout_scales=...)``: what bench.py's ``fwd_bwd_base_train_mode``
+    parity object is computed with) against the reference's own files in ``train()`` with ``F.dropout`` replaced by the
+    SAME scale tensors, consumed in call order: bit-equal output = same sites, same tensors, same order."""
+    g = torch.Generator().manual_seed(11)
+    scales, used = [], {"n": 0}
+
+    def replay_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        if used["n"] == len(scales):
+            scales.append((torch.rand(x.shape, generator=g) >= p).to(x.dtype) / (1.0 - p))
+        s = scales[used["n"]]
+        used["n"] += 1
+        return x * s
+
+    monkeypatch.setattr(torch.nn.functional, "dropout", replay_dropout)
+    ref = mmcv_stub.build_reference_encoder(S.encoder_cfg("micro4"))
+    sd = S.trained_like_({k: v.clone() for k, v in ref.state_dict().items()}, seed=5)
+    ref.load_state_dict(sd)
+    q, f, kw = S.make_inputs("micro4", seed=2, temporal=temporal)
+    ref.train()
+    with torch.no_grad():
+        want = ref(q, f, f, **kw)
+        assert used["n"] == len(scales) == 2 * 4
+        got = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, dropout_scales=scales, **kw)
+        plain = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+    assert (want - plain).abs().max() > 1e-2
+    assert torch.equal(got, want)

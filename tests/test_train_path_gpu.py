@@ -430,3 +430,54 @@ def test_fast_training_path_with_a_batch_and_with_three_cameras_per_query(case):
     for k in g_s:
         e2, _ = _rel(g_f[k], g_s[k])
         assert e2 < 3e-2, f"grad {k}: relative L2 {e2:.2e}"
+
+
+@pytest.mark.parametrize("which", ["sca", "tsa"])
+def test_second_consumer_of_the_hoisted_values_keeps_its_gradient(which):
+    """ADVICE r4 / VERDICT r5: an auxiliary loss on a hoisted value tensor is a SECOND consumer of a grouped projection's
+    output; its gradient reaches the projection's backward summed with the sampling operator's placeholder and must be
+    added to the gradient the operator deposited in the sink — not dropped.  Checked on the value-projection weight
+    gradients against the per-op path (``train_chain=False``: plain autograd accumulation) with the same auxiliary loss."""
+    enc, _ = build_pair("micro4", device=DEV)
+    q, f, kw = S.make_inputs("micro4", seed=4, temporal=True, device=DEV)
+    gout = torch.randn(1, q.shape[0], 256, generator=torch.Generator().manual_seed(9)).to(DEV) * 1e-2
+    taken = {}
+    orig = type(enc).hoisted_value_projections_autograd
+
+    def spy(self, value, tsa_value):
+        sca, tsa = orig(self, value, tsa_value)
+        taken["vals"] = sca if which == "sca" else tsa
+        return sca, tsa
+
+    def run(fast):
+        enc.zero_grad(set_to_none=True)
+        taken.clear()
+        out = enc(q, f, f, **kw)
+        loss = (out * gout).sum()
+        if fast:
+            assert taken.get("vals") is not None, "the fast path did not hoist the value projections"
+            aux_src = taken["vals"][1]
+        else:
+            # per-op path: the same tensor = layer 1's own value projection of the same input
+            att = enc.layers[1].attentions[1 if which == "sca" else 0]
+            vp = (att.deformable_attention if which == "sca" else att).value_proj
+            if which == "sca":
+                src = f.reshape(-1, 256)
+            else:
+                src = torch.cat([kw["prev_bev"].reshape(-1, 256), q.reshape(-1, 256)], 0)
+            aux_src = torch.nn.functional.linear(src, vp.weight, vp.bias)
+        w_aux = torch.linspace(-1, 1, aux_src.numel(), device=DEV).view(aux_src.shape)
+        (loss + (aux_src.float() * w_aux).sum() * 1e-3).backward()
+        att = enc.layers[1].attentions[1 if which == "sca" else 0]
+        vp = (att.deformable_attention if which == "sca" else att).value_proj
+        return vp.weight.grad.clone(), vp.bias.grad.clone()
+
+    import unittest.mock as mock
+    with mock.patch.object(type(enc), "hoisted_value_projections_autograd", spy):
+        gw_f, gb_f = run(True)
+    with ops.using(train_chain=False):
+        gw_s, gb_s = run(False)
+    # the auxiliary term dominates these two gradients: dropping it (the round-5 behaviour) is a relative error of ~1
+    e_w, _ = _rel(gw_f, gw_s)
+    e_b, _ = _rel(gb_f, gb_s)
+    assert e_w < 2e-2 and e_b < 2e-2, (e_w, e_b)

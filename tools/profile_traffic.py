@@ -94,12 +94,16 @@ def collect(config, out):
 
 
 def kernel_sources_sha():
-    """Hash of the sampling kernels' sources: ``bench.py`` quotes ``profiles/traffic.json`` only while it matches the tree
-    (a changed kernel makes ``roofline.traffic`` null instead of silently stale)."""
+    """Hash of EVERY source of the library (csrc/*.h, csrc/*.hip: kernels, their launchers and the selection logic in
+    the C ABI units): ``bench.py`` quotes ``profiles/traffic.json`` only while it matches the tree — any change to the
+    native code makes ``roofline.traffic`` null instead of silently stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("msda_d32.h", "msda_kernels.h"):
-        h.update(open(os.path.join(ROOT, "bevformer_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "bevformer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
