@@ -146,6 +146,8 @@ SIGNATURES = {
                                              _c_int),
     "bevmsda_linear_panel_pack_weight_t_f32": ([_c_void_p, ctypes.c_int64, _c_int, _c_int, _c_void_p, _c_void_p],
                                              _c_int),
+    "bevmsda_linear_pack_job_blocks": ([_c_int, _c_int, _c_int], ctypes.c_int64),
+    "bevmsda_linear_pack_weights_multi_f32": ([_c_void_p, _c_int, ctypes.c_int64, _c_void_p], _c_int),
     "bevmsda_linear_panel_f32": ([_c_void_p] * 8 + [ctypes.POINTER(LinearDesc), ctypes.POINTER(LayerNormDesc),
                                                   _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_panel_rows2_f32": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, ctypes.POINTER(LinearDesc), _c_void_p,

@@ -66,7 +66,28 @@ static int linear_launch(const float *x0, const float *a0, const float *x1, cons
   // desc->variant: 0 = library default; 1 = the first kernel over the fp32 weight matrix, 13 = over the packed weight
   // image (LDS-DMA into a single W area); 131 = the software-pipelined kernel (BEVMSDA_ERR_UNSUPPORTED when it does not
   // cover the call).  desc->reserved[1] = 1 keeps the default off the software-pipelined kernel.
-  if (d->variant != 0 && d->variant != 1 && d->variant != 13 && d->variant != 131) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->variant != 0 && d->variant != 1 && d->variant != 13 && d->variant != 131 && d->variant != 17) return BEVMSDA_ERR_BAD_OPTION;
+  // desc->variant = 17 (round 6): 64-row x 256-column tiles of the first kernel over the packed weight image — for
+  // 128 < N <= 256 every input row is staged ONCE (the 128 x 128 default stages it once per column tile) and the
+  // 64-row workgroups (3 per CU) cover a 40,000-row call in one round
+  if (d->variant == 17) {
+    if (!wpack || a.accum || mask || d->N <= 128 || d->N % 4 != 0 || d->ldy % 4 != 0 || misaligned(y) || (bias && misaligned(bias)))
+      return BEVMSDA_ERR_UNSUPPORTED;
+    const long long nbm = (d->M + 63) / 64, nbn = (d->N + 255) / 256;
+    const long long grid = ((nbm + 7) / 8) * 8 * nbn;
+    if (grid >= (1LL << 31) || nbm >= (1LL << 28)) return BEVMSDA_ERR_TOO_LARGE;
+    a.nblk_m = static_cast<int>(nbm);
+    a.nblk_n = static_cast<int>(nbn);
+    const dim3 g(static_cast<unsigned>(grid)), b(256);
+    if (d->precision == 0) {
+      if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, true, 32, true, 3, 256, false, 64>), g, b, 0, st, a);
+      else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<3, false, 32, true, 3, 256, false, 64>), g, b, 0, st, a);
+    } else {
+      if (add) hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, true, 32, true, 3, 256, false, 64>), g, b, 0, st, a);
+      else hipLaunchKernelGGL((bevmsda::linear_splitbf16_kernel<1, false, 32, true, 3, 256, false, 64>), g, b, 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  }
   // software-pipelined kernel (linear_pipe.h)
   {
     const int nch = (d->K0 + d->K1) / 32;
@@ -299,6 +320,34 @@ int bevmsda_linear_panel_pack_weight_t_f32(const float *wt, int64_t ldwt, int N,
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   hipLaunchKernelGGL(bevmsda::lin_panel_pack_weight_kernel<true>, dim3(static_cast<unsigned>(nb)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), wt, static_cast<long>(ldwt), N, K, tiles32, blob);
+  return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+}
+
+// Many weight images in one launch (linear_panel.h: lin_pack_weights_multi_kernel).  `jobs` is a DEVICE array of `njobs`
+// bevmsda_pack_job (the caller keeps it alive and unchanged while launches that read it — graph replays included — can
+// run); `blocks` = the total number of 256-thread blocks = first_block of a job past the last (bevmsda_linear_pack_job_blocks
+// gives a job's block count).  Jobs are validated by the caller against the single-image entry points' rules.
+int64_t bevmsda_linear_pack_job_blocks(int N, int K, int kind) {
+  if (N <= 0 || K <= 0 || kind < 0 || kind > 3) return 0;
+  if (kind & 2) {
+    if (K % bevmsda::kPanelK != 0) return 0;
+    const long long threads = 1LL * ((N + 63) / 64) * 2 * (K / 16) * 64;
+    return (threads + 255) / 256;
+  }
+  if (K % 32 != 0) return 0;
+  const long long threads = static_cast<long long>((N + 127) / 128) * 128 * (K / 8);
+  return (threads + 255) / 256;
+}
+
+int bevmsda_linear_pack_weights_multi_f32(const bevmsda_pack_job *jobs, int njobs, int64_t blocks, void *stream) {
+  static_assert(sizeof(bevmsda_pack_job) == sizeof(bevmsda::PackJob), "bevmsda_pack_job layout");
+  if (njobs < 0 || blocks < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (njobs == 0 || blocks == 0) return BEVMSDA_OK;
+  if (!jobs) return BEVMSDA_ERR_NULL_POINTER;
+  if (misaligned(jobs)) return BEVMSDA_ERR_MISALIGNED;
+  if (blocks >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
+  hipLaunchKernelGGL(bevmsda::lin_pack_weights_multi_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const bevmsda::PackJob *>(jobs), njobs);
   return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
 }
 

@@ -580,12 +580,11 @@ linear_splitbf16_kernel(const LinArgs a) {
 // TRANSPOSED: element (n, k) of the weight is w[k * ldw + n] — the image of W^T packed straight from W (the operand of an
 // input-gradient GEMM g W: no contiguous transpose in between; the matrices are a few hundred squared, the strided reads
 // cost nothing next to a second launch).
-template <bool TRANSPOSED = false>
-__global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__restrict__ w, long ldw, int N,
-                                                             int K, uint16_t *__restrict__ blob) {
+template <bool TRANSPOSED>
+__device__ __forceinline__ void lin_pack_weight_thread(long t, const float *__restrict__ w, long ldw, int N, int K,
+                                                       uint16_t *__restrict__ blob) {
   constexpr int ROW = 40, PLANE = 128 * ROW;
   const int kch = K / 32;
-  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   const long rows = static_cast<long>((N + 127) / 128) * 128;
   if (t >= rows * (K / 8)) return;
   const int n = static_cast<int>(t / (K / 8));
@@ -609,6 +608,12 @@ __global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__res
     *reinterpret_cast<uint4 *>(chunk + off + 8) = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4 *>(chunk + PLANE + off + 8) = make_uint4(0, 0, 0, 0);
   }
+}
+
+template <bool TRANSPOSED = false>
+__global__ void __launch_bounds__(256) lin_pack_weight_kernel(const float *__restrict__ w, long ldw, int N,
+                                                             int K, uint16_t *__restrict__ blob) {
+  lin_pack_weight_thread<TRANSPOSED>(static_cast<long>(blockIdx.x) * 256 + threadIdx.x, w, ldw, N, K, blob);
 }
 
 }  // namespace bevmsda

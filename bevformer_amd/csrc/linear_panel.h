@@ -756,11 +756,10 @@ linear_panel_kernel(const PanelArgs a) {
 //   k = 256 (sg / 16) + 32 (2 p + (e >> 2)) + 4 c + (e & 3),  8 p + c = 2 (sg % 16) + (lane >> 5)
 // Rows >= N are zero (N is padded to the launcher's column-tile width).  One thread per (T, sg, lane).
 // TRANSPOSED: element (n, k) of the weight is w[k * ldw + n] (the image of W^T from W where it lies: backward GEMMs).
-template <bool TRANSPOSED = false>
-__global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float *__restrict__ w, long ldw, int N, int K,
-                                                                   int n_tiles32, uint16_t *__restrict__ blob) {
+template <bool TRANSPOSED>
+__device__ __forceinline__ void lin_panel_pack_weight_thread(long t, const float *__restrict__ w, long ldw, int N, int K,
+                                                             int n_tiles32, uint16_t *__restrict__ blob) {
   const int nstep = K / 16;
-  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (t >= static_cast<long>(n_tiles32) * nstep * 64) return;
   const int lane = static_cast<int>(t & 63);
   const int sg = static_cast<int>((t >> 6) % nstep);
@@ -783,6 +782,42 @@ __global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float 
   uint4 *dst = reinterpret_cast<uint4 *>(blob) + ((static_cast<long>(T) * nstep + sg) * 2) * 64 + lane;
   dst[0] = hi;
   dst[64] = lo;
+}
+
+template <bool TRANSPOSED = false>
+__global__ void __launch_bounds__(256) lin_panel_pack_weight_kernel(const float *__restrict__ w, long ldw, int N, int K,
+                                                                   int n_tiles32, uint16_t *__restrict__ blob) {
+  lin_panel_pack_weight_thread<TRANSPOSED>(static_cast<long>(blockIdx.x) * 256 + threadIdx.x, w, ldw, N, K, n_tiles32, blob);
+}
+
+// Many weight images in ONE launch (round 6): the training step re-packs the images of every trainable weight from the
+// weights' current values — 52 launches of ~5 us each at base, now one.  `jobs` lives in DEVICE memory (a captured graph
+// replays the launch with the table it was captured with); job j owns the blocks [first_block[j], first_block[j + 1]).
+struct PackJob {
+  const float *w;         // the weight matrix, or (kind & 1) the memory its transpose lies in
+  long long ldw;
+  unsigned short *blob;
+  int N, K;
+  int kind;               // bit 0: transposed source; bit 1: row-panel image (fragment order), else the first kernel's
+  int first_block;
+};
+
+__global__ void __launch_bounds__(256) lin_pack_weights_multi_kernel(const PackJob *__restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;                   // the job whose block range holds blockIdx.x (uniform: scalar loads)
+  const int b = static_cast<int>(blockIdx.x);
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  const long t = static_cast<long>(b - j.first_block) * 256 + threadIdx.x;
+  uint16_t *blob = reinterpret_cast<uint16_t *>(j.blob);
+  switch (j.kind) {
+    case 0: lin_pack_weight_thread<false>(t, j.w, j.ldw, j.N, j.K, blob); break;
+    case 1: lin_pack_weight_thread<true>(t, j.w, j.ldw, j.N, j.K, blob); break;
+    case 2: lin_panel_pack_weight_thread<false>(t, j.w, j.ldw, j.N, j.K, ((j.N + 63) / 64) * 2, blob); break;
+    default: lin_panel_pack_weight_thread<true>(t, j.w, j.ldw, j.N, j.K, ((j.N + 63) / 64) * 2, blob); break;
+  }
 }
 
 }  // namespace bevmsda

@@ -14,7 +14,7 @@ import threading
 import torch
 
 GEMM_MODES = ("split", "bf16", "native")
-GEMM_KERNELS = (None, "first", "pipe", "panel", "panel64", "panel128", "panel64w2", "panel64w6") + tuple(
+GEMM_KERNELS = (None, "first", "first64", "pipe", "panel", "panel64", "panel128", "panel64w2", "panel64w6") + tuple(
     # A/B knobs of the row-panel epilogue (tools/gemm_epilogue_ab.py): e1 dripping stores, e2 weight fragments 4 steps
     # ahead, e3 both, e4 the round-4 epilogue (bias loaded per piece)
     f"panel{bm}e{v}" for bm in (64, 128) for v in (1, 2, 3, 4)) + tuple(

@@ -368,6 +368,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
                                             spatial_shapes=spatial_shapes,
                                             level_start_index=level_start_index,
                                             prev_bev=prev_bev, shift=shift, **kwargs)
+        if torch.is_grad_enabled() and bev_query.is_cuda and value.is_cuda:
+            # a differentiable step: ONE launch rebuilds the weight images the last steps used from the weights' current
+            # values (ops.begin_training_step; until round 6 every image was re-packed by its own launch, 52 per step at base)
+            ops.begin_training_step(self)
+        else:
+            ops.end_training_steps()
         bs = bev_query.size(1)
         train_fast = bev_query.is_cuda and value.is_cuda and self._train_fast_path(
             value.device, (bev_query, value, bev_pos, prev_bev))

@@ -67,8 +67,22 @@ def _cache_ok(weight):
     conversion kernels are captured too.  A graph captured under ``torch.no_grad()`` is an inference graph: it freezes
     the images it was captured with, exactly as it freezes the merged (concatenated) projection weights — change the
     weights, capture again (round 5: the 24 re-packing launches per replayed forward step were 2.8 % of it)."""
-    return not (weight.requires_grad and (torch.is_grad_enabled() or _m().graph_repack) and weight.is_cuda
-                and torch.cuda.is_current_stream_capturing())
+    if not weight.is_cuda or not torch.cuda.is_current_stream_capturing():
+        return True
+    if weight.requires_grad and (torch.is_grad_enabled() or _m().graph_repack):
+        return False
+    # Round 6: the autograd Functions run their forward and backward with grad mode OFF, so the rule above never saw the
+    # captures it was written for — a captured TRAINING step froze the images of every weight that reached the kernels
+    # as the parameter object itself (the FFN's: output off by 4e-3, gradients by 7 % after one optimizer step between
+    # replays; tools/probes/graph_update_check.py).  What tells a training capture is the step state: between
+    # ``begin_training_step(module)`` and the next forward without gradients, images of memory that belongs to the module's
+    # parameters are rebuilt inside the capture (by the one-launch rebuild when it covers them, else by their own launch).
+    if _TRAIN["active"]:
+        try:
+            return weight.untyped_storage().data_ptr() not in _TRAIN["storages"]
+        except Exception:       # noqa: BLE001
+            return False
+    return True
 
 
 # Weight images a stream capture handed to a graph, by id(image): {image (kept alive: the graph holds its address), a weak
@@ -126,6 +140,128 @@ def release_captured_images():
     return n
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Weight images of a TRAINING step (round 6).  The weights change between steps, so a training step rebuilds every image
+# it uses from their current values — until round 5 image by image, 52 launches of ~5 us each per step at base (also
+# inside the captured graph of a step).  Now: an image packed under grad mode from memory that belongs to a parameter of
+# the module whose step is running is REGISTERED (its blob keeps its address), and ``begin_training_step(module)`` — the
+# encoder calls it when a differentiable forward starts — rebuilds all registered images with ONE launch
+# (``bevmsda_linear_pack_weights_multi_f32``) and marks them fresh for this step; ``packed_weight`` / ``panel_weight``
+# then hand out the fresh blob without a launch.  Safety net for calls outside a step: an image is only handed out while
+# the version counter of the tensor it was packed from is the one recorded at the rebuild.
+# (``active``: between the start of a differentiable forward and the next forward without gradients — the autograd
+# Functions run their forward AND backward with grad mode off, so grad mode cannot tell a training step from inference)
+_TRAIN = {"step": 0, "entries": {}, "table": None, "table_key": None, "table_blocks": 0, "storages": frozenset(),
+          "multi_launches": 0, "single_launches": 0, "enabled": __import__("os").environ.get("BEVMSDA_IMAGE_BATCH", "1") == "1",
+          "active": False}
+
+
+def set_training_image_batching(flag):
+    """A/B switch of the one-launch image rebuild (default on)."""
+    _TRAIN["enabled"] = bool(flag)
+    _TRAIN["active"] = False
+    _TRAIN["entries"].clear()
+    _TRAIN["table"] = _TRAIN["table_key"] = None
+
+
+def training_image_stats():
+    return dict(step=_TRAIN["step"], images=len(_TRAIN["entries"]), multi_launches=_TRAIN["multi_launches"],
+                single_launches=_TRAIN["single_launches"], unregistered=dict(_TRAIN.get("unregistered", {})))
+
+
+def _train_key(kind, weight):
+    return (kind, _is_transposed_view(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
+
+
+def _train_image(kind, weight):
+    """The fresh image of ``weight`` rebuilt at the start of this training step, or None."""
+    if not (_TRAIN["enabled"] and _TRAIN["active"] and _TRAIN["entries"]):
+        return None
+    e = _TRAIN["entries"].get(_train_key(kind, weight))
+    if e is None or e["fresh_step"] != _TRAIN["step"] or e["version"] != _ver(weight):
+        return None
+    e["used_step"] = _TRAIN["step"]
+    return e["blob"]
+
+
+def _train_register(kind, weight, blob, launched=True):
+    """Called after an image was packed the single way (or found in the per-version cache) during a training step: from the
+    next step on it is rebuilt in the batch."""
+    _TRAIN["single_launches"] += int(_TRAIN["active"] and launched)
+    if not (_TRAIN["enabled"] and _TRAIN["active"] and weight.is_cuda):
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return              # (a blob allocated in a capture's private pool is that graph's: never adopted)
+    try:
+        sp = weight.untyped_storage().data_ptr()
+    except Exception:       # noqa: BLE001
+        return
+    if sp not in _TRAIN["storages"]:
+        # (not a parameter of the module whose step is running: a derived tensor may move or die)
+        _TRAIN.setdefault("unregistered", {})[(kind, tuple(weight.shape))] = "memory outside the module's parameters"
+        return
+    N, K = weight.shape
+    t = _is_transposed_view(weight)
+    _TRAIN["entries"][_train_key(kind, weight)] = dict(
+        # (a DETACHED alias: same memory, same version counter — the weight itself may carry a grad_fn, and a reference to
+        # it would keep that step's autograd graph, with the streams its nodes were created on, alive into the next steps:
+        # a later graph capture then ran those nodes' gradient accumulation on the old stream and hipStreamEndCapture crashed)
+        blob=blob, tensor=weight.detach(), storage=sp, N=N, K=K, ldw=weight.stride(1) if t else weight.stride(0),
+        kind=(1 if t else 0) | (2 if kind == "panel" else 0), used_step=_TRAIN["step"], fresh_step=_TRAIN["step"],
+        version=_ver(weight))
+
+
+def begin_training_step(module):
+    """Start of a differentiable forward of ``module``: ONE launch rebuilds every weight image registered in the previous
+    steps from the weights' current values (nothing on the first step: images register as they are packed)."""
+    st = _TRAIN
+    st["active"] = True
+    if not torch.cuda.is_current_stream_capturing() or st.get("storages_of") != id(module):
+        st["storages"] = frozenset(p.untyped_storage().data_ptr() for p in module.parameters() if p.is_cuda)
+        st["storages_of"] = id(module)
+    if not st["enabled"]:
+        return
+    st["step"] += 1
+    # images not used for two steps, or whose memory no longer belongs to this module's parameters, are forgotten
+    if not torch.cuda.is_current_stream_capturing():     # (nothing is released while a capture is under way)
+        for k in [k for k, e in st["entries"].items() if e["used_step"] < st["step"] - 2 or e["storage"] not in st["storages"]]:
+            del st["entries"][k]
+    live = list(st["entries"].values())
+    if not live:
+        return
+    key = tuple(id(e) for e in live)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and __import__("os").environ.get("BEVMSDA_IMAGE_BATCH_CAPTURE", "1") == "0":
+        return              # (A/B knob: a captured step packs image by image)
+    if st["table_key"] != key:
+        if capturing:
+            return          # (no host-to-device copy inside a capture: this step packs image by image, as before round 6)
+        lib = _lib.load()
+        rows, first = [], 0
+        for e in live:
+            nb = lib.bevmsda_linear_pack_job_blocks(e["N"], e["K"], e["kind"])
+            if nb <= 0:
+                return
+            # struct bevmsda_pack_job as five int64 words: w, ldw, blob, (N | K << 32), (kind | first_block << 32)
+            rows.append([e["tensor"].data_ptr(), e["ldw"], e["blob"].data_ptr(), e["N"] | (e["K"] << 32), e["kind"] | (first << 32)])
+            first += nb
+        st["table"] = torch.tensor(rows, dtype=torch.int64).to(live[0]["blob"].device)
+        st["table_key"], st["table_blocks"] = key, first
+    with torch.cuda.device(st["table"].device):
+        _lib.check(_lib.load().bevmsda_linear_pack_weights_multi_f32(
+            st["table"].data_ptr(), len(live), st["table_blocks"], torch.cuda.current_stream().cuda_stream),
+            "linear_pack_weights_multi")
+    st["multi_launches"] += 1
+    for e in live:
+        e["fresh_step"] = st["step"]
+        e["version"] = _ver(e["tensor"])
+
+
+def end_training_steps():
+    """A forward WITHOUT gradients started: weight images come from the per-version caches again."""
+    _TRAIN["active"] = False
+
+
 def clear_weight_caches(module):
     """Drop every derived weight image (packed / panel / transposed copies, cached on the parameters per version) of
     ``module``'s parameters.  Needed in ONE situation: parameters that are inference tensors (a model built or loaded
@@ -153,9 +289,13 @@ def packed_weight(weight):
     """Pre-split bf16 image of an (N, K) fp32 weight (``bevmsda_linear_pack_weight_f32``),
     cached on the tensor object until it is written to or moved.  A transposed view (``_is_transposed_view``) is packed
     from the memory it aliases (``bevmsda_linear_pack_weight_t_f32``)."""
+    fresh = _train_image("pack", weight)
+    if fresh is not None:
+        return fresh
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_pack", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
+        _train_register("pack", weight, hit[1], launched=False)     # (a training step adopts it: rebuilt in the batch from now on)
         return _cached_image(hit, weight)
     lib = _lib.load()
     N, K = weight.shape
@@ -177,15 +317,20 @@ def packed_weight(weight):
         weight._bevmsda_pack = (key, blob)
     except AttributeError:
         pass
+    _train_register("pack", weight, blob)
     return blob
 
 
 def panel_weight(weight):
     """Fragment-order bf16 image of an (N, K) fp32 weight for the row-panel kernel
     (``bevmsda_linear_panel_pack_weight_f32``), cached on the tensor until it is written to or moved."""
+    fresh = _train_image("panel", weight)
+    if fresh is not None:
+        return fresh
     key = (_ver(weight), weight.data_ptr(), tuple(weight.shape), weight.stride(0), weight.stride(1))
     hit = getattr(weight, "_bevmsda_panel", None)
     if hit is not None and hit[0] == key and _cache_ok(weight):
+        _train_register("panel", weight, hit[1], launched=False)
         return _cached_image(hit, weight)
     lib = _lib.load()
     N, K = weight.shape
@@ -207,6 +352,7 @@ def panel_weight(weight):
         weight._bevmsda_panel = (key, blob)
     except AttributeError:
         pass
+    _train_register("panel", weight, blob)
     return blob
 
 
@@ -229,6 +375,9 @@ KERNEL_SELECTION = {
     "layernorm_fused":         (True,   "row-panel kernel whenever the residual + LayerNorm epilogue is wanted (N = 256)",
                                 "output_proj + LN 45.4 vs 51.6 us, fc2 + LN 59.3 vs 66.1 us against two launches",
                                 "profiles/r3/r3a_gemm_ab_first_vs_panel.txt"),
+    "first_64x256_rows":       (32768, "first kernel in 64-row x 256-column tiles (every input row staged once) for 128 < N <= 256 from this many rows on",
+                                "TemporalSelfAttention's two-source projection (N = 192, K = 512): 49.1 vs 51.8 us at 40,000 rows, level at 20,000 (32.7 vs 32.8), bit-identical results",
+                                "profiles/r6/r6c_first64x256_ab.txt"),
     # ---- in the library (constants of csrc/bevmsda_linear.hip)
     "pipe_max_rows":           (8192,   "kLinearPipeMaxRows: software-pipelined kernel for first-kernel calls of up to this many rows",
                                 "13.1-19.9 vs 14.7-23.0 us at 2,500-5,000 rows; level at 10,000, behind from 20,000 rows on",
@@ -435,6 +584,9 @@ def linear(x, weight, bias=None, *, relu=False, x_add=None, x2=None, x2_add=None
             desc.variant = 131              # force the software-pipelined kernel
     elif _m().gemm_kernel == "first":
         desc.reserved[1] = 1                # keep the first kernel
+    elif blob is not None and accumulate_into is None and 128 < N <= 256 and groups == 1 \
+            and (_m().gemm_kernel == "first64" or (_m().gemm_kernel is None and _sel("first_64x256_rows") <= M)):
+        desc.variant = 17                   # 64 x 256 tiles: every input row staged once (KERNEL_SELECTION)
     lib = _lib.load()
     fn = lib.bevmsda_linear_f32 if blob is None else lib.bevmsda_linear_packed_f32
     cb = _GEMM_TIMER["cb"]

@@ -479,8 +479,8 @@ typedef struct bevmsda_layernorm_desc {
  * K = 512 and ln need N <= 256; N % 4 == 0, group_cols % 64 == 0, all pointers 16-byte aligned, row strides
  * multiples of 4; anything else returns BEVMSDA_ERR_UNSUPPORTED / _MISALIGNED and the caller uses the entry
  * points above.  The k order inside an MFMA differs from the first kernel's: results agree to fp32 summation
- * order, not bit for bit.  The epilogue addresses one output group (M, ldy) through a 32-bit raw buffer: M * ldy * 4 must
- * stay below 2 GiB per group (BEVMSDA_ERR_TOO_LARGE otherwise).  desc->reserved[3] is a BENCHMARK knob (0 in
+ * order, not bit for bit.  The epilogue addresses one ROW PANEL (<= 128 rows x ldy) of an output group through a 32-bit
+ * raw buffer with a 64-bit base: 128 * ldy * element size must stay below 2 GiB (BEVMSDA_ERR_TOO_LARGE otherwise).  desc->reserved[3] is a BENCHMARK knob (0 in
  * production; tools/gemm_epilogue_ab.py, profiles/r5): 2 / 6 weight-fragment prefetch depth of the 64-row shape;
  * 32 + {1: finished tile stored one piece per k16 step, 2: prefetch depth 4, 3: both, 4: the round-4 epilogue};
  * 64 + n: phase skew of the column sweep (n x 1024 clocks); 97 / 98: one wavefront per SIMD with dripping stores. */
@@ -488,6 +488,25 @@ int64_t bevmsda_linear_panel_packed_bytes(int N, int K);
 int bevmsda_linear_panel_pack_weight_f32(const float *w, int64_t ldw, int N, int K, uint16_t *blob, void *stream);
 /* ... of the (N, K) weight whose transpose lies in memory: wt (K, ldwt), element (n, k) = wt[k * ldwt + n] (backward GEMMs). */
 int bevmsda_linear_panel_pack_weight_t_f32(const float *wt, int64_t ldwt, int N, int K, uint16_t *blob, void *stream);
+/* Many weight images in ONE launch (round 6; the reference re-reads its nn.Linear weights on every call, e.g.
+ * temporal_self_attention.py:197-211 — the images are this library's derived copies and a training step rebuilds all of
+ * them from the weights' current values: 52 launches at bevformer_base, one with this entry).  `jobs`: DEVICE array, kept
+ * alive and unchanged by the caller while a launch that reads it can run (graph replays included); kind bit 0 = the
+ * source is the memory of the transpose (w[k * ldw + n]), bit 1 = row-panel image (bevmsda_linear_panel_pack_weight*),
+ * else the first kernel's (bevmsda_linear_pack_weight*); first_block = sum of the block counts
+ * (bevmsda_linear_pack_job_blocks) of the jobs before; `blocks` = the total.  Per-job shape / alignment rules are those
+ * of the single-image entry points and are the caller's to check. */
+typedef struct bevmsda_pack_job {
+  const float *w;
+  int64_t ldw;
+  uint16_t *blob;
+  int32_t N, K;
+  int32_t kind;
+  int32_t first_block;
+} bevmsda_pack_job;
+int64_t bevmsda_linear_pack_job_blocks(int N, int K, int kind);
+int bevmsda_linear_pack_weights_multi_f32(const bevmsda_pack_job *jobs, int njobs, int64_t blocks, void *stream);
+
 int bevmsda_linear_panel_f32(const float *x0, const float *a0, const float *x1, const float *a1, const int32_t *idx,
                              const float *scale, const uint16_t *wpanel, const float *bias,
                              const bevmsda_linear_desc *desc, const bevmsda_layernorm_desc *ln, float *y,

@@ -481,3 +481,90 @@ def test_second_consumer_of_the_hoisted_values_keeps_its_gradient(which):
     e_w, _ = _rel(gw_f, gw_s)
     e_b, _ = _rel(gb_f, gb_s)
     assert e_w < 2e-2 and e_b < 2e-2, (e_w, e_b)
+
+
+def test_training_step_rebuilds_its_weight_images_with_one_launch():
+    """Round 6: from the second differentiable step on, the weight images of the trainable weights are
+    rebuilt from the weights' current values by ONE launch at the start of the step (``ops.begin_training_step``) instead of one
+    launch per image — and an in-place weight update between steps (an optimizer step) is seen: same gradients as with the
+    batching switched off, eagerly and from a captured graph of the step."""
+    name = "micro4"
+    enc, _ = build_pair(name, device=DEV)
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    q, f, kw = S.make_inputs(name, seed=7, temporal=True, device=DEV)
+    gout = torch.randn(1, q.shape[0], 256, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def step():
+        enc.zero_grad(set_to_none=True)
+        out = enc(q, f, f, **kw)
+        out.backward(gout)
+        return out.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}
+
+    def sgd(scale):
+        with torch.no_grad():
+            for i, p in enumerate(enc.parameters()):
+                p.add_(torch.full_like(p, scale * (1 + i % 3)))
+
+    ops.set_training_image_batching(True)
+    try:
+        s0 = ops.training_image_stats()
+        step()                                           # registers the images as they are packed
+        s1 = ops.training_image_stats()
+        assert s1["single_launches"] - s0["single_launches"] >= 10 and s1["images"] >= 10, (s0, s1)
+        step()
+        s2 = ops.training_image_stats()
+        assert s2["multi_launches"] == s1["multi_launches"] + 1
+        left = s2["single_launches"] - s1["single_launches"]
+        assert left <= 0.4 * (s1["single_launches"] - s0["single_launches"]), \
+            f"{left} images still packed one by one in the second step (first step: {s1['single_launches'] - s0['single_launches']}): {s2['unregistered']}"
+        print("single-image launches: first step", s1["single_launches"] - s0["single_launches"], "second step", left, s2["unregistered"])
+        sgd(1e-3)                                        # an optimizer step between two training steps
+        out_b, g_b = step()
+        ops.set_training_image_batching(False)
+        out_s, g_s = step()
+        _check(out_b, out_s, "output after a weight update", 1e-6, 1e-5)
+        for k in g_s:
+            e2, _ = _rel(g_b[k], g_s[k])
+            assert e2 < 1e-3, f"grad {k}: batched vs single image rebuild, relative L2 {e2:.2e}"
+        # ... and inside a captured graph: capture, update the weights in place, replay — with the one-launch rebuild and
+        # without it (image by image).  Until round 6 a captured training step FROZE the images of the weights that reach the
+        # kernels as the parameter objects themselves (ops._cache_ok: the autograd Functions run with grad mode off):
+        # 4e-3 on the output, 7 % on gradients after one update (tools/probes/graph_update_check.py).
+        for batching in (True, False):
+            ops.set_training_image_batching(batching)
+            step()
+            step()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            holder = {}
+
+            def captured_step():
+                enc.zero_grad(set_to_none=True)
+                out = enc(q, f, f, **kw)
+                out.backward(gout)
+                holder["out"] = out.detach()
+                holder["g"] = {k: p.grad for k, p in enc.named_parameters()}
+            before = ops.training_image_stats()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                captured_step()
+            after = ops.training_image_stats()
+            assert after["multi_launches"] == before["multi_launches"] + int(batching), "the one-launch rebuild was not captured"
+            sgd(-2e-3 if batching else 1.5e-3)
+            graph.replay()
+            torch.cuda.synchronize()
+            got_out, got = holder["out"].clone(), {k: v.clone() for k, v in holder["g"].items()}
+            ops.set_training_image_batching(False)
+            want_out, want = step()
+            _check(got_out, want_out, f"graph replay after a weight update (batching {batching})", 1e-6, 1e-5)
+            for k in want:
+                e2, _ = _rel(got[k], want[k])
+                assert e2 < 1e-3, f"grad {k}: graph replay after a weight update vs eager (batching {batching}), relative L2 {e2:.2e}"
+            del graph
+    finally:
+        ops.set_training_image_batching(True)
