@@ -206,11 +206,20 @@ int bevmsda_linear_wgrad_f32(const float *g, int64_t ldg, const float *x, int64_
 
 int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob, int64_t M, int precision, int workgroups,
                                    int variant, void *stream) {
-  if (variant != 0 && variant != 1) return BEVMSDA_ERR_BAD_OPTION;
+  if (variant != 0 && variant != 1 && variant != 2) return BEVMSDA_ERR_BAD_OPTION;
   if (nprob < 0 || nprob > bevmsda::kWgMaxProblems || M < 0) return BEVMSDA_ERR_BAD_SHAPE;
   if (precision != 0 && precision != 1) return BEVMSDA_ERR_BAD_OPTION;
   if (nprob == 0 || M == 0) return BEVMSDA_OK;
   if (!probs) return BEVMSDA_ERR_NULL_POINTER;
+  if (variant == 2 && workgroups == 0) {
+    // the 256 x 128 shape runs ONE 512-thread workgroup per CU, slices dealt to the XCDs in eights: it is taken when
+    // tiles x 8 k workgroups fill at least 208 of the 256 CUs in one round (the grouped value projections, 12 tiles ->
+    // 192 workgroups, stay on the 128 x 128 shape: 553 vs 538 us)
+    long long t2 = 0;
+    for (int i = 0; i < nprob; ++i) t2 += 1LL * ((probs[i].N + 255) / 256) * ((probs[i].K + 127) / 128);
+    const long long s2 = t2 > 0 ? (256 / t2 / 8) * 8 : 0;
+    if (s2 < 8 || t2 * s2 < 208) variant = 0;
+  }
   bevmsda::WgradMultiArgs a{};
   long long tiles = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -222,7 +231,8 @@ int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob
     if (misaligned(q.g) || misaligned(q.x) || (reinterpret_cast<uintptr_t>(q.grad_w) & 3u) != 0) return BEVMSDA_ERR_MISALIGNED;
     bevmsda::WgradArgs &w = a.p[i];
     w.g = q.g; w.x = q.x; w.ldg = q.ldg; w.ldx = q.ldx; w.gw = q.grad_w; w.ldgw = q.ldgw; w.gb = q.grad_b; w.M = M;
-    w.N = q.N; w.K = q.K; w.tiles_n = (q.N + 127) / 128; w.tiles_k = (q.K + 127) / 128;
+    // variant 2 (wgrad_tr.h, third shape): 256 x 128 output tiles
+    w.N = q.N; w.K = q.K; w.tiles_n = (q.N + (variant == 2 ? 255 : 127)) / (variant == 2 ? 256 : 128); w.tiles_k = (q.K + 127) / 128;
     a.tile0[i] = static_cast<int>(tiles);
     tiles += 1LL * w.tiles_n * w.tiles_k;
   }
@@ -233,6 +243,13 @@ int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob
   // `workgroups` > 0: the caller's target instead (benchmark sweeps)
   if (workgroups < 0 || workgroups > (1 << 20)) return BEVMSDA_ERR_BAD_OPTION;
   long long slices = workgroups > 0 ? workgroups / tiles : (tiles >= 12 ? (768 + tiles - 1) / tiles : 512 / tiles);
+  if (variant == 2 && workgroups == 0) {
+    // one 512-thread workgroup per CU and slices dealt to the XCDs in eights: the largest grid of tiles x 8 k workgroups
+    // that still fits ONE round of 256 (a 257th workgroup costs a whole second round: 2.85 ms per step at 192 workgroups
+    // against 3.81 at "256" = 288 launched, profiles/r6/r6e_wgrad_256x128_sweep.txt)
+    slices = (256 / tiles / 8) * 8;
+    if (slices < 8) slices = 8;
+  }
   if (slices < 1) slices = 1;
   long long rows = (M + slices - 1) / slices;
   rows = ((rows + 31) / 32) * 32;
@@ -243,8 +260,12 @@ int bevmsda_linear_wgrad_multi_f32(const bevmsda_wgrad_problem *probs, int nprob
   if (tiles * slices8 >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   const dim3 grid(static_cast<unsigned>(tiles * slices8)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // variant 0: bf16 planes + transposing LDS reads (wgrad_tr.h); 1: fp32 tiles + gathered fragments (wgrad_mfma.h)
-  if (variant == 0) {
+  // variant 0: bf16 planes + transposing LDS reads (wgrad_tr.h); 1: fp32 tiles + gathered fragments (wgrad_mfma.h);
+  // 2: 256 x 128 tiles, eight wavefronts, two LDS stages (wgrad_tr.h)
+  if (variant == 2) {
+    if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_tr2_multi_kernel<3>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bevmsda::wgrad_tr2_multi_kernel<1>), grid, dim3(512), 0, st, a);
+  } else if (variant == 0) {
     if (precision == 0) hipLaunchKernelGGL((bevmsda::wgrad_tr_multi_kernel<3>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((bevmsda::wgrad_tr_multi_kernel<1>), grid, block, 0, st, a);
   } else {

@@ -189,6 +189,205 @@ __device__ __forceinline__ void wgrad_tile_tr(const WgradArgs &a, int tile, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third shape (round 6): 256 x 128 output tiles on EIGHT wavefronts with TWO LDS stages.
+//
+// The 128 x 128 / four-wavefront form above is issue-bound, not MFMA- or HBM-bound (27 % MFMA busy, 2.7 TB/s): per 32-row
+// chunk a wavefront issues 24 MFMAs (~770 clk) against ~1,000 clk of VALU for the hi / lo split of its 32 elements per
+// thread, and the chunk is bracketed by two barriers because the single LDS stage serialises "store planes" and "read
+// fragments" inside a workgroup.  Here a workgroup's 512 threads stage a 32 x 256 strip of G and a 32 x 128 strip of X
+// (24 elements per thread: the G strip is split once for two 128-column X tiles' worth of MFMAs), the planes of chunk
+// c + 1 are written into the OTHER stage while chunk c's fragments are read — one barrier per chunk — and the loads run
+// three chunks ahead.  One workgroup (112 KB of LDS) per CU = the same eight wavefronts per CU as two of the old ones.
+// G rows keep the bank property of the 320-byte stride: 576 bytes = 144 banks = 16 (mod 64).
+constexpr int kW2GRowBytes = 576;                    // (256 + 32 pad) bf16
+constexpr int kW2GPlane = 32 * kW2GRowBytes;         // 18,432 bytes
+constexpr int kW2XPlane = kWtPlane;                  // 10,240 bytes (320-byte rows as above)
+
+template <int ROWBYTES>
+__device__ __forceinline__ lin_bf16x8 wt_fragment_rb(const unsigned char *p) {
+  const wt_i16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) wt_i16x4 *)(const_cast<unsigned char *>(p)));
+  const wt_i16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) wt_i16x4 *)(const_cast<unsigned char *>(p + 4 * ROWBYTES)));
+  const wt_i16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(lin_bf16x8, v);
+}
+
+template <int NPROD>
+__device__ __forceinline__ void wgrad_tile_tr2(const WgradArgs &a, int tile, int slice, unsigned char *lds) {
+  constexpr bool LO = NPROD == 3;
+  constexpr int NPL = LO ? 2 : 1;
+  constexpr int STAGE = NPL * (kW2GPlane + kW2XPlane);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;                  // 4 x 2 wavefronts of 64 x 64 over the 256 x 128 tile
+  const int tiles_k = (a.K + 127) / 128;
+  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  const int n0 = tn * 256, k0 = tk * 128;
+  const long m_begin = static_cast<long>(slice) * a.rows_per_block;
+  if (m_begin >= a.M) return;
+  const long m_end = m_begin + a.rows_per_block < a.M ? m_begin + a.rows_per_block : a.M;
+  const int nchunks = static_cast<int>((m_end - m_begin + 31) / 32);
+
+  // my pieces of a chunk: G column piece tid & 63 of rows (tid >> 6) + 8 i (i < 4); X column piece tid & 31 of rows (tid >> 5) + 16 i (i < 2)
+  const int grow0 = tid >> 6, gc4 = (tid & 63) * 4;
+  const int xrow0 = tid >> 5, xc4 = (tid & 31) * 4;
+  const int gcol = n0 + gc4 < a.N ? n0 + gc4 : (a.N - 4);     // (columns past the matrix: clamped, never stored)
+  const int xcol = k0 + xc4 < a.K ? k0 + xc4 : (a.K - 4);
+  const bool want_bias = a.gb != nullptr && tk == 0;
+  float4 rgA[4], rxA[2], rgB[4], rxB[2];
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load = [&](int c, float4 (&rg)[4], float4 (&rx)[2]) {
+    const long mb = m_begin + static_cast<long>(c) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long m = mb + grow0 + 8 * i;
+      if (m >= a.M) m = a.M - 1;
+      rg[i] = *reinterpret_cast<const float4 *>(a.g + m * a.ldg + gcol);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long m = mb + xrow0 + 16 * i;
+      if (m >= a.M) m = a.M - 1;
+      rx[i] = *reinterpret_cast<const float4 *>(a.x + m * a.ldx + xcol);
+    }
+  };
+  auto split_store = [&](unsigned char *dst, int plane_bytes, float4 v) {
+    uint2 hi;
+    hi.x = lin_pack2(v.x, v.y);
+    hi.y = lin_pack2(v.z, v.w);
+    *reinterpret_cast<uint2 *>(dst) = hi;
+    if (LO) {
+      uint2 lo;
+      lo.x = lin_pack2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = lin_pack2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+      *reinterpret_cast<uint2 *>(dst + plane_bytes) = lo;
+    }
+  };
+  auto store = [&](int c, const float4 (&rg)[4], const float4 (&rx)[2]) {
+    unsigned char *const pg = lds + (c & 1) * STAGE, *const px = pg + NPL * kW2GPlane;
+    const long mrem = m_end - (m_begin + static_cast<long>(c) * 32);      // valid rows of this chunk (>= 1)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = grow0 + 8 * i;
+      const float4 gv = row < mrem ? rg[i] : z;
+      if (want_bias) csum = lin_add4(csum, gv);
+      split_store(pg + row * kW2GRowBytes + gc4 * 2, kW2GPlane, gv);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = xrow0 + 16 * i;
+      split_store(px + row * kWtRowBytes + xc4 * 2, kW2XPlane, row < mrem ? rx[i] : z);
+    }
+  };
+
+  const int s = lane & 15, g0 = (lane >> 4) & 1, g1 = lane >> 5;
+  const int frow = 8 * g1 + (s >> 2), fcolb = (16 * g0 + 4 * (s & 3)) * 2;
+  unsigned fa[2], fb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    fa[t] = static_cast<unsigned>(frow * kW2GRowBytes + (wn * 64 + t * 32) * 2 + fcolb);
+    fb[t] = static_cast<unsigned>(frow * kWtRowBytes + (wk * 64 + t * 32) * 2 + fcolb);
+  }
+
+  lin_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mma = [&](int c) {
+    const unsigned char *const pg = lds + (c & 1) * STAGE, *const px = pg + NPL * kW2GPlane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      lin_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = wt_fragment_rb<kW2GRowBytes>(pg + fa[t] + ks * 16 * kW2GRowBytes);
+        bh[t] = wt_fragment_rb<kWtRowBytes>(px + fb[t] + ks * 16 * kWtRowBytes);
+        if (LO) {
+          al[t] = wt_fragment_rb<kW2GRowBytes>(pg + kW2GPlane + fa[t] + ks * 16 * kW2GRowBytes);
+          bl[t] = wt_fragment_rb<kWtRowBytes>(px + kW2XPlane + fb[t] + ks * 16 * kWtRowBytes);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (LO) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  // iteration c: the planes of chunk c + 1 go into the other stage (its last readers passed the barrier that ended
+  // iteration c - 1), the loads of chunk c + 3 go into the register set just stored, chunk c is multiplied
+  auto step = [&](int c, float4 (&rg)[4], float4 (&rx)[2]) {     // (rg, rx) hold chunk c + 1
+    if (c + 1 < nchunks) store(c + 1, rg, rx);
+    if (c + 3 < nchunks) load(c + 3, rg, rx);
+    mma(c);
+    wt_lds_barrier();
+  };
+  load(0, rgA, rxA);
+  if (nchunks > 1) load(1, rgB, rxB);
+  store(0, rgA, rxA);
+  if (nchunks > 2) load(2, rgA, rxA);
+  wt_lds_barrier();
+  for (int c = 0; c < nchunks; c += 2) {
+    step(c, rgB, rxB);
+    if (c + 1 < nchunks) step(c + 1, rgA, rxA);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < a.N && k < a.K) unsafeAtomicAdd(a.gw + static_cast<long>(n) * a.ldgw + k, acc[i][j][r]);
+      }
+    }
+  if (want_bias) {
+    // the 8 threads that share a G column piece (tid & 63) combine through LDS; one atomic per column and workgroup
+    float *red = reinterpret_cast<float *>(lds);                      // [8][256]  (the last barrier of the loop passed)
+    *reinterpret_cast<float4 *>(red + grow0 * 256 + gc4) = csum;
+    wt_lds_barrier();
+    if (tid < 256) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r * 256 + tid];
+      const int n = n0 + tid;
+      if (n < a.N) unsafeAtomicAdd(a.gb + n, sum);
+    }
+  }
+}
+
+template <int NPROD>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_tr2_multi_kernel(const WgradMultiArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (NPROD == 3 ? 2 : 1) * (kW2GPlane + kW2XPlane)];
+  const int ntile = a.tile0[a.nprob];
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int tile = seq % ntile;
+  const int slice = (seq / ntile) * 8 + xcd;
+  WgradArgs w = a.p[0];
+  int t0 = 0;
+#pragma unroll
+  for (int i = 1; i < kWgMaxProblems; ++i)
+    if (i < a.nprob && tile >= a.tile0[i]) {
+      w = a.p[i];
+      t0 = a.tile0[i];
+    }
+  wgrad_tile_tr2<NPROD>(w, tile - t0, slice, lds);
+}
+
 template <int NPROD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_tr_multi_kernel(const WgradMultiArgs a) {

@@ -63,7 +63,7 @@ class Modes:
         # backward needs, hoisted value projections, device-side row count through forward and backward
         self.train_chain = env("BEVMSDA_TRAIN_CHAIN", "1") == "1"
         self.wgrad_workgroups = int(env("BEVMSDA_WGRAD_WGS", "0"))  # benchmark knob: workgroup target of the multi-problem weight gradient
-        self.wgrad_variant = int(env("BEVMSDA_WGRAD_VARIANT", "0"))  # 0: bf16 planes + transposing LDS reads; 1: gathered fragments
+        self.wgrad_variant = int(env("BEVMSDA_WGRAD_VARIANT", "2"))  # 2 (default, round 6): 256 x 128 tiles on 8 wavefronts with 2 LDS stages where its one-workgroup-per-CU grid fills the chip, else 0; 0: 128 x 128, bf16 planes + transposing LDS reads; 1: gathered fragments
         # training: the parameter-gradient arena of the encoder call being recorded (train_ops.GradArena; set by
         # BEVFormerEncoder.forward for the duration of its call, carried to the backward pass by the Functions' snapshots)
         self.grad_arena = None

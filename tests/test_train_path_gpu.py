@@ -279,12 +279,13 @@ def test_training_step_replays_from_a_hip_graph():
         assert e2 < 1e-3, f"grad {k}: graph replay vs eager relative L2 {e2:.2e}"     # (atomics: summation order)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
 def test_multi_problem_weight_gradient_matches_float64(variant, mode):
     """``bevmsda_linear_wgrad_multi_f32``: three problems over the same rows in one launch (a ragged row count, N = 192
     with a partial tile, row views with a stride, one problem without bias) against float64; variant 0 = bf16 planes +
-    transposing LDS reads (csrc/wgrad_tr.h), 1 = the first kernel's gathered fragments."""
+    transposing LDS reads (csrc/wgrad_tr.h), 1 = the first kernel's gathered fragments, 2 = 256 x 128 tiles on eight wavefronts with two
+    LDS stages (round 6; forced here with a workgroup target, since the library picks it only where its grid fills the chip)."""
     g = torch.Generator().manual_seed(17 + variant)
     M = 4999
     G1, X1 = torch.randn(M, 256, generator=g), torch.randn(M, 512, generator=g)
@@ -300,7 +301,7 @@ def test_multi_problem_weight_gradient_matches_float64(variant, mode):
         gb = torch.zeros(G.shape[1], device=DEV) if bias else None
         dev_probs.append((Gd, X.to(DEV), gw, gb))
         outs.append((gw, gb))
-    with ops.using(gemm=mode, wgrad_variant=variant):
+    with ops.using(gemm=mode, wgrad_variant=variant, wgrad_workgroups=224 if variant == 2 else 0):
         train_ops._wgrad_multi(dev_probs, "test_dw")
     torch.cuda.synchronize()
     tol = (2e-5, 1e-4) if mode == "split" else (6e-3, 3e-2)
