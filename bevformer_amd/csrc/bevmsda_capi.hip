@@ -132,7 +132,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       }
       if (chunks * a.M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
       const size_t lds_bytes = (static_cast<size_t>(bevmsda::kGvBuckets) + static_cast<size_t>(s.rows_per_block) * a.P * 8 +
-                                static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4;
+                                static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4 +
+                               bevmsda::gv_stage_extra_bytes(gv_threads);
       const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(gv_threads);
       // tuning->reserved[1..2] = device address of 8 uint64 (low, high word): phase clocks of the sort kernel (tools/gvprof.py)
       unsigned long long *const pe = a.gv_prof;

@@ -53,6 +53,24 @@ constexpr int kGvThreads = 1024;     // 32 half-waves
 constexpr int kGvMaxRows = 256;      // rows of one head per workgroup
 constexpr int kGvBuckets = 4096;     // counters of the sort
 constexpr int kGvMaxLevels = 4;
+// the walk of the sorted entries: 8 = 8-lane groups with 4 channels per lane and an LDS stage for finished runs
+// (round 6), 32 = a half-wave per share, a channel per lane (round 2)
+#ifndef BEVMSDA_GV_WALK
+#define BEVMSDA_GV_WALK 8
+#endif
+// diagnostic builds only (-DBEVMSDA_GV_DIAG_NOATOMIC=1): the flush atomics are issued for one impossible sum only, everything
+// before them stays — the kernel's time without its memory-side traffic (results are wrong by construction)
+#ifndef BEVMSDA_GV_DIAG_NOATOMIC
+#define BEVMSDA_GV_DIAG_NOATOMIC 0
+#endif
+__device__ __forceinline__ void gv_flush(float *p, float v) {
+  if (BEVMSDA_GV_DIAG_NOATOMIC && v != 12345.678f) return;
+  unsafeAtomicAdd(p, v);
+}
+constexpr int kGvStageSlots = 15;                         // parked runs per wavefront (>= 8 + 7: see park())
+constexpr int kGvStageWords = 512;                        // 15 x 32 sums + 15 pixel indices, in 2 KB
+// extra LDS of a launch: workgroups of <= 512 threads park their runs in the counters' 16 KB, 1,024 threads need 32 KB
+constexpr size_t gv_stage_extra_bytes(int threads) { return BEVMSDA_GV_WALK == 8 && threads > 512 ? (threads / 64) * kGvStageWords * 4 : 0; }
 
 template <typename T> __device__ __forceinline__ float4 load_gout4(const T *p);
 template <> __device__ __forceinline__ float4 load_gout4<float>(const float *p) {
@@ -140,6 +158,9 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
   float *gl = reinterpret_cast<float *>(ent + s.rows_per_block * P * 4);
   int *wsum = reinterpret_cast<int *>(gl + static_cast<long>(s.rows_per_block) * D);
   int *misc = wsum + THREADS / 64;
+  // (wsum is sized for 1,024 threads by the launcher: the stage of a 1,024-thread workgroup starts behind it)
+  [[maybe_unused]] float *const stage = THREADS <= 512 ? reinterpret_cast<float *>(cnt)
+                                                       : reinterpret_cast<float *>(wsum + kGvThreads / 64 + 4);
   const int tid = threadIdx.x;
   const int m = blockIdx.x % a.M;
   const int chunk = blockIdx.x / a.M;
@@ -164,7 +185,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
     return (y < H0 && x < W0) ? tile_n * a.Q + y * W0 + x : -1;
   };
   const long pix_stride = a.gv_stride > 0 ? a.gv_stride : static_cast<long>(a.M * D);
-  const int half = tid >> 5;          // 32 half-waves per workgroup
+  [[maybe_unused]] const int half = tid >> 5;          // 32 half-waves per workgroup
   const int c = tid & 31;             // my channel
   // bucket of a tap: [point group | y mod 2^yb | x mod 2^xb], 12 bits
   const int gbits = s.gbits, gmask = (1 << gbits) - 1;
@@ -290,7 +311,100 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
           }
       lds_barrier();
       GV_TICK(3)
-      // ---- (4) segmented reduction: my 1/32 of the sorted entries, one atomic per pixel run
+      // ---- (4) segmented reduction, one memory-side atomic per pixel run
+#if BEVMSDA_GV_WALK == 8
+      // Round 6.  The walk is where this kernel's instructions go (round 5: 309 M wavefront instructions per base SCA call,
+      // of which ~300 M here: a half-wave per entry = 17 issue slots per TWO entries).  Now an 8-lane group owns a share
+      // of the sorted entries and a lane carries 4 channels: one wavefront instruction serves EIGHT entries, and the run
+      // logic (pixel changed?) is one compare + a wavefront-uniform branch.  A finished run is 8 lanes x float4 — not the
+      // shape of a line atomic — so it is parked in a per-wavefront LDS stage (the counters' space: they are dead during
+      // the walk) and drained by the whole wavefront, half-wave per run: still ONE 128-byte-line atomic per run.  Shares
+      // are cut at pixel changes (searched from the nominal cut, 8 candidates per step), so a share boundary does not
+      // split a run and costs no extra flush.
+      {
+        constexpr int NG = THREADS / 8;
+        constexpr int U = 4;
+        const int lane = tid & 63, gw = lane >> 3, j = tid & 7, grp = tid >> 3;
+        float *const stg = stage + (tid >> 6) * kGvStageWords;
+        int *const spx = reinterpret_cast<int *>(stg + kGvStageSlots * D);
+        // first e >= nom where a pixel run starts (or 0, or total); gives up after 32 entries (a split run costs one
+        // more atomic, never a wrong sum)
+        auto run_start = [&](int nom) -> int {
+          int res = -1;
+#pragma unroll 1
+          for (int step = 0; step < 4; ++step) {
+            const int e = nom + j;
+            bool b = e >= total || e <= 0;
+            if (!b) b = ((ent[e].x ^ ent[e - 1].x) & 0x7fffff) != 0;
+            const unsigned long long mk = __ballot(b);
+            const unsigned mine = static_cast<unsigned>(mk >> (gw * 8)) & 0xffu;
+            if (res < 0 && mine) res = nom + __ffs(mine) - 1;
+            if (res < 0) nom += 8;
+            if (__ballot(res < 0) == 0) break;
+          }
+          if (res < 0) res = nom < total ? nom : total;
+          return res < total ? res : total;
+        };
+        int e = run_start(static_cast<int>(static_cast<long>(total) * grp / NG));
+        const int e1 = grp == NG - 1 ? total : run_start(static_cast<int>(static_cast<long>(total) * (grp + 1) / NG));
+        int cur = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int nst = 0;                                   // parked runs of my wavefront (uniform)
+        const float *const glj = gl + j * 4;
+        const int half32 = lane >> 5, c32 = lane & 31;
+        auto drain = [&](int n) {
+          for (int sl = half32; sl < n; sl += 2) {
+            const float v = stg[sl * D + c32];
+            const int p = spx[sl];
+            gv_flush(gv + p * pix_stride, v);
+            if constexpr (PROF) { if (c32 == 0) atomicAdd(&s.prof[7], 1ULL); }
+          }
+        };
+        auto park = [&](bool fl) {                     // (called by the whole wavefront)
+          const unsigned long long fm = __ballot(fl);
+          if (fm) {
+            const int below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(fm >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(fm), 0u));
+            const int slot = nst + (below >> 3);
+            if (fl) {
+              *reinterpret_cast<float4 *>(stg + slot * D + j * 4) = acc;
+              if (j == 0) spx[slot] = cur;
+            }
+            nst += __popcll(fm) >> 3;
+            if (nst > kGvStageSlots - 8) { drain(nst); nst = 0; }
+          }
+        };
+        const int last = total - 1;
+        while (__ballot(e < e1)) {
+          int2 en[U];
+          float4 gg[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) en[u] = ent[e + u < last ? e + u : last];
+#pragma unroll
+          for (int u = 0; u < U; ++u) gg[u] = *reinterpret_cast<const float4 *>(glj + (static_cast<unsigned>(en[u].x) >> 23) * D);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool act = e + u < e1;
+            const int px = act ? (en[u].x & 0x7fffff) : cur;
+            const float kk = act ? __int_as_float(en[u].y) : 0.f;
+            const bool chg = px != cur;
+            if (__ballot(chg)) {
+              park(chg && cur >= 0);
+              if (chg) { acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = px; }
+            }
+            acc.x = fmaf(kk, gg[u].x, acc.x);
+            acc.y = fmaf(kk, gg[u].y, acc.y);
+            acc.z = fmaf(kk, gg[u].z, acc.z);
+            acc.w = fmaf(kk, gg[u].w, acc.w);
+          }
+          e += U;
+        }
+        park(cur >= 0);
+        drain(nst);
+        if constexpr (THREADS <= 512) lds_barrier();   // the stage is the counters' space: the next level zeroes it
+      }
+#else
+      // (round 2: a half-wave per share, lane c = channel c)
       {
         const int e0 = static_cast<int>(static_cast<long>(total) * half / (THREADS / 32));
         const int e1 = static_cast<int>(static_cast<long>(total) * (half + 1) / (THREADS / 32));
@@ -315,7 +429,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             const int px = en[j].x & 0x7fffff;
             if (px != cur) {
               if (cur >= 0) {
-                unsafeAtomicAdd(gv + cur * pix_stride, acc);
+                gv_flush(gv + cur * pix_stride, acc);
                 if constexpr (PROF) { if (c == 0) atomicAdd(&s.prof[7], 1ULL); }
               }
               cur = px;
@@ -324,8 +438,9 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             acc = fmaf(__int_as_float(en[j].y), gg[j], acc);
           }
         }
-        if (cur >= 0) unsafeAtomicAdd(gv + cur * pix_stride, acc);
+        if (cur >= 0) gv_flush(gv + cur * pix_stride, acc);
       }
+#endif
       GV_TICK(4)
       // (the next level's placement is separated from these reads by the barriers of its steps 1-3)
     }
