@@ -131,9 +131,7 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
         chunks = 1L * a.N * s.dense_tiles;
       }
       if (chunks * a.M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
-      const size_t lds_bytes = (static_cast<size_t>(bevmsda::kGvBuckets) + static_cast<size_t>(s.rows_per_block) * a.P * 8 +
-                                static_cast<size_t>(s.rows_per_block) * 32 + bevmsda::kGvThreads / 64 + 4) * 4 +
-                               bevmsda::gv_stage_extra_bytes(gv_threads);
+      const size_t lds_bytes = bevmsda::gv_lds_bytes(gv_threads, s.rows_per_block, a.P);
       const dim3 ggrid(static_cast<unsigned>(chunks * a.M)), gblock(gv_threads);
       // tuning->reserved[1..2] = device address of 8 uint64 (low, high word): phase clocks of the sort kernel (tools/gvprof.py)
       unsigned long long *const pe = a.gv_prof;
@@ -162,7 +160,8 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       } else if (gv_threads == 512) {
         auto k1 = bevmsda::msda_gradvalue_sort_kernel<T, 1, false, 512>;
         auto k2 = bevmsda::msda_gradvalue_sort_kernel<T, 2, false, 512>;
-        auto kern = rpt == 1 ? k1 : k2;
+        auto k2p = bevmsda::msda_gradvalue_sort_kernel<T, 2, true, 512>;       // phase clocks (tools/gvprof.py)
+        auto kern = rpt == 1 ? k1 : (pe ? k2p : k2);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_bytes)) != hipSuccess) return BEVMSDA_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, ggrid, gblock, lds_bytes, stream, s);

@@ -67,10 +67,22 @@ __device__ __forceinline__ void gv_flush(float *p, float v) {
   if (BEVMSDA_GV_DIAG_NOATOMIC && v != 12345.678f) return;
   unsafeAtomicAdd(p, v);
 }
-constexpr int kGvStageSlots = 15;                         // parked runs per wavefront (>= 8 + 7: see park())
-constexpr int kGvStageWords = 512;                        // 15 x 32 sums + 15 pixel indices, in 2 KB
-// extra LDS of a launch: workgroups of <= 512 threads park their runs in the counters' 16 KB, 1,024 threads need 32 KB
-constexpr size_t gv_stage_extra_bytes(int threads) { return BEVMSDA_GV_WALK == 8 && threads > 512 ? (threads / 64) * kGvStageWords * 4 : 0; }
+constexpr int kGvWalkU = 4;                               // entries a group reads ahead (and sentinel entries behind the last)
+constexpr int kGvGlStride = 36;                           // words per grad_out row in LDS: 32 + 4, so that the 64- / 128-byte
+                                                          // pieces different groups read spread over the 64 banks
+// the stage of finished runs, per wavefront: S slots of 32 sums, then S pixel indices.  A step can park one run per
+// group (8 or 16 groups per wavefront) on top of at most S - groups parked ones.
+constexpr int kGvStageSlots = BEVMSDA_GV_WALK == 4 ? 24 : 15;
+constexpr int kGvStageWords = BEVMSDA_GV_WALK == 4 ? 800 : 512;
+// LDS carve, in 4-byte words: [cnt: kGvBuckets][stage overflow][entries: (rows * P * 4 + U) x 2][grad_out rows: rows x 36]
+// [wsum 16][misc 4].  The stage starts at cnt (the counters are dead during the walk) and runs into the overflow words.
+constexpr int gv_stage_overflow_words(int threads) {
+  return BEVMSDA_GV_WALK == 32 || (threads / 64) * kGvStageWords <= kGvBuckets ? 0 : (threads / 64) * kGvStageWords - kGvBuckets;
+}
+constexpr size_t gv_lds_bytes(int threads, int rows, int P) {
+  return (static_cast<size_t>(kGvBuckets) + gv_stage_overflow_words(threads) + (static_cast<size_t>(rows) * P * 4 + kGvWalkU) * 2 +
+          static_cast<size_t>(rows) * kGvGlStride + kGvThreads / 64 + 4) * 4;
+}
 
 template <typename T> __device__ __forceinline__ float4 load_gout4(const T *p);
 template <> __device__ __forceinline__ float4 load_gout4<float>(const float *p) {
@@ -141,7 +153,7 @@ __device__ __forceinline__ int block_exclusive_scan(int *cnt, int *wsum /* THREA
     t_prev = t_;                                                                               \
   }
 
-// LDS carve (4-byte words): [cnt: kGvBuckets][entries: rows * P * 4 x 2][grad_out rows: rows * 32][wsum 16][misc 4]
+// LDS carve: gv_lds_bytes() above.
 // RPT = (row, point) records per thread and level = ceil(rows_per_block * P / THREADS).
 // THREADS = 1024 with 256 rows per workgroup (112 KB of LDS: one workgroup per CU) or 512 with 128 rows (64 KB: two
 // workgroups per CU, one sorting while the other's flushes drain, at the price of a smaller footprint per flush).
@@ -154,13 +166,11 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
   constexpr int D = 32;
   const int L = a.L, P = a.P;
   int *cnt = reinterpret_cast<int *>(lds);
-  int2 *ent = reinterpret_cast<int2 *>(cnt + kGvBuckets);
-  float *gl = reinterpret_cast<float *>(ent + s.rows_per_block * P * 4);
-  int *wsum = reinterpret_cast<int *>(gl + static_cast<long>(s.rows_per_block) * D);
-  int *misc = wsum + THREADS / 64;
-  // (wsum is sized for 1,024 threads by the launcher: the stage of a 1,024-thread workgroup starts behind it)
-  [[maybe_unused]] float *const stage = THREADS <= 512 ? reinterpret_cast<float *>(cnt)
-                                                       : reinterpret_cast<float *>(wsum + kGvThreads / 64 + 4);
+  int2 *ent = reinterpret_cast<int2 *>(cnt + kGvBuckets + gv_stage_overflow_words(THREADS));
+  float *gl = reinterpret_cast<float *>(ent + s.rows_per_block * P * 4 + kGvWalkU);
+  int *wsum = reinterpret_cast<int *>(gl + static_cast<long>(s.rows_per_block) * kGvGlStride);
+  int *misc = wsum + kGvThreads / 64;
+  [[maybe_unused]] float *const stage = reinterpret_cast<float *>(cnt);
   const int tid = threadIdx.x;
   const int m = blockIdx.x % a.M;
   const int chunk = blockIdx.x / a.M;
@@ -202,7 +212,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
       gq = load_gout4<T>(static_cast<const T *>(a.grad_out) + (grow * a.M + m) * D + q4);
       if (a.gout_rows > 0) { gq.x *= a.gout_scale; gq.y *= a.gout_scale; gq.z *= a.gout_scale; gq.w *= a.gout_scale; }
     }
-    reinterpret_cast<float4 *>(gl)[i] = gq;
+    *reinterpret_cast<float4 *>(gl + row * kGvGlStride + q4) = gq;
   }
 
   // sub-ranges of rows that share a value batch entry (rows are grouped by camera: normally one)
@@ -301,6 +311,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
       // ---- (3) scan, place
       const int total = block_exclusive_scan<THREADS>(cnt, wsum);
       GV_TICK(2)
+      if (tid < kGvWalkU) ent[total + tid] = make_int2(0, 0);   // what the walk reads past the last entry: coefficient 0
 #pragma unroll
       for (int j = 0; j < RPT; ++j)
 #pragma unroll
@@ -312,19 +323,22 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
       lds_barrier();
       GV_TICK(3)
       // ---- (4) segmented reduction, one memory-side atomic per pixel run
-#if BEVMSDA_GV_WALK == 8
+#if BEVMSDA_GV_WALK == 8 || BEVMSDA_GV_WALK == 4
       // Round 6.  The walk is where this kernel's instructions go (round 5: 309 M wavefront instructions per base SCA call,
-      // of which ~300 M here: a half-wave per entry = 17 issue slots per TWO entries).  Now an 8-lane group owns a share
-      // of the sorted entries and a lane carries 4 channels: one wavefront instruction serves EIGHT entries, and the run
-      // logic (pixel changed?) is one compare + a wavefront-uniform branch.  A finished run is 8 lanes x float4 — not the
-      // shape of a line atomic — so it is parked in a per-wavefront LDS stage (the counters' space: they are dead during
-      // the walk) and drained by the whole wavefront, half-wave per run: still ONE 128-byte-line atomic per run.  Shares
-      // are cut at pixel changes (searched from the nominal cut, 8 candidates per step), so a share boundary does not
-      // split a run and costs no extra flush.
+      // most of them here: a half-wave per entry = 17 issue slots per TWO entries).  Now a group of LG = 8 (4) lanes owns
+      // a share of the sorted entries and a lane carries 4 (8) channels: one wavefront instruction serves 8 (16) entries,
+      // and the run logic (pixel changed?) is one compare + a wavefront-uniform branch.  A finished run is LG lanes x
+      // float4 — not the shape of a line atomic — so it is parked in a per-wavefront LDS stage (the counters' space: they
+      // are dead during the walk) and drained by the whole wavefront, half-wave per run: still ONE 128-byte-line atomic
+      // per run.  Shares are cut at pixel changes (searched from the nominal cut, LG candidates per step), so a share
+      // boundary does not split a run and costs no extra flush.
       {
-        constexpr int NG = THREADS / 8;
-        constexpr int U = 4;
-        const int lane = tid & 63, gw = lane >> 3, j = tid & 7, grp = tid >> 3;
+        constexpr int LG = BEVMSDA_GV_WALK, LGS = LG == 8 ? 3 : 2;
+        constexpr int NV = D / LG / 4;                 // float4 per lane: 1 or 2
+        constexpr int NGW = 64 / LG;                   // groups per wavefront
+        constexpr int NG = THREADS / LG;
+        constexpr int U = kGvWalkU;
+        const int lane = tid & 63, gw = lane >> LGS, j = lane & (LG - 1), grp = tid >> LGS;
         float *const stg = stage + (tid >> 6) * kGvStageWords;
         int *const spx = reinterpret_cast<int *>(stg + kGvStageSlots * D);
         // first e >= nom where a pixel run starts (or 0, or total); gives up after 32 entries (a split run costs one
@@ -332,25 +346,28 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
         auto run_start = [&](int nom) -> int {
           int res = -1;
 #pragma unroll 1
-          for (int step = 0; step < 4; ++step) {
+          for (int step = 0; step < 32 / LG; ++step) {
             const int e = nom + j;
             bool b = e >= total || e <= 0;
             if (!b) b = ((ent[e].x ^ ent[e - 1].x) & 0x7fffff) != 0;
             const unsigned long long mk = __ballot(b);
-            const unsigned mine = static_cast<unsigned>(mk >> (gw * 8)) & 0xffu;
+            const unsigned mine = static_cast<unsigned>(mk >> (gw * LG)) & ((1u << LG) - 1u);
             if (res < 0 && mine) res = nom + __ffs(mine) - 1;
-            if (res < 0) nom += 8;
+            if (res < 0) nom += LG;
             if (__ballot(res < 0) == 0) break;
           }
-          if (res < 0) res = nom < total ? nom : total;
+          if (res < 0) res = nom;
           return res < total ? res : total;
         };
         int e = run_start(static_cast<int>(static_cast<long>(total) * grp / NG));
         const int e1 = grp == NG - 1 ? total : run_start(static_cast<int>(static_cast<long>(total) * (grp + 1) / NG));
-        int cur = -1;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        GV_TICK(5)
+        int nrem = e1 - e;
+        int cur = nrem > 0 ? (ent[e].x & 0x7fffff) : -1;   // my first run is open from the start: every change parks a run
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         int nst = 0;                                   // parked runs of my wavefront (uniform)
-        const float *const glj = gl + j * 4;
         const int half32 = lane >> 5, c32 = lane & 31;
         auto drain = [&](int n) {
           for (int sl = half32; sl < n; sl += 2) {
@@ -360,48 +377,63 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             if constexpr (PROF) { if (c32 == 0) atomicAdd(&s.prof[7], 1ULL); }
           }
         };
-        auto park = [&](bool fl) {                     // (called by the whole wavefront)
-          const unsigned long long fm = __ballot(fl);
-          if (fm) {
-            const int below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(fm >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(fm), 0u));
-            const int slot = nst + (below >> 3);
-            if (fl) {
-              *reinterpret_cast<float4 *>(stg + slot * D + j * 4) = acc;
-              if (j == 0) spx[slot] = cur;
-            }
-            nst += __popcll(fm) >> 3;
-            if (nst > kGvStageSlots - 8) { drain(nst); nst = 0; }
+        auto park = [&](bool fl, unsigned long long fm) {   // fm = ballot(fl), not 0; called by the whole wavefront
+          const int below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(fm >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(fm), 0u));
+          const int slot = nst + (below >> LGS);
+          if (fl) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(stg + slot * D + v * (LG * 4) + j * 4) = acc[v];
+            spx[slot] = cur;                           // (the same word from every lane of the group)
           }
+          nst += __popcll(fm) >> LGS;
+          if (nst > kGvStageSlots - NGW) { drain(nst); nst = 0; }
         };
-        const int last = total - 1;
-        while (__ballot(e < e1)) {
+        const float *const glj = gl + j * 4;
+        const int2 *ep = ent + e;
+        while (__ballot(nrem > 0)) {
           int2 en[U];
-          float4 gg[U];
+          float4 gg[U][NV];
 #pragma unroll
-          for (int u = 0; u < U; ++u) en[u] = ent[e + u < last ? e + u : last];
+          for (int u = 0; u < U; ++u) en[u] = ep[u];    // (past my share: the next group's entries or the sentinels)
 #pragma unroll
-          for (int u = 0; u < U; ++u) gg[u] = *reinterpret_cast<const float4 *>(glj + (static_cast<unsigned>(en[u].x) >> 23) * D);
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+              gg[u][v] = *reinterpret_cast<const float4 *>(glj + (static_cast<unsigned>(en[u].x) >> 23) * kGvGlStride + v * (LG * 4));
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const bool act = e + u < e1;
+            const bool act = u < nrem;
             const int px = act ? (en[u].x & 0x7fffff) : cur;
             const float kk = act ? __int_as_float(en[u].y) : 0.f;
             const bool chg = px != cur;
-            if (__ballot(chg)) {
-              park(chg && cur >= 0);
-              if (chg) { acc = make_float4(0.f, 0.f, 0.f, 0.f); cur = px; }
+            const unsigned long long cm = __ballot(chg);
+            if (cm) {
+              park(chg, cm);
+              if (chg) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                cur = px;
+              }
             }
-            acc.x = fmaf(kk, gg[u].x, acc.x);
-            acc.y = fmaf(kk, gg[u].y, acc.y);
-            acc.z = fmaf(kk, gg[u].z, acc.z);
-            acc.w = fmaf(kk, gg[u].w, acc.w);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              acc[v].x = fmaf(kk, gg[u][v].x, acc[v].x);
+              acc[v].y = fmaf(kk, gg[u][v].y, acc[v].y);
+              acc[v].z = fmaf(kk, gg[u][v].z, acc[v].z);
+              acc[v].w = fmaf(kk, gg[u][v].w, acc[v].w);
+            }
           }
-          e += U;
+          ep += nrem > U ? U : 0;                      // (a finished group keeps re-reading entries that exist: what follows
+          nrem -= U;                                   // the sentinels is not an entry, and 0 x garbage may be a NaN)
         }
-        park(cur >= 0);
+        {
+          const bool fl = cur >= 0;
+          const unsigned long long fm = __ballot(fl);
+          if (fm) park(fl, fm);
+        }
         drain(nst);
-        if constexpr (THREADS <= 512) lds_barrier();   // the stage is the counters' space: the next level zeroes it
+        lds_barrier();                                 // the stage is the counters' space: the next level zeroes it
       }
 #else
       // (round 2: a half-wave per share, lane c = channel c)
@@ -423,7 +455,7 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
             if (!in) en[j].y = 0;
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) gg[j] = gl[(en[j].x >> 23) * D + c];
+          for (int j = 0; j < 8; ++j) gg[j] = gl[(en[j].x >> 23) * kGvGlStride + c];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int px = en[j].x & 0x7fffff;

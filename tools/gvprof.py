@@ -12,7 +12,7 @@ from bevformer_amd.synthetic import make_sca_msda_case, make_tsa_msda_case  # no
 
 DEV = "cuda:0"
 names = ["grad_out + record loads", "zero + count (2 barriers)", "scan (2 barriers)", "place (1 barrier)",
-         "segmented reduce + flush", "-", "tail"]
+         "segmented reduce + flush", "share boundaries (walk 8)", "tail"]
 def image_sorted(case):
     from bevformer_amd.modules.geometry import _morton_key
     v, sh, st, loc, attn, hits = case
