@@ -67,7 +67,10 @@ __device__ __forceinline__ void gv_flush(float *p, float v) {
   if (BEVMSDA_GV_DIAG_NOATOMIC && v != 12345.678f) return;
   unsafeAtomicAdd(p, v);
 }
-constexpr int kGvWalkU = 4;                               // entries a group reads ahead (and sentinel entries behind the last)
+#ifndef BEVMSDA_GV_WALK_U
+#define BEVMSDA_GV_WALK_U 4
+#endif
+constexpr int kGvWalkU = BEVMSDA_GV_WALK_U;                               // entries a group reads ahead (and sentinel entries behind the last)
 constexpr int kGvGlStride = 36;                           // words per grad_out row in LDS: 32 + 4, so that the 64- / 128-byte
                                                           // pieces different groups read spread over the 64 banks
 // the stage of finished runs, per wavefront: S slots of 32 sums, then S pixel indices.  A step can park one run per
