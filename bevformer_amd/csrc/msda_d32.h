@@ -35,12 +35,16 @@ namespace bevmsda {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kOobOffset = 0x80000000u;  // > num_records of any eligible tensor
+// cache-policy bits of the tap loads (A/B builds: -DBEVMSDA_TAP_AUX=1 sc0, 2 nt, 16 sc1; measured in round 6, see DESIGN K1f)
+#ifndef BEVMSDA_TAP_AUX
+#define BEVMSDA_TAP_AUX 0
+#endif
 
 template <typename T> struct TapLoad;
 template <> struct TapLoad<float> {
   static constexpr int kBytes = 16;
   static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, 0);
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, BEVMSDA_TAP_AUX);
     f32x4 o;
     o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]);
     o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
@@ -50,7 +54,7 @@ template <> struct TapLoad<float> {
 template <> struct TapLoad<bf16_t> {
   static constexpr int kBytes = 8;
   static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    auto v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, 0);
+    auto v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, BEVMSDA_TAP_AUX);
     f32x4 o;
     o[0] = bf16_lo(v[0]); o[1] = bf16_hi(v[0]); o[2] = bf16_lo(v[1]); o[3] = bf16_hi(v[1]);
     return o;

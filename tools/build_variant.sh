@@ -7,6 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 cd "$root/bevformer_amd/csrc"
 obj=../lib/obj/${src%.hip}_$name.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed "$@" -c $src -o $obj
-objs=$(ls ../lib/obj/*.o | grep -v "_exp\|_var" | grep -v "/${src%.hip}.o" | grep -v "${src%.hip}_" ; echo $obj)
+# every default object except SOURCE's own (default objects are exactly the csrc/*.hip names; other variants' objects are skipped)
+objs=$(for f in *.hip; do [ "$f" = "$src" ] || echo ../lib/obj/${f%.hip}.o; done; echo $obj)
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libbevmsda_$name.so $objs
 echo built bevformer_amd/lib/libbevmsda_$name.so
