@@ -95,6 +95,31 @@ def test_forward_backward_bf16(case):
     torch.testing.assert_close(gl.cpu(), wl, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("rows", [64, 128, 256])
+@pytest.mark.parametrize("case", [(3, 300, 8, 32, [(16, 26), (8, 13), (4, 7), (2, 4)], 8),    # SCA-like: 4 levels, 8 points
+                                  (2, 1600, 8, 32, [(40, 40)], 4),                            # TSA-like: rows = a 40 x 40 grid
+                                  (2, 333, 8, 32, [(9, 11), (4, 6)], 4)])
+def test_grad_value_sort_kernel_at_every_workgroup_shape(case, rows):
+    """``bevmsda_tuning.reserved[0]`` = 64 / 128 / 256 rows per workgroup of the LDS-sorting grad_value kernel (256 / 512 / 1,024
+    threads: 4 / 8 / 16 wavefronts share the stage of finished runs, which overflows the counters' space at 16).  Row counts
+    that leave the last workgroup nearly empty: its walk reads the sentinel entries, never what lies behind them (round 6: a
+    finished lane group that kept advancing multiplied a zero coefficient with stale LDS words — NaN in one test only)."""
+    N, Q, M, D, shapes, P = case
+    value, sh, start, loc, attn = make_msda_case(N, Q, M, D, shapes, P, seed=21)
+    g = torch.randn(N, Q, M * D, generator=torch.Generator().manual_seed(22))
+    wv, wl, wa = msda_c.backward(value, sh, start, loc, attn, g)
+    args = _gpu(value, sh, start, loc, attn)
+    t = _lib.Tuning()
+    t.reserved[0] = rows
+    for _ in range(2):
+        gv = torch.zeros_like(args[0]); gl = torch.empty_like(args[3]); ga = torch.empty_like(args[4])
+        ext.ms_deform_attn_backward(*args, g.to(DEV), gv, gl, ga, tuning=ctypes.byref(t))
+        assert torch.isfinite(gv).all()
+        torch.testing.assert_close(gv.cpu(), wv, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(ga.cpu(), wa, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gl.cpu(), wl, rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("qtile,xcd,variant", [(1, 1, 0), (1, 2, 0), (8, 1, 0), (32, 2, 0),
                                                (128, 2, 0), (8, 2, 2), (8, 2, 1), (1, 2, 1),
                                                (8, 2, 3), (1, 1, 4), (32, 2, 5), (3, 2, 3)])
