@@ -87,13 +87,30 @@ constexpr size_t gv_lds_bytes(int threads, int rows, int P) {
           static_cast<size_t>(rows) * kGvGlStride + kGvThreads / 64 + 4) * 4;
 }
 
+// The kernel's operands are read once (records, grad_out rows) while the lines its flush atomics touch are revisited by the
+// workgroups of neighbouring rows: -DBEVMSDA_GV_STREAM_NT=1 marks the reads non-temporal so that they do not push those
+// lines out of the L2 (round 6 A/B, DESIGN K2).
+#ifndef BEVMSDA_GV_STREAM_NT
+#define BEVMSDA_GV_STREAM_NT 0
+#endif
+typedef float gv_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gv_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gv_u32x2 __attribute__((ext_vector_type(2)));
+template <typename V> __device__ __forceinline__ V gv_stream_load(const V *p) {
+#if BEVMSDA_GV_STREAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 template <typename T> __device__ __forceinline__ float4 load_gout4(const T *p);
 template <> __device__ __forceinline__ float4 load_gout4<float>(const float *p) {
-  return *reinterpret_cast<const float4 *>(p);
+  const gv_f32x4 t = gv_stream_load(reinterpret_cast<const gv_f32x4 *>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
 }
 template <> __device__ __forceinline__ float4 load_gout4<bf16_t>(const bf16_t *p) {
-  const uint2 t = *reinterpret_cast<const uint2 *>(p);
-  return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
+  const gv_u32x2 t = gv_stream_load(reinterpret_cast<const gv_u32x2 *>(p));
+  return make_float4(bf16_lo(t[0]), bf16_hi(t[0]), bf16_lo(t[1]), bf16_hi(t[1]));
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on
@@ -255,8 +272,9 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
           const int pr = phys(r0 + rw);
           if (pr >= 0) {
             const long pi = ((static_cast<long>(pr) * a.M + m) * L + l) * P + p;
-            xy[l][j] = reinterpret_cast<const float2 *>(a.loc)[pi];
-            aw[l][j] = a.attn[pi];
+            const gv_f32x2 t2 = gv_stream_load(reinterpret_cast<const gv_f32x2 *>(a.loc) + pi);
+            xy[l][j] = make_float2(t2[0], t2[1]);
+            aw[l][j] = gv_stream_load(a.attn + pi);
           }
         }
       }
