@@ -30,6 +30,7 @@ using bevmsda::bf16_t;
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
 constexpr int kGvRowsPerBlock = 256;         // rows of one head per workgroup of the LDS-tiled grad_value kernel
+constexpr int kTsaPipeGrid = 1024;           // resident workgroups of the pipelined TSA sampling kernel: 4 per CU, 128 per XCD
 constexpr long kDynGridBlocks = 2048;        // grid of the device-row-count sampling launches (multiple of 8)
                                              // (128 rows with 320 + 128 pixels, two workgroups per CU: 320 us vs 270 us)
 
@@ -497,7 +498,20 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   if (d->reserved[5] < 0 || d->reserved[5] > 3) return BEVMSDA_ERR_BAD_OPTION;
   const bool specable = sizeof(T) == 4 && d->M == 8 && a.qtile == 8 && d->reserved[0] == 0;
   const bool spec = specable && d->reserved[5] == 3;
-  if (specable && d->reserved[5] == 2 && d->P == 4 && d->K == 2 && d->L == 1) {
+  // TemporalSelfAttention's shape in the resident, software-pipelined grid (msda_d32.h, round 6) once there is more than one
+  // round of workgroups to pipeline over; -DBEVMSDA_TSA_PIPE=0 keeps one workgroup per logical block
+#ifndef BEVMSDA_TSA_PIPE
+#define BEVMSDA_TSA_PIPE 1
+#endif
+  if (BEVMSDA_TSA_PIPE && specable && d->reserved[5] == 0 && d->P == 4 && d->K == 2 && d->L == 1 && nb >= 2 * kTsaPipeGrid && d->R < (1LL << 24) && !row_batch && !row_src && d->R == d->Q &&
+      d->R * static_cast<long long>(d->proj_row) < (1LL << 29) && d->R * static_cast<long long>(d->K) * d->A < (1LL << 28)) {
+#ifndef BEVMSDA_TSA_PIPE_WPE
+#define BEVMSDA_TSA_PIPE_WPE 4
+#endif
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL((bevmsda::msda_fused_d32_tsa_pipe_kernel<T, BEVMSDA_TSA_PIPE_WPE>), dim3(kTsaPipeGrid / 4 * BEVMSDA_TSA_PIPE_WPE),
+                         dim3(256), 0, st, f);
+  } else if (specable && d->reserved[5] == 2 && d->P == 4 && d->K == 2 && d->L == 1) {
     hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 8, 1, 8>), grid, dim3(256), 0, st, f);
   } else if (specable && d->reserved[5] != 1 && d->P == 4 && d->K == 2 && d->L == 1) {
     hipLaunchKernelGGL((bevmsda::msda_fused_d32_kernel<T, 4, 2, 4, 1, 8>), grid, dim3(256), 0, st, f);

@@ -381,6 +381,100 @@ msda_fused_d32_kernel(const FusedArgs f) {
   msda_fused_d32_body<T, PT, KT, false, LC, MC>(f, logical_block(f.k), f.k.NQ, threadIdx.x);
 }
 
+// TemporalSelfAttention's shape (fp32, 8 heads, ONE level, 2 queue entries x 4 points, qtile 8) in a resident grid with the
+// front end of the NEXT block under the taps of this one (round 6).  With one level a lane group's life is: parameter loads
+// (one trip to memory) -> softmax / locations -> 32 taps -> store; nothing of it overlaps inside a wavefront, and the
+// wavefronts of a CU spend ~40 % of their time with no tap in flight (the kernel ran at 52 % of the gather ceiling where
+// SpatialCrossAttention's four-level loop, which prefetches the next level's record, reaches 68 %).  Here 1,024 workgroups
+// (4 per CU) stay resident; workgroup w of XCD x takes the logical blocks x * per + w, + 128, + 256 .. of that XCD's range
+// (the window of blocks an XCD works on at any time is the same as with one workgroup per block), and the logits / offsets /
+// reference of block i + 1 are requested BEFORE the taps of block i.  Same arithmetic, same order of sums: bit-equal to
+// msda_fused_d32_kernel<float, 4, 2, 4, 1, 8>.
+// The launcher takes this kernel for ONE batch entry without row indirection (R == Q, no row_batch, no row_src: the
+// encoder's call): consecutive blocks of a workgroup are then 4 x (workgroups per XCD) rows apart with the same head and
+// lane roles, so the front end of the next block is three loads at fixed strides from this one's — a handful of live
+// registers across the taps (a first version recomputed every address per block: at 128 registers hipcc spilled
+// lane-constant 64-bit temporaries, and each reload from scratch drew an `s_waitcnt vmcnt(0)` in front of the prefetch).
+template <typename T, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_tsa_pipe_kernel(const FusedArgs f) {
+  constexpr int D = 32, PT = 4, NP = 8, Mh = 8;
+  const KArgs &a = f.k;
+  const int tid = threadIdx.x, lig = tid & 7;
+  const int per = (a.nblocks + 7) >> 3;                      // logical blocks per XCD range (as logical_block())
+  const int wpx = static_cast<int>(gridDim.x >> 3);          // workgroups per XCD
+  const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+  const int hi = (x + 1) * per < a.nblocks ? (x + 1) * per : a.nblocks;
+  int lb = x * per + w;
+  if (lb >= hi) return;
+  const int H = static_cast<int>(a.shapes[0]), W = static_cast<int>(a.shapes[1]);
+  const uint32_t pix_bytes = static_cast<uint32_t>(Mh) * D * sizeof(T);
+  const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
+  const uint32_t lbytes = static_cast<uint32_t>(a.lstart[0]) * pix_bytes;
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  const float sc = f.out_scale;
+  const float inv_w = static_cast<float>(W), inv_h = static_cast<float>(H);
+  // my (row, head) of the first block; the next ones are `rstep` rows further
+  const uint32_t G = static_cast<uint32_t>(lb) * 32u + static_cast<uint32_t>(tid >> 3);
+  const uint32_t rr = G & 63u, m = rr >> 3;
+  uint32_t r = ((G >> 6) << 3) + (rr & 7u);
+  const uint32_t NQ = static_cast<uint32_t>(a.NQ);
+  const uint32_t rstep = 4u * static_cast<uint32_t>(wpx);
+  const uint32_t q = lig / PT, pj = lig % PT;
+  const uint32_t n = q * static_cast<uint32_t>(f.vadd);                                        // (batch entry 0)
+  const uint32_t level_base = static_cast<uint32_t>((static_cast<unsigned long long>(n) * a.S * Mh + m) * D * sizeof(T)) + lbytes;
+  const uint32_t rc = r < NQ ? r : NQ - 1;
+  // (front-end operands through raw buffer descriptors: one 32-bit byte offset per stream instead of a 64-bit address pair)
+  const auto whole = [](const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000); };
+  const __amdgpu_buffer_rsrc_t lg_rs = whole(f.logits), of_rs = whole(f.offs), rf_rs = whole(f.ref);
+  uint32_t lg_b = (rc * static_cast<uint32_t>(f.proj_row) + m * f.lg_head + q * f.lg_k + pj) * 4u;
+  uint32_t of_b = (rc * static_cast<uint32_t>(f.proj_row) + m * f.off_head + q * f.off_k + 2u * pj) * 4u;
+  uint32_t rf_b = ((rc * f.K + q) * f.A + (f.ref_mode == 0 ? pj % f.A : 0)) * 8u;
+  uint32_t out_i = (r * Mh + m) * D + lig * 4;
+  const uint32_t lg_s = rstep * static_cast<uint32_t>(f.proj_row) * 4u, rf_s = rstep * f.K * f.A * 8u, out_s = rstep * Mh * D;
+  const auto ld1 = [](__amdgpu_buffer_rsrc_t rs, uint32_t b) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(b), 0, 0)); };
+  const auto ld2 = [](__amdgpu_buffer_rsrc_t rs, uint32_t b) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, static_cast<int>(b), 0, 0);
+    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+  };
+  float lg = ld1(lg_rs, lg_b);
+  float2 of = ld2(of_rs, of_b), rf = ld2(rf_rs, rf_b);
+#pragma nounroll
+  for (;;) {
+    const bool more = lb + wpx < hi;                          // (uniform)
+    const bool active = r < NQ;
+    const float lg0 = lg;
+    const float2 of0 = of, rf0 = rf;
+    const uint32_t out0 = out_i;
+    if (more) {                                               // the next block's front end, under this block's taps
+      lb += wpx;
+      r += rstep;
+      out_i += out_s;
+      if (r < NQ) { lg_b += lg_s; of_b += lg_s; rf_b += rf_s; }     // (rows beyond the last re-read the previous block's: valid memory)
+      lg = ld1(lg_rs, lg_b);
+      of = ld2(of_rs, of_b);
+      rf = ld2(rf_rs, rf_b);
+    }
+    // softmax over the PT logits of my (row, head, queue entry)
+    const float mx = lanes_max<PT>(lg0);
+    const float e = expf(lg0 - mx);
+    const float sum = lanes_sum<PT>(e);
+    const float lx = rf0.x + of0.x / inv_w;
+    const float ly = rf0.y + of0.y / inv_h;
+    const float aw = active ? e / sum : 0.f;
+    const PointParams p = point_params(lx, ly, aw, H, W, level_base, pix_bytes);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sample_points<0, NP, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
+    if (active) {
+      T *op = static_cast<T *>(a.out) + out0;
+      *reinterpret_cast<float4 *>(op) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
+    }
+    if (!more) break;
+  }
+}
+
 // The same kernel over a device-side row count (DynRows): head = one workgroup per logical block of
 // the hinted count, tail = a small strided grid for rows beyond the hint.
 template <typename T, int PT, int KT, int WPE, bool SAVE = false, int LC = 0, int MC = 0>
