@@ -382,7 +382,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   // desc->reserved[5] (kernel-body selection, A/B knob: values below) is validated HERE, for every path: it only acts on
   // the static-row fp32 launches, and the other paths (device-side row count: values 0, 1, 3; bf16 storage: 0, 1) must
   // not accept a value they would silently ignore — an A/B run would then report the knob as set and measure the default
-  if (d->reserved[5] < 0 || d->reserved[5] > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->reserved[5] < 0 || d->reserved[5] > 4) return BEVMSDA_ERR_BAD_OPTION;
   if (sizeof(T) == 2 && d->reserved[5] > 1) return BEVMSDA_ERR_BAD_OPTION;
   if (nrows && d->reserved[5] == 2) return BEVMSDA_ERR_BAD_OPTION;
   bevmsda::FusedArgs f{};
@@ -495,15 +495,17 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   // TemporalSelfAttention's shape (8 heads, one level, two queue entries) on the specialised body at 128 registers
   // (70 vs 72.4 us; at 64 registers it spills: 131 us); 1 = generic kernels only; 2 = that body at 64 registers;
   // 3 = SpatialCrossAttention's shape specialised too (no gain: the kernel is bound by the L1 / TA path)
-  if (d->reserved[5] < 0 || d->reserved[5] > 3) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->reserved[5] < 0 || d->reserved[5] > 4) return BEVMSDA_ERR_BAD_OPTION;
   const bool specable = sizeof(T) == 4 && d->M == 8 && a.qtile == 8 && d->reserved[0] == 0;
   const bool spec = specable && d->reserved[5] == 3;
-  // TemporalSelfAttention's shape in the resident, software-pipelined grid (msda_d32.h, round 6) once there is more than one
-  // round of workgroups to pipeline over; -DBEVMSDA_TSA_PIPE=0 keeps one workgroup per logical block
+  // TemporalSelfAttention's shape in the resident, software-pipelined grid (msda_d32.h, round 6): 68.3 against 70.6 us per launch,
+  // but the resident workgroups drift apart and with them the band of history rows the XCD's L2 has to hold — 2.49 M L2 misses
+  // per launch against 1.29 M, 319 MB of counter traffic against 165 MB (profiles/r6x) — so it is opt-in (reserved[5] = 4, or
+  // -DBEVMSDA_TSA_PIPE=1 to make it the default), and only once there is more than one round of workgroups to pipeline over
 #ifndef BEVMSDA_TSA_PIPE
-#define BEVMSDA_TSA_PIPE 1
+#define BEVMSDA_TSA_PIPE 0
 #endif
-  if (BEVMSDA_TSA_PIPE && specable && d->reserved[5] == 0 && d->P == 4 && d->K == 2 && d->L == 1 && nb >= 2 * kTsaPipeGrid && d->R < (1LL << 24) && !row_batch && !row_src && d->R == d->Q &&
+  if (specable && (d->reserved[5] == 4 || (BEVMSDA_TSA_PIPE && d->reserved[5] == 0)) && d->P == 4 && d->K == 2 && d->L == 1 && nb >= 2 * kTsaPipeGrid && d->R < (1LL << 24) && !row_batch && !row_src && d->R == d->Q &&
       d->R * static_cast<long long>(d->proj_row) < (1LL << 29) && d->R * static_cast<long long>(d->K) * d->A < (1LL << 28)) {
 #ifndef BEVMSDA_TSA_PIPE_WPE
 #define BEVMSDA_TSA_PIPE_WPE 4

@@ -43,7 +43,8 @@ class Modes:
         self.fused_wpe = int(env("BEVMSDA_FUSED_WPE", "0"))         # benchmark knob: register budget of the fused kernel
         # fused sampling kernels with compile-time head / level counts (msda_d32.h LC / MC), the library's reserved[5]: 0 =
         # default (TemporalSelfAttention's shape specialised at 128 registers), 1 = generic kernels only, 2 = TSA's at 64
-        # registers, 3 = SpatialCrossAttention's shape specialised too (A/B knobs; profiles/r5)
+        # registers, 3 = SpatialCrossAttention's shape specialised too (A/B knobs; profiles/r5), 4 = TSA's shape on the
+        # resident, software-pipelined grid (round 6: 3 % faster, twice the L2 misses — opt-in; profiles/r6x)
         self.fused_spec = int(env("BEVMSDA_FUSED_SPEC", "0"))
         # sampling launches over a device-side row count: 1 = ONE launch sized by the row CAPACITY (surplus workgroups return on
         # their first instruction), 0 = a launch sized by the host's hint + a small strided tail launch for rows beyond it

@@ -204,7 +204,8 @@ typedef struct bevmsda_fused_desc {
                             [5] (fp32 entry points, benchmark knob): bodies with compile-time head / level counts —
                             0 = default (the 8-head, one-level, two-entry shape of TemporalSelfAttention at 128
                             registers), 1 = generic kernels only, 2 = that body at 64 registers, 3 = the 8-head,
-                            4-level shape of SpatialCrossAttention specialised too (no gain: profiles/r5) */
+                            4-level shape of SpatialCrossAttention specialised too (no gain: profiles/r5), 4 = TemporalSelfAttention's
+                            shape on a resident, software-pipelined grid (3 % faster, twice the L2 misses: profiles/r6x) */
 } bevmsda_fused_desc;
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,

@@ -140,6 +140,21 @@ def test_fused_tsa_kernel_at_the_full_base_grid():
     want = _oracle_msda_fused(value, shapes, start, proj[rows], n_off, ref[rows], torch.zeros(len(rows), dtype=torch.int32),
                               **{**kw, "Q": 0})
     torch.testing.assert_close(out.cpu()[rows], want, rtol=1e-4, atol=1e-5)
+    # the opt-in resident, software-pipelined form of this launch (bevmsda_fused_desc.reserved[5] = 4) computes the same sums in
+    # the same order: bit-equal over the whole grid; the generic kernel (1) within round-off
+    from bevformer_amd.ops import _base
+    m = _base._m()
+    keep = m.fused_spec
+    try:
+        for spec in (4, 1):
+            m.fused_spec = spec
+            alt = ops.msda_fused(value.to(DEV), shapes.to(DEV), start.to(DEV), proj.to(DEV), n_off, ref.to(DEV), None, **kw)
+            if spec == 4:
+                assert torch.equal(alt, out), spec
+            else:
+                torch.testing.assert_close(alt, out, rtol=1e-5, atol=1e-6)
+    finally:
+        m.fused_spec = keep
 
 
 def _gradient_case(name, storage, l2_tol, max_tol):

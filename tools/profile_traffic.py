@@ -37,6 +37,8 @@ def classify(name):
         nums = [x for x in a if x.isdigit()]
         if len(nums) >= 2:
             return {("8", "1"): "sca_fwd", ("4", "2"): "tsa_fwd", ("4", "1"): "tsa_fwd_first_frame"}.get((nums[0], nums[1]))
+    if "msda_fused_d32_tsa_pipe_kernel" in name:      # round 6: TSA's resident-grid form (K = 2 queue entries, 4 points)
+        return "tsa_fwd"
     if "msda_gradvalue_sort_kernel" in name:
         return "grad_value_sort:" + re.sub(r".*kernel", "", name)
     if "msda_gradloc_d32" in name:
@@ -66,6 +68,12 @@ def collect(config, out):
     for f in ("kernel_stats.csv", "pmc.json", "failed_passes.txt"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(out, f))
+    derive(config, out)
+
+
+def derive(config, out):
+    """pmc.json of a collected configuration -> traffic.json (also ``--rederive`` here, e.g. after ``classify`` learnt a new kernel name)."""
+    c = CONFIGS[config]
     pmc = json.load(open(os.path.join(out, "pmc.json")))
     kernels = {}
     for name, d in pmc.items():
@@ -139,9 +147,17 @@ def main():
     ap.add_argument("--config", default="base_fwd", choices=sorted(CONFIGS))
     ap.add_argument("--tag", default="r3")
     ap.add_argument("--install", action="store_true")
+    ap.add_argument("--rederive", action="store_true", help="recompute traffic.json of every collected configuration from its pmc.json")
     a = ap.parse_args()
+    if a.rederive:
+        base = os.path.join(ROOT, "gpurun_out", "profile_traffic")
+        for config in sorted(os.listdir(base)):
+            if config in CONFIGS and os.path.exists(os.path.join(base, config, "pmc.json")):
+                derive(config, os.path.join(base, config))
     if a.install:
         install(a.tag)
+    elif a.rederive:
+        pass
     else:
         collect(a.config, os.path.join(ROOT, "gpurun_out", "profile_traffic", a.config))
 
