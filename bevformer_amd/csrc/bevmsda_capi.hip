@@ -29,7 +29,6 @@ using bevmsda::bf16_t;
 // library defaults (chosen from the sweeps recorded in DESIGN.md)
 constexpr int kDefaultQtileFwd = 8;
 constexpr int kDefaultQtileBwd = 8;
-constexpr int kGvRowsPerBlock = 256;         // rows of one head per workgroup of the LDS-tiled grad_value kernel
 constexpr int kTsaPipeGrid = 1024;           // resident workgroups of the pipelined TSA sampling kernel: 4 per CU, 128 per XCD
 constexpr long kDynGridBlocks = 2048;        // grid of the device-row-count sampling launches (multiple of 8)
                                              // (128 rows with 320 + 128 pixels, two workgroups per CU: 320 us vs 270 us)
@@ -106,15 +105,21 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
     const int gcap = a.L == 1 ? BEVMSDA_GV_GROUPS_SINGLE : BEVMSDA_GV_GROUPS_MULTI;
     if (G > gcap) G = gcap;
     // (entries carry the pixel index of a level in 23 bits and the row of the block in 8)
-    // 256 rows / 1024 threads per workgroup (one per CU) for single-level calls (TemporalSelfAttention: the
-    // 16 x 16 grid tiles), 128 rows / 512 threads (two per CU: one sorts while the other's flushes drain) for
-    // multi-level calls — measured on the padded base SCA call, image-ordered rows: 1.13 vs 1.27 ms (raster rows:
-    // 2.10 vs 1.88 ms; TSA 0.90 vs 0.42 ms).  tuning->reserved[0] = 64 / 128 / 256 forces one.
+    // 128 rows / 512 threads per workgroup (two per CU: one sorts while the other's flushes drain) — measured on the padded base
+    // SCA call, image-ordered rows, against 256 rows / 1,024 threads (one per CU): 1.13 vs 1.27 ms in round 2, 0.97 vs 1.01 ms
+    // on round 6's walk (64 rows: 1.15).  Dense single-level calls (TemporalSelfAttention) take grid tiles of that many rows
+    // instead of consecutive rows (until round 6 only the 256-row shape had tiles: 0.42 ms against 0.90 ms for 128 CONSECUTIVE
+    // rows; with 16 x 8 tiles the two-per-CU shape is ahead there too).  tuning->reserved[0] = 64 / 128 / 256 forces one.
     const int gv_forced = a.gv_rows;           // bevmsda_tuning.reserved[0]
 #ifndef BEVMSDA_GV_ROWS_MULTI
 #define BEVMSDA_GV_ROWS_MULTI 128
 #endif
-    const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? BEVMSDA_GV_ROWS_MULTI : kGvRowsPerBlock);
+    // (single-level dense calls — TemporalSelfAttention's grid in 16 x (rows / 16) tiles: 16 x 8 tiles on two workgroups per CU
+    // measured 267 vs 273-278 us for sort + gather at base, profiles/r6/r6q_gv_rows_tsa_tiles_ab.txt)
+#ifndef BEVMSDA_GV_ROWS_SINGLE
+#define BEVMSDA_GV_ROWS_SINGLE 128
+#endif
+    const int gv_rows = gv_forced == 64 || gv_forced == 128 || gv_forced == 256 ? gv_forced : (a.L > 1 ? BEVMSDA_GV_ROWS_MULTI : BEVMSDA_GV_ROWS_SINGLE);
     const int gv_threads = gv_rows == 64 ? 256 : (gv_rows == 128 ? 512 : bevmsda::kGvThreads);
     const int rpt = (gv_rows * a.P + gv_threads - 1) / gv_threads;
     bool tiled = a.variant != 3 && a.L >= 1 && a.L <= bevmsda::kGvMaxLevels && a.P >= 1 && (rpt == 1 || rpt == 2);   // P <= 8: 112 KB of LDS
@@ -126,9 +131,9 @@ int launch_grouped(const KArgs &base, hipStream_t stream) {
       s.rows_per_block = gv_rows;
       s.gbits = G == 4 ? 2 : (G == 2 ? 1 : 0);
       long chunks = (a.NQ + s.rows_per_block - 1) / s.rows_per_block;
-      if (!a.row_batch && a.L == 1 && a.Q >= 1024 && s.rows_per_block == 256) {
-        // dense single-level call: room for the 16 x 16 tiles of a roughly square grid (msda_bwd_lds.h)
-        s.dense_tiles = static_cast<int>(1LL * a.Q * 3 / (256 * 2) + 4);
+      if (!a.row_batch && a.L == 1 && a.Q >= 1024) {
+        // dense single-level call: room for the 16 x (rows / 16) tiles of a roughly square grid (msda_bwd_lds.h)
+        s.dense_tiles = static_cast<int>(1LL * a.Q * 3 / (s.rows_per_block * 2) + 4 * (256 / s.rows_per_block));
         chunks = 1L * a.N * s.dense_tiles;
       }
       if (chunks * a.M >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;

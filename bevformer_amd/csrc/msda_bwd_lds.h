@@ -36,10 +36,10 @@
 namespace bevmsda {
 
 struct GradValueArgs {
-  int dense_tiles;     // > 0 (dense single-level calls, rows_per_block = 256): the launch has this many row
+  int dense_tiles;     // > 0 (dense single-level calls, rows_per_block = 64 / 128 / 256): the launch has this many row
                        // chunks per batch entry; when the level is an H0 x W0 grid with Q = H0 * W0 (read on
                        // the device: TemporalSelfAttention, whose rows are the BEV grid in raster order) and
-                       // its 16 x 16 tiles fit that count, chunk t takes tile t of the grid instead of 256
+                       // its 16 x (rows_per_block / 16) tiles fit that count, chunk t takes tile t of the grid instead of that many
                        // consecutive rows — any row order gives the same sums, this one makes the rows of a
                        // workgroup share taps
   KArgs k;             // value unused; loc, attn, grad_out, grad_value, row_batch, NQ, N, S, M, L, Q, P
@@ -196,21 +196,22 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
   const int chunk = blockIdx.x / a.M;
   // virtual row -> row of the operands (-1: a tile cell outside the grid)
   const int W0 = static_cast<int>(a.shapes[1]), H0 = static_cast<int>(a.shapes[0]);
-  const int tile_w = (W0 + 15) >> 4, tile_h = (H0 + 15) >> 4;
+  const int th = s.rows_per_block >> 4;                                      // tiles are 16 cells wide, rows_per_block / 16 high
+  const int tile_w = (W0 + 15) >> 4, tile_h = (H0 + th - 1) / th;
   const bool tiled = s.dense_tiles > 0 && static_cast<long>(H0) * W0 == a.Q && tile_w * tile_h <= s.dense_tiles;
   // (row counts fit 31 bits: checked by the launcher)
-  const int vq = tiled ? s.dense_tiles * 256 : a.Q;                           // virtual rows per batch entry
+  const int vq = tiled ? s.dense_tiles * s.rows_per_block : a.Q;                           // virtual rows per batch entry
   const int vrows = tiled ? vq * a.N : static_cast<int>(effective_rows(a));    // (device-side row count: ragged calls)
   const int c0 = chunk * s.rows_per_block;
   if (c0 >= vrows) return;
   const int c1 = c0 + s.rows_per_block < vrows ? c0 + s.rows_per_block : vrows;
   const int my_tile = tiled ? chunk % s.dense_tiles : 0;                      // tiled: one chunk = one tile
   if (tiled && my_tile >= tile_w * tile_h) return;
-  const int tile_y0 = tiled ? (my_tile / tile_w) * 16 : 0, tile_x0 = tiled ? (my_tile % tile_w) * 16 : 0;
+  const int tile_y0 = tiled ? (my_tile / tile_w) * th : 0, tile_x0 = tiled ? (my_tile % tile_w) * 16 : 0;
   const int tile_n = tiled ? chunk / s.dense_tiles : 0;
   auto phys = [&](int vr) -> int {
     if (!tiled) return vr;
-    const int w = vr - c0;                                                    // 0 .. 255 inside my tile
+    const int w = vr - c0;                                                    // 0 .. rows_per_block - 1 inside my tile
     const int y = tile_y0 + (w >> 4), x = tile_x0 + (w & 15);
     return (y < H0 && x < W0) ? tile_n * a.Q + y * W0 + x : -1;
   };
