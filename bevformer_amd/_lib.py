@@ -33,6 +33,12 @@ class FusedDesc(ctypes.Structure):
                 ("reserved", ctypes.c_int32 * 6)]
 
 
+class LocSource(ctypes.Structure):
+    """Mirror of ``struct bevmsda_loc_source``."""
+    _fields_ = [("offs", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("row_src", ctypes.c_void_p),
+                ("proj_row", ctypes.c_int64), ("off_head", ctypes.c_int32), ("A", ctypes.c_int32)]
+
+
 class LinearDesc(ctypes.Structure):
     """Mirror of ``struct bevmsda_linear_desc``."""
     _fields_ = [("M", ctypes.c_int64), ("ldx0", ctypes.c_int64), ("lda0", ctypes.c_int64),
@@ -93,6 +99,10 @@ SIGNATURES = {
                                     + [_c_void_p] * 3, _c_int),
     "bevmsda_backward_rows_f32": ([_c_void_p] * 8 + _DIMS + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
     "bevmsda_backward_rows_bf16": ([_c_void_p] * 8 + _DIMS + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
+    "bevmsda_backward_rows_offs_f32": ([_c_void_p] * 3 + [ctypes.POINTER(LocSource)] + [_c_void_p] * 4 + _DIMS
+                                       + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
+    "bevmsda_backward_rows_offs_bf16": ([_c_void_p] * 3 + [ctypes.POINTER(LocSource)] + [_c_void_p] * 4 + _DIMS
+                                        + [_c_void_p, ctypes.c_int64] + [_c_void_p] * 3, _c_int),
     "bevmsda_frontend_expand_rows_f32": ([_c_void_p] * 7 + [ctypes.POINTER(FusedDesc)] + [_c_void_p] * 4, _c_int),
     "bevmsda_cast_rows_bf16": ([_c_void_p, _c_void_p, ctypes.c_int64, _c_int, ctypes.c_float, _c_void_p, _c_void_p], _c_int),
     "bevmsda_rows_from_slots_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, ctypes.c_int64, _c_int,

@@ -316,8 +316,16 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
                   const float *attn, const T *grad_out, int N, int S, int M, int D, int L, int Q,
                   int P, float *grad_value, float *grad_loc, float *grad_attn, void *stream,
                   const bevmsda_tuning *tuning, const int32_t *row_batch = nullptr, int R = -1,
-                  const int32_t *nrows_dev = nullptr, long gout_rows = 0, float gout_scale = 1.f, long gv_stride = 0) {
+                  const int32_t *nrows_dev = nullptr, long gout_rows = 0, float gout_scale = 1.f, long gv_stride = 0,
+                  const bevmsda_loc_source *ls = nullptr) {
   const int Nv = N;
+  if (ls) {          // locations recomputed from the fused forward's operands: the rows form of the second-generation kernels only
+    if (!ls->offs || !ls->ref) return BEVMSDA_ERR_NULL_POINTER;
+    if (loc || !nrows_dev || R < 0) return BEVMSDA_ERR_UNSUPPORTED;
+    if (ls->A < 1 || ls->proj_row < 0 || ls->off_head < 0 || ls->proj_row % 2 != 0 || ls->off_head % 2 != 0) return BEVMSDA_ERR_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(ls->offs) & 7u) != 0 || (reinterpret_cast<uintptr_t>(ls->ref) & 7u) != 0) return BEVMSDA_ERR_MISALIGNED;
+    loc = ls->offs;   // (for the operand checks below; the kernels get KArgs::loc = nullptr)
+  }
   if (R >= 0) {
     if (R > 0 && !row_batch) return BEVMSDA_ERR_NULL_POINTER;
     N = 1;
@@ -333,6 +341,11 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lstart, 
     return BEVMSDA_ERR_MISALIGNED;
   KArgs a{};
   a.value = value; a.shapes = shapes; a.lstart = lstart; a.loc = loc; a.attn = attn;
+  if (ls) {
+    a.loc = nullptr;
+    a.loc_offs = ls->offs; a.loc_ref = ls->ref; a.loc_row_src = ls->row_src;
+    a.loc_proj_row = static_cast<long>(ls->proj_row); a.loc_off_head = ls->off_head; a.loc_A = ls->A;
+  }
   a.grad_out = grad_out; a.grad_value = grad_value; a.grad_loc = grad_loc; a.grad_attn = grad_attn;
   a.row_batch = (R >= 0) ? row_batch : nullptr;
   a.NQ = 1L * N * Q; a.N = Nv; a.S = S; a.M = M; a.D = D; a.L = L; a.Q = Q; a.P = P;
@@ -398,9 +411,9 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   a.mshift = ilog2_exact(a.M); a.qshift = ilog2_exact(a.qtile);
   // SAVE kernels (training forward): SCA's shape only — device-side row count, one queue entry, 8 points, several levels
   const bool save = save_loc != nullptr || save_attn != nullptr;
-  if (save && (!save_loc || !save_attn)) return BEVMSDA_ERR_NULL_POINTER;
+  if (save && !save_attn) return BEVMSDA_ERR_NULL_POINTER;      // (save_loc may be null: the backward recomputes the locations)
   if (save && (!nrows || d->K != 1 || d->P != 8 || d->L < 2)) return BEVMSDA_ERR_UNSUPPORTED;
-  if (save && (misaligned(save_loc) || misaligned(save_attn))) return BEVMSDA_ERR_MISALIGNED;
+  if (save && ((save_loc && misaligned(save_loc)) || misaligned(save_attn))) return BEVMSDA_ERR_MISALIGNED;
   f.save_loc = save_loc; f.save_attn = save_attn;
   f.offs = offs; f.logits = logits; f.ref = ref; f.row_src = row_src; f.proj_row = d->proj_row;
   f.off_head = d->off_head; f.off_k = d->off_k; f.lg_head = d->lg_head; f.lg_k = d->lg_k;
@@ -686,6 +699,26 @@ int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_sha
                                grad_value, grad_loc, grad_attn, stream, nullptr, row_batch, R, nrows, 0, 1.f, static_cast<long>(grad_value_stride));
 }
 
+int bevmsda_backward_rows_offs_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const bevmsda_loc_source *loc_source, const float *attn, const int32_t *row_batch,
+                                   const float *grad_out, const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                                   float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!nrows || !loc_source) return BEVMSDA_ERR_NULL_POINTER;
+  return backward_impl<float>(value, spatial_shapes, level_start, nullptr, attn, grad_out, N, S, M, D, L, 0, P, grad_value, grad_loc,
+                              grad_attn, stream, nullptr, row_batch, R, nrows, 0, 1.f, static_cast<long>(grad_value_stride), loc_source);
+}
+
+int bevmsda_backward_rows_offs_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const bevmsda_loc_source *loc_source, const float *attn, const int32_t *row_batch,
+                                    const uint16_t *grad_out, const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                                    float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream) {
+  if (R < 0) return BEVMSDA_ERR_BAD_SHAPE;
+  if (!nrows || !loc_source) return BEVMSDA_ERR_NULL_POINTER;
+  return backward_impl<bf16_t>(value, spatial_shapes, level_start, nullptr, attn, grad_out, N, S, M, D, L, 0, P, grad_value, grad_loc,
+                               grad_attn, stream, nullptr, row_batch, R, nrows, 0, 1.f, static_cast<long>(grad_value_stride), loc_source);
+}
+
 int bevmsda_backward_shared_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *loc,
                                 const float *attn, const float *grad_out, int64_t grad_rows, float grad_scale, int N, int S, int M,
                                 int D, int L, int Q, int P, float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn,
@@ -775,7 +808,7 @@ int bevmsda_fused_forward_rows_save_f32(const float *value, const int64_t *spati
                                         const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
                                         const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
                                         float *save_loc, float *save_attn, void *stream) {
-  if (!nrows || !save_loc || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
+  if (!nrows || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
   return fused_impl<float>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out, stream, nrows,
                            save_loc, save_attn);
 }
@@ -784,7 +817,7 @@ int bevmsda_fused_forward_rows_save_bf16(const uint16_t *value, const int64_t *s
                                          const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
                                          const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc,
                                          uint16_t *out, float *save_loc, float *save_attn, void *stream) {
-  if (!nrows || !save_loc || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
+  if (!nrows || !save_attn) return BEVMSDA_ERR_NULL_POINTER;
   return fused_impl<bf16_t>(value, spatial_shapes, level_start, offs, logits, ref, row_batch, row_src, desc, out, stream, nrows,
                             save_loc, save_attn);
 }

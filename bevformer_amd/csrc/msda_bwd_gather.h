@@ -130,7 +130,8 @@ msda_gradloc_d32_kernel(const KArgs a) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
                                                                   static_cast<int>(total_bytes), 0x00020000);
   const int pj = lig % PT;          // the point this lane owns (PT = 4: both halves of the group own 0..3)
-  const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * PT + pj;
+  const float2 *__restrict__ lp = loc_records(a, nq, m) + pj;       // (locations, or raw offsets + the reference point below)
+  const float2 lrf = loc_reference(a, nq, pj);
   const float *__restrict__ ap = a.attn + row * L * PT + pj;
   float2 *__restrict__ glp = reinterpret_cast<float2 *>(a.grad_loc) + row * L * PT + pj;
   float *__restrict__ gap = a.grad_attn + row * L * PT + pj;
@@ -148,7 +149,8 @@ msda_gradloc_d32_kernel(const KArgs a) {
   for (int l = 0; l < L; ++l) {
     const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
     const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
-    const GradPointParams p = grad_point_params(xy.x, xy.y, H, W, head_base + lbytes, pix_bytes);
+    const float2 at = loc_of_record(a, xy, lrf, H, W);
+    const GradPointParams p = grad_point_params(at.x, at.y, H, W, head_base + lbytes, pix_bytes);
     const float aw_l = aw;
     if (l + 1 < L) {                // next level's record travels under this level's taps
       xy = lp[(l + 1) * PT];
@@ -250,7 +252,8 @@ msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
                                                                   static_cast<int>(total_bytes), 0x00020000);
   const int pj = lig % PT;
-  const float2 *__restrict__ lp = reinterpret_cast<const float2 *>(a.loc) + row * L * PT + pj;
+  const float2 *__restrict__ lp = loc_records(a, nq, m) + pj;       // (locations, or raw offsets + the reference point below)
+  const float2 lrf = loc_reference(a, nq, pj);
   const float *__restrict__ ap = a.attn + row * L * PT + pj;
   float2 *__restrict__ glp = reinterpret_cast<float2 *>(a.grad_loc) + row * L * PT + pj;
   float *__restrict__ gap = a.grad_attn + row * L * PT + pj;
@@ -268,7 +271,8 @@ msda_gradloc_d32_bf16x8_kernel(const KArgs a) {
   for (int l = 0; l < L; ++l) {
     const int H = static_cast<int>(a.shapes[2 * l]), W = static_cast<int>(a.shapes[2 * l + 1]);
     const uint32_t lbytes = static_cast<uint32_t>(a.lstart[l]) * pix_bytes;
-    const GradPointParams p = grad_point_params(xy.x, xy.y, H, W, head_base + lbytes, pix_bytes);
+    const float2 at = loc_of_record(a, xy, lrf, H, W);
+    const GradPointParams p = grad_point_params(at.x, at.y, H, W, head_base + lbytes, pix_bytes);
     const float aw_l = aw;
     if (l + 1 < L) {
       xy = lp[(l + 1) * PT];

@@ -257,6 +257,19 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
     const int grow0 = r0 - c0;                         // first row of the sub-range inside gl
     const int nrec = nrows * P;                        // records per level
 
+    // level geometry up front as well: a load inside the level loop would wait on vmcnt and with it on every
+    // flush atomic still in flight (the counter retires in order)
+    int Hs[kGvMaxLevels], Ws[kGvMaxLevels];
+    long ls[kGvMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kGvMaxLevels; ++l) {
+      const int ll = l < L ? l : 0;
+      // (readfirstlane pins the loads here — the scheduler would otherwise sink them back into the loop —
+      // and keeps the uniform values in SGPRs)
+      Hs[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll]));
+      Ws[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll + 1]));
+      ls[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.lstart[ll]));
+    }
     // every record of every level of my rows, loaded up front (the only trips to memory on the critical
     // path; a later wait for loads would also drain the wave's outstanding flush atomics)
     float2 xy[kGvMaxLevels][RPT];
@@ -273,27 +286,15 @@ __global__ void __launch_bounds__(THREADS) msda_gradvalue_sort_kernel(const Grad
           const int pr = phys(r0 + rw);
           if (pr >= 0) {
             const long pi = ((static_cast<long>(pr) * a.M + m) * L + l) * P + p;
-            const gv_f32x2 t2 = gv_stream_load(reinterpret_cast<const gv_f32x2 *>(a.loc) + pi);
-            xy[l][j] = make_float2(t2[0], t2[1]);
+            const gv_f32x2 t2 = gv_stream_load(reinterpret_cast<const gv_f32x2 *>(loc_records(a, pr, m)) + l * P + p);
+            // (KArgs::loc == nullptr: t2 is the raw offset; the location is the forward's reference + offset / (W_l, H_l))
+            xy[l][j] = loc_of_record(a, make_float2(t2[0], t2[1]), loc_reference(a, pr, p), Hs[l], Ws[l]);
             aw[l][j] = gv_stream_load(a.attn + pi);
           }
         }
       }
     GV_TICK(0)
 
-    // level geometry up front as well: a load inside the level loop would wait on vmcnt and with it on every
-    // flush atomic still in flight (the counter retires in order)
-    int Hs[kGvMaxLevels], Ws[kGvMaxLevels];
-    long ls[kGvMaxLevels];
-#pragma unroll
-    for (int l = 0; l < kGvMaxLevels; ++l) {
-      const int ll = l < L ? l : 0;
-      // (readfirstlane pins the loads here — the scheduler would otherwise sink them back into the loop —
-      // and keeps the uniform values in SGPRs)
-      Hs[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll]));
-      Ws[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.shapes[2 * ll + 1]));
-      ls[l] = __builtin_amdgcn_readfirstlane(static_cast<int>(a.lstart[ll]));
-    }
 #pragma unroll
     for (int l = 0; l < kGvMaxLevels; ++l) {
       if (l >= L) break;

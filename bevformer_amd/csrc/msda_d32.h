@@ -36,6 +36,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kOobOffset = 0x80000000u;  // > num_records of any eligible tensor
 // cache-policy bits of the tap loads (A/B builds: -DBEVMSDA_TAP_AUX=1 sc0, 2 nt, 16 sc1; measured in round 6, see DESIGN K1f)
+// diagnostic build only (-DBEVMSDA_DIAG_NO_SAVE_LOC=1): the training forward keeps its attention weights but not its sampling
+// locations (wrong gradients by construction) — what the location stores cost the kernel
+#ifndef BEVMSDA_DIAG_NO_SAVE_LOC
+#define BEVMSDA_DIAG_NO_SAVE_LOC 0
+#endif
 #ifndef BEVMSDA_TAP_AUX
 #define BEVMSDA_TAP_AUX 0
 #endif
@@ -351,7 +356,9 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
     if constexpr (SAVE) {
       if (live) {                   // (r, m, l, pj): 64 + 32 contiguous bytes per (row, head, level)
         const long o = ((r * Mh + m) * L + l) * PT + pj;
-        reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);
+#if !BEVMSDA_DIAG_NO_SAVE_LOC
+        if (f.save_loc) reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);     // (nullptr: the backward recomputes them)
+#endif
         f.save_attn[o] = aw;
       }
     }
@@ -600,7 +607,9 @@ __device__ __forceinline__ void msda_fused_d32_bf16x8_body(const FusedArgs &f, i
     if constexpr (SAVE) {
       if (live) {
         const long o = ((r * a.M + m) * L + l) * PT + pj;
-        reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);
+#if !BEVMSDA_DIAG_NO_SAVE_LOC
+        if (f.save_loc) reinterpret_cast<float2 *>(f.save_loc)[o] = make_float2(lx, ly);     // (nullptr: the backward recomputes them)
+#endif
         f.save_attn[o] = aw;
       }
     }

@@ -62,7 +62,31 @@ struct KArgs {
   float gout_scale;              // the operands reads scale * grad_out[r % gout_rows] — the queue entries of
                                  // TemporalSelfAttention share one output row (their mean: scale = 1 / entries); 0: one
                                  // grad_out row per operand row, scale ignored
+  // backward (second-generation D = 32 kernels, rows form): loc == nullptr — the sampling locations are not an operand but
+  // recomputed from what the fused forward kernel read (msda_d32.h, K = 1, ref_mode 0), with the forward's own expression:
+  //   loc(r, m, l, p) = loc_ref[r * loc_A + p % loc_A] + loc_offs[rs * loc_proj_row + m * loc_off_head + (l * P + p) * 2 + {0, 1}] / (W_l, H_l)
+  // (rs = loc_row_src ? loc_row_src[r] : r) — the training forward then keeps 4 bytes per point (its attention weight) instead of 12
+  const float *loc_offs, *loc_ref;
+  const int32_t *loc_row_src;
+  long loc_proj_row;
+  int loc_off_head, loc_A;
 };
+
+// the (L, P) float2 records of (row nq, head m) — locations, or (loc == nullptr) raw offsets — and the reference point of point p
+__device__ __forceinline__ const float2 *loc_records(const KArgs &a, long nq, int m) {
+  if (a.loc) return reinterpret_cast<const float2 *>(a.loc) + (nq * a.M + m) * a.L * a.P;
+  const long rs = a.loc_row_src ? static_cast<long>(a.loc_row_src[nq]) : nq;
+  return reinterpret_cast<const float2 *>(a.loc_offs + rs * a.loc_proj_row + static_cast<long>(m) * a.loc_off_head);
+}
+__device__ __forceinline__ float2 loc_reference(const KArgs &a, long nq, int p) {
+  if (a.loc) return make_float2(0.f, 0.f);
+  return reinterpret_cast<const float2 *>(a.loc_ref)[nq * a.loc_A + p % a.loc_A];
+}
+// a record -> the location the forward sampled at (msda_fused_d32_body: lx = rf.x + of.x / W, the same two operations)
+__device__ __forceinline__ float2 loc_of_record(const KArgs &a, float2 rec, float2 rf, int H, int W) {
+  if (a.loc) return rec;
+  return make_float2(rf.x + rec.x / static_cast<float>(W), rf.y + rec.y / static_cast<float>(H));
+}
 
 // rows the launch has to process: the host's NQ, or the device-side count below it
 __device__ __forceinline__ long effective_rows(const KArgs &a) {

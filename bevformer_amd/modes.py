@@ -56,7 +56,12 @@ class Modes:
         self.stack_free = env("BEVMSDA_STACK_FREE", "1") == "1"      # inference: TSA's [history ; queries] value projected without forming the stack
         self.weight_views = env("BEVMSDA_WEIGHT_VIEWS", "1") == "1"  # training: W^T images packed from W (no transposed copies)
         self.flatten_params = env("BEVMSDA_FLATTEN_PARAMS", "1") == "1"  # training: merged projections' parameters back to back (views, no cat)
-        self.fused_save = env("BEVMSDA_FUSED_SAVE", "1") == "1"      # training: SCA's forward kernel writes the locations / weights its backward reads
+        # training: what SCA's forward kernel writes for its backward — 1 = locations and weights (round 5, the default), 2 = the
+        # attention weights only (round 6: the backward kernels recompute the locations from the projection rows,
+        # bevmsda_backward_rows_offs_*: 564 MB less kept per base step, bit-equal gradients, the same step time — the forward kernel's
+        # 32 us come back in the backward kernels' row_src -> offset indirection, profiles/r6/r6t_fused_save_ab.txt), 0 = nothing
+        # (a bevmsda_frontend_expand_rows_f32 pass in the backward recomputes both)
+        self.fused_save = int(env("BEVMSDA_FUSED_SAVE", "1"))
         self.chain_backward = env("BEVMSDA_CHAIN_BWD", "1") == "1"   # training: the row-local backward of the SCA seam in one kernel
         self.chain_shape = int(env("BEVMSDA_CHAIN_SHAPE", "0"))     # benchmark knob: workgroup shape of the row-chain kernels
         self.grad_thread = env("BEVMSDA_GRAD_THREAD", "1") == "1"   # training: value-projection input gradients summed in the GEMMs

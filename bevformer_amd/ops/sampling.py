@@ -154,7 +154,7 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     rows; R above is then the capacity of the row arrays and the returned tensor has that many
     rows, of which only the first ``nrows`` are written (``bevmsda_fused_forward_rows_*``);
     ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint).
-    ``save = (loc (R, M, L, P, 2), attn (R, M, L, P))`` fp32 (with ``nrows``; K = 1, P = 8, L >= 2): the kernel also
+    ``save = (loc (R, M, L, P, 2) or None, attn (R, M, L, P))`` fp32 (with ``nrows``; K = 1, P = 8, L >= 2): the kernel also
     writes the sampling locations and attention weights its rows used (``bevmsda_fused_forward_rows_save_*``) — what the
     operator's backward reads."""
     unknown = set(retired) - _RETIRED_FUSED_KWARGS
@@ -212,12 +212,12 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                 extra = ()
                 if save is not None:
                     sl, sa = save
-                    _req(sl.dtype == torch.float32 and sa.dtype == torch.float32 and sl.is_contiguous() and sa.is_contiguous()
-                         and sl.numel() == R * M * L * P * 2 and sa.numel() == R * M * L * P,
-                         "bevmsda: save = (loc (R, M, L, P, 2), attn (R, M, L, P)) contiguous fp32 tensors")
+                    _req(sa.dtype == torch.float32 and sa.is_contiguous() and sa.numel() == R * M * L * P
+                         and (sl is None or (sl.dtype == torch.float32 and sl.is_contiguous() and sl.numel() == R * M * L * P * 2)),
+                         "bevmsda: save = (loc (R, M, L, P, 2) or None, attn (R, M, L, P)) contiguous fp32 tensors")
                     fnr = lib.bevmsda_fused_forward_rows_save_f32 if store == torch.float32 \
                         else lib.bevmsda_fused_forward_rows_save_bf16
-                    extra = (_ptr(sl), _ptr(sa))
+                    extra = (_ptr(sl) if sl is not None else None, _ptr(sa))
                 else:
                     fnr = lib.bevmsda_fused_forward_rows_f32 if store == torch.float32 \
                         else lib.bevmsda_fused_forward_rows_bf16
@@ -278,9 +278,14 @@ class _FusedSampleFunction(Function):
                 and meta["vmul"] == 1 and meta["vadd"] == 0 and row_batch is not None and _m().fused_save \
                 and not (_m().value_storage == torch.bfloat16 and _m().bf16_lanes8):
             Rr, Mh, Lv, Pp = row_src.numel(), meta["M"], meta["L"], meta["P"]
-            saved = (torch.empty((Rr, Mh, Lv, Pp, 2), dtype=torch.float32, device=vs.device),
+            # fused_save = 2: the weights only — 4 of the 12 bytes per sampling point; the backward kernels recompute the locations
+            # from proj / ref with the forward's own expression (bevmsda_backward_rows_offs_*; pillar-anchor references only)
+            lean = _m().fused_save == 2 and meta["ref_mode"] == 0 and proj.stride(0) % 2 == 0 and meta["off_head"] % 2 == 0 \
+                and proj.data_ptr() % 8 == 0
+            saved = (None if lean else torch.empty((Rr, Mh, Lv, Pp, 2), dtype=torch.float32, device=vs.device),
                      torch.empty((Rr, Mh, Lv, Pp), dtype=torch.float32, device=vs.device))
             dyn["save"] = saved
+            saved = tuple(t for t in saved if t is not None)
         out = _pkg().msda_fused(vs, shapes, start, proj.detach(), n_off, ref, row_batch, row_src=row_src,
                          tag=tag, **meta, **dyn)
         if out is None:
@@ -317,7 +322,10 @@ class _FusedSampleFunction(Function):
         lib = _lib.load()
         st = torch.cuda.current_stream().cuda_stream
         RK = R * K
-        if kept is not None:
+        lean = kept is not None and len(kept) == 1          # the forward kept its weights only: locations from proj / ref
+        if lean:
+            loc, attn, rbk = None, kept[0], row_batch
+        elif kept is not None:
             loc, attn, rbk = kept[0], kept[1], row_batch        # (K = 1: the value batch entry of a row is its row_batch)
         else:
             loc = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
@@ -370,7 +378,7 @@ class _FusedSampleFunction(Function):
                 gvs = 0 if gv is None else gv.stride(1)
             if gv is None:
                 gv = torch.zeros(value.shape, dtype=torch.float32, device=dev)
-            gl = torch.empty_like(loc)
+            gl = torch.empty((RK, M, L, P, 2), dtype=torch.float32, device=dev)
             ga = torch.empty_like(attn)
             # algorithmic bytes of the operator's backward: value + locations + weights + grad_out read,
             # grad_value + grad_loc + grad_attn written
@@ -381,7 +389,13 @@ class _FusedSampleFunction(Function):
                 alg = ("per_row", value.numel() * value.element_size() + value.numel() * 4,
                        M * L * P * 24 + M * D * g.element_size())
             with (cb(ctx.tag.replace("_fwd", "") + "_bwd", alg) if cb is not None else _NoTimer()):
-                if nrows is not None:
+                if lean:
+                    src = _lib.LocSource(offs=proj.data_ptr(), ref=_ptr(ref), row_src=_ptr(row_src), proj_row=proj.stride(0),
+                                         off_head=m["off_head"], A=A)
+                    _lib.check((lib.bevmsda_backward_rows_offs_bf16 if bf else lib.bevmsda_backward_rows_offs_f32)(
+                        _ptr(value), _ptr(shapes), _ptr(start), ctypes.byref(src), _ptr(attn), _ptr(rbk), _ptr(g), nrows.data_ptr(),
+                        N, S, M, D, L, RK, P, _ptr(gv), gvs, _ptr(gl), _ptr(ga), st), "fused backward: operator (rows, locations recomputed)")
+                elif nrows is not None:
                     _lib.check((lib.bevmsda_backward_rows_bf16 if bf else lib.bevmsda_backward_rows_f32)(
                         _ptr(value), _ptr(shapes), _ptr(start), _ptr(loc), _ptr(attn), _ptr(rbk), _ptr(g), nrows.data_ptr(),
                         N, S, M, D, L, RK, P, _ptr(gv), gvs, _ptr(gl), _ptr(ga), st), "fused backward: operator (rows)")

@@ -132,6 +132,33 @@ int bevmsda_backward_rows_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
                                float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream);
 
+/* bevmsda_backward_rows_* WITHOUT the sampling locations as an operand (round 6): when the forward was
+ * bevmsda_fused_forward_rows_save_* with save_loc = NULL, the backward kernels recompute every location from what that
+ * forward read, with its own two operations (spatial_cross_attention.py:357-372: reference + offset / (W_l, H_l)):
+ *   loc(r, m, l, p) = ref[(r * A + p % A) * 2 + c] + offs[row_src[r] * proj_row + m * off_head + (l * P + p) * 2 + c] / (W_l, H_l)[c]
+ * (row_src NULL: row r itself; one queue entry, pillar-anchor references: the K = 1, ref_mode = 0 form of
+ * bevmsda_fused_desc).  `attn` stays an operand (the forward's save_attn).  What multi_scale_deformable_attn_function.py
+ * :94-128 keeps for backward shrinks from 12 to 4 bytes per sampling point (564 MB of a bevformer_base training step); the
+ * step takes the same time — what the forward kernel gains without its location stores (32 us of 335 per layer) the backward
+ * kernels spend on the row_src -> offset indirection (profiles/r6/r6t_fused_save_ab.txt, r6s_save_loc_cost.txt).
+ * offs / ref 8-byte aligned, proj_row and off_head even; else as bevmsda_backward_rows_*. */
+typedef struct bevmsda_loc_source {
+  const float *offs;        /* sampling-offset projections (the fused forward's `offs`) */
+  const float *ref;         /* reference points (R, A, 2), normalised (x, y) */
+  const int32_t *row_src;   /* optional: projection row of operand row r */
+  int64_t proj_row;         /* floats between two projection rows */
+  int32_t off_head;         /* floats between two heads' offsets inside a row */
+  int32_t A;                /* reference points per row: point p uses anchor p % A */
+} bevmsda_loc_source;
+int bevmsda_backward_rows_offs_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const bevmsda_loc_source *loc_source, const float *attn, const int32_t *row_batch,
+                                   const float *grad_out, const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                                   float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream);
+int bevmsda_backward_rows_offs_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const bevmsda_loc_source *loc_source, const float *attn, const int32_t *row_batch,
+                                    const uint16_t *grad_out, const int32_t *nrows, int N, int S, int M, int D, int L, int R, int P,
+                                    float *grad_value, int64_t grad_value_stride, float *grad_loc, float *grad_attn, void *stream);
+
 /* bevmsda_backward_* whose N * Q operand rows SHARE `grad_rows` rows of grad_out: row r reads grad_scale *
  * grad_out[r % grad_rows] — TemporalSelfAttention averages its queue entries (temporal_self_attention.py:257-262), so the
  * N = 2 entries of a query receive the same output gradient times 1 / 2; no repeated, pre-scaled copy of it is formed.
@@ -242,7 +269,8 @@ int bevmsda_fused_forward_rows_bf16(const uint16_t *value, const int64_t *spatia
  * sampling locations reference + offset / (W_l, H_l) (spatial_cross_attention.py:357-372), save_attn (R, M, L, P) = the
  * softmax over the L * P logits of a head (:340-348) — the operands `sampling_locations` / `attention_weights` that
  * multi_scale_deformable_attn_function.py:94-128 saves for backward.  Rows [0, *nrows) are written.  The backward then
- * needs no bevmsda_frontend_expand_rows_f32 pass. */
+ * needs no bevmsda_frontend_expand_rows_f32 pass.  save_loc may be NULL: the locations are then not written and the
+ * backward is bevmsda_backward_rows_offs_* (above), which recomputes them. */
 int bevmsda_fused_forward_rows_save_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                         const float *offs, const float *logits, const float *ref, const int32_t *row_batch,
                                         const int32_t *row_src, const int32_t *nrows, const bevmsda_fused_desc *desc, float *out,
