@@ -165,6 +165,9 @@ SIGNATURES = {
     "bevmsda_linear_panel_segments_f32": ([_c_void_p] * 3 + [ctypes.POINTER(LinearDesc), _c_void_p, ctypes.c_int64, _c_void_p,
                                            _c_int, _c_void_p, _c_void_p], _c_int),
     "bevmsda_proj_ffn_chain_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p], _c_int),
+    "bevmsda_proj_ffn_chain_tail_f32": ([_c_void_p] * 14 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p, ctypes.c_int64,
+                                         _c_void_p, ctypes.c_int64, _c_void_p, _c_void_p, _c_int, _c_void_p, ctypes.c_int64,
+                                         _c_void_p], _c_int),
     "bevmsda_proj_ln_proj_chain_f32": ([_c_void_p] * 10 + [ctypes.POINTER(ChainDesc), _c_void_p, _c_void_p, _c_void_p], _c_int),
     "bevmsda_linear_wgrad_f32": ([_c_void_p, ctypes.c_int64, _c_void_p, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int,
                                   _c_void_p, ctypes.c_int64, _c_void_p, _c_int, _c_void_p], _c_int),

@@ -261,8 +261,14 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     if stack_free:
         tsa_value = history.expand(2, Q, history.shape[-1]) if tsa_vals is not None \
             else torch.stack([history, full_query], 1).reshape(bs * 2, Q, -1)
+    seam = None
     for li, layer in enumerate(encoder.layers):
         hoisted = {}
+        if seam is not None and seam.get("proj") is not None:
+            hoisted["tsa_proj"] = seam["proj"]           # (the previous layer's last kernel made this layer's TSA projection)
+        seam = encoder.tsa_seam(li, history_local, pos_local) if history_local is not None else None
+        if seam is not None:
+            hoisted["tsa_seam"] = seam
         if history_local is not None:
             hoisted["tsa_history"] = history_local       # (the K source of TSA's projection: gathered once, not per layer)
         if sca_vals is not None:

@@ -532,14 +532,33 @@ int bevmsda_linear_panel_rows2_f32(const float *x_lo, const float *x_hi, int64_t
 }
 
 // ---- row-local tail of an encoder layer in one kernel (linear_chain.h)
+// the next layer's [first | y + pos] projection behind y (linear_chain.h TP; bevmsda_proj_ffn_chain_tail_f32)
+struct ChainTail {
+  const float *first; long long ld_first;
+  const float *pos; long long ld_pos;
+  const uint16_t *w3p; const float *b3;
+  float *proj; long long ld_proj;
+  int n3;
+};
+
 static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
                             const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
                             const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
                             const bevmsda_chain_desc *d, float *y, void *stream, bool save, float *sv_z0, float *sv_x,
                             float *sv_h, float *sv_z1, const float *dk0 = nullptr, const float *dkh = nullptr,
-                            const float *dk1 = nullptr) {
+                            const float *dk1 = nullptr, const ChainTail *tp = nullptr) {
   if (!d) return BEVMSDA_ERR_NULL_POINTER;
   const bool drop = dk0 || dkh || dk1;
+  if (tp) {
+    if (save || drop) return BEVMSDA_ERR_BAD_OPTION;
+    if (tp->n3 <= 0 || tp->n3 > 256 || tp->n3 % 64 != 0) return BEVMSDA_ERR_UNSUPPORTED;      // (whole tiles of both workgroup shapes)
+    if (d->M > 0 && (!tp->first || !tp->w3p || !tp->proj)) return BEVMSDA_ERR_NULL_POINTER;
+    if (tp->ld_first % 4 != 0 || tp->ld_proj % 4 != 0 || (tp->pos && tp->ld_pos % 4 != 0)) return BEVMSDA_ERR_UNSUPPORTED;
+    if (tp->ld_first < 256 || tp->ld_proj < tp->n3 || (tp->pos && tp->ld_pos < 256)) return BEVMSDA_ERR_BAD_SHAPE;
+    if (misaligned(tp->first) || misaligned(tp->w3p) || misaligned(tp->proj) || (tp->pos && misaligned(tp->pos)) ||
+        (tp->b3 && misaligned(tp->b3)))
+      return BEVMSDA_ERR_MISALIGNED;
+  }
   if (drop && !save) return BEVMSDA_ERR_BAD_OPTION;
   if ((dk0 && misaligned(dk0)) || (dkh && misaligned(dkh)) || (dk1 && misaligned(dk1))) return BEVMSDA_ERR_MISALIGNED;
   if (save && d->M > 0 && (!sv_z0 || !sv_x || !sv_h || !sv_z1)) return BEVMSDA_ERR_NULL_POINTER;
@@ -562,7 +581,10 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
   // default: 32-row panels up to kChainSmallRows rows, mixed from one whole round of 64-row panels on (measured at 40,000
   // rows, interleaved runs on one box: 103.2-103.6 vs 106.6-107.2 us; profiles/r4/r4f_chain_mixed_shape_ab.txt)
-  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : (d->M >= 256LL * 64 ? 3 : 1);
+  // (with the next layer's projection behind it the 32-row shape wins at every row count: two workgroups per CU cover each
+  // other's fetch / split / barrier phases of the extra stage — 127 vs 140 us at 40,000 rows, base frame 4.09 vs 4.20 ms;
+  // profiles/r6/r6u_seam_ab.txt)
+  if (shape == 0) shape = (tp || d->M <= kChainSmallRows) ? 2 : (d->M >= 256LL * 64 ? 3 : 1);
   if (shape == 3) {
     // mixed (round 4): whole rounds of the 64-row shape (one workgroup per CU: 256 x 64 rows per round)
     // and the remainder — a partial round that would leave most CUs idle behind a few 64-row workgroups — on the 32-row
@@ -574,20 +596,27 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
       bevmsda_chain_desc one = *d;
       one.reserved[1] = (head == 0) ? 2 : 1;
       return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &one, y, stream,
-                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1);
+                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1, tp);
     }
     bevmsda_chain_desc dh = *d, dt = *d;
     dh.M = head; dh.reserved[1] = 1;
     dt.M = tail; dt.reserved[1] = 2;
     int rc = ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dh, y, stream,
-                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1);
+                              save, sv_z0, sv_x, sv_h, sv_z1, dk0, dkh, dk1, tp);
     if (rc != BEVMSDA_OK) return rc;
     const long long o = head;
+    ChainTail tt{};
+    if (tp) {
+      tt = *tp;
+      tt.first += o * tp->ld_first;
+      if (tt.pos) tt.pos += o * tp->ld_pos;
+      tt.proj += o * tp->ld_proj;
+    }
     return ffn_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p, b0,
                             res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dt,
                             y + o * d->ld_y, stream, save, save ? sv_z0 + o * 256 : nullptr, save ? sv_x + o * 256 : nullptr,
                             save ? sv_h + o * 512 : nullptr, save ? sv_z1 + o * 256 : nullptr, dk0 ? dk0 + o * 256 : nullptr,
-                            dkh ? dkh + o * 512 : nullptr, dk1 ? dk1 + o * 256 : nullptr);
+                            dkh ? dkh + o * 512 : nullptr, dk1 ? dk1 + o * 256 : nullptr, tp ? &tt : nullptr);
   }
   const int bm = shape == 1 ? 64 : 32;
   const long long nb = (d->M + bm - 1) / bm;
@@ -599,8 +628,23 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   a.eps0 = d->eps0; a.eps1 = d->eps1; a.y = y; a.ld_y = d->ld_y; a.M = d->M;
   a.sv_z0 = sv_z0; a.sv_x = sv_x; a.sv_h = sv_h; a.sv_z1 = sv_z1;
   a.dk0 = dk0; a.dkh = dkh; a.dk1 = dk1;
+  if (tp) {
+    a.tp_first = tp->first; a.ld_tp_first = tp->ld_first; a.tp_pos = tp->pos; a.ld_tp_pos = tp->ld_pos;
+    a.w3 = tp->w3p; a.b3 = tp->b3; a.y3 = tp->proj; a.ld_y3 = tp->ld_proj; a.N3 = tp->n3;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(nb));
+#define BEVMSDA_CHAIN_TP(NP_, PRE_)                                                                                               \
+  do {                                                                                                                            \
+    if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8, false, false, true>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 1, 2, 4, false, false, true>), grid, dim3(256), 0, st, a);            \
+  } while (0)
+  if (tp) {
+    if (d->precision == 0) { if (idx) BEVMSDA_CHAIN_TP(3, 2); else BEVMSDA_CHAIN_TP(3, 0); }
+    else { if (idx) BEVMSDA_CHAIN_TP(1, 2); else BEVMSDA_CHAIN_TP(1, 0); }
+    return hipGetLastError() == hipSuccess ? BEVMSDA_OK : BEVMSDA_ERR_LAUNCH;
+  }
+#undef BEVMSDA_CHAIN_TP
 #define BEVMSDA_CHAIN(NP_, PRE_, SV_, DR_)                                                                                        \
   do {                                                                                                                            \
     if (shape == 1) hipLaunchKernelGGL((bevmsda::linear_chain_kernel<NP_, PRE_, 0, 2, 1, 8, SV_, DR_>), grid, dim3(512), 0, st, a); \
@@ -626,6 +670,17 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
                                const bevmsda_chain_desc *d, float *y, void *stream) {
   return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, false,
                           nullptr, nullptr, nullptr, nullptr);
+}
+
+int bevmsda_proj_ffn_chain_tail_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                    const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                    const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
+                                    const bevmsda_chain_desc *d, float *y, const float *first, int64_t ld_first,
+                                    const float *pos, int64_t ld_pos, const uint16_t *w3p, const float *b3, int n3,
+                                    float *proj_out, int64_t ld_proj, void *stream) {
+  const ChainTail tp{first, ld_first, pos, ld_pos, w3p, b3, proj_out, ld_proj, n3};
+  return ffn_chain_launch(rows, idx, scale, w0p, b0, res, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, d, y, stream, false,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tp);
 }
 
 int bevmsda_proj_ffn_chain_train_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,

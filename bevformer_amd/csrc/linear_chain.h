@@ -28,12 +28,21 @@
 // x is stored (it is SpatialCrossAttention's residual) AND kept as planes, so the second projection never re-reads it;
 // a wavefront walks the 32-column tiles t = wave, wave + 8, ... of p.
 //
+// TP = true (MODE 0, inference; round 6) — the seam BETWEEN two layers on the same machinery: behind y the workgroup also
+// forms the NEXT layer's TemporalSelfAttention offset / weight projection of the rows it has just produced,
+//     p = [first | y + pos] W3^T + b3        (temporal_self_attention.py:197-211: cat([value[:bs], query + query_pos], -1))
+// `first` (the history BEV's rows: the K columns 0 .. 255) is fetched by LDS-DMA into buffer 1 under LayerNorm1, y + pos
+// goes into buffer 0 as planes straight from the accumulators (y is never re-read from HBM), and a wavefront walks the
+// 32 NT-column tiles t = wave, wave + NW, ... of p over K = 512 (32 k16 steps across the two buffers).  The stand-alone
+// projection it replaces re-reads y and runs at 20 % MFMA utilisation in its own launch (DESIGN §4 K3c "tail projection").
+//
 // LDS: 2 x 64 KiB plane buffers + 2 KiB of row statistics: one workgroup (512 threads, 2 wavefronts per SIMD) per CU.
 // The accumulator -> plane write uses the same slot map the DMA + split pass produces, so the fragment reads of every
 // stage are the conflict-free ones of linear_panel.h (tests/test_linear_layout_model.py replays the arithmetic).
 #pragma once
 #include <type_traits>
 #include "linear_panel.h"
+#include "scalar_ops.h"
 
 namespace bevmsda {
 
@@ -81,6 +90,16 @@ struct ChainArgs {
   // the hidden dropout (h is zero where dropped), and the projection's gradient gz0 * dk0 goes to bw_gzp (din = that W0)
   float bw_hscale;
   float *bw_gzp;
+  // TP = true: the next layer's [first | y + pos] projection (header comment)
+  const float *tp_first;            // (M, ld_tp_first): K columns 0 .. 255 of the projection's input
+  long ld_tp_first;
+  const float *tp_pos;              // (M, ld_tp_pos) addend of y (the positional encoding), or nullptr
+  long ld_tp_pos;
+  const uint16_t *w3;               // fragment-order image of the (N3, 512) weight
+  const float *b3;                  // (N3) or nullptr
+  float *y3;                        // (M, ld_y3): the projection
+  long ld_y3;
+  int N3;                           // a multiple of 32 NT, <= 256
 #ifdef BEVMSDA_CHAIN_PROF
   unsigned long long *prof;         // tools/gemm_diag: 12 phase clocks, summed over workgroups (lane 0 of wavefront 0)
 #endif
@@ -109,10 +128,11 @@ constexpr int kChainMaxN2 = 768;   // MODE 1: columns of the second projection (
 //              phases (58 % of a workgroup's cycles in the first shape: tools/gemm_diag/chain_run.py) run under the
 //              other's MFMAs, and 1,250 half-size workgroups quantise better over 256 CUs than 625 — at twice the
 //              weight traffic from L2 per row.
-template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8, bool SAVE = false, bool DROP = false>
+template <int NPROD, int PRE, int MODE = 0, int MT = 2, int NT = 1, int NW = 8, bool SAVE = false, bool DROP = false, bool TP = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 linear_chain_kernel(const ChainArgs a) {
   static_assert(NPROD == 1 || NPROD == 3, "NPROD");
+  static_assert(!TP || (MODE == 0 && !SAVE && !DROP), "TP: the inference form of MODE 0");
   static_assert(PRE == 0 || PRE == 2, "PRE: 0 plain rows, 2 two-row gather");
   static_assert(MODE < 2 || (MT == 1 && NT == 2 && PRE == 0 && !SAVE && !DROP), "MODE 2 / 3: 32-row workgroups of 4 wavefronts");
   static_assert(NW * NT == 8 && (MT == 1 || MT == 2) && (NT == 1 || NT == 2), "workgroup shape");
@@ -149,6 +169,8 @@ linear_chain_kernel(const ChainArgs a) {
       else if (t4 < 512) src = MODE >= 2 ? nullptr : a.beta0 + (t4 - 256);
       else if (t4 < 768) src = (MODE == 0 || MODE == 2) ? a.gamma1 + (t4 - 512) : nullptr;
       else if (t4 < 1024) src = MODE == 0 ? a.beta1 + (t4 - 768) : nullptr;
+      else if (TP && t4 >= 1024 + kChainF && t4 < 1024 + kChainMaxN2)         // (b3 behind the 512 values of b1)
+        src = (a.b3 && t4 - 1024 - kChainF < a.N3) ? a.b3 + (t4 - 1024 - kChainF) : nullptr;
       else if (t4 < 1024 + kChainMaxN2) src = (a.b1 && t4 - 1024 < nb1) ? a.b1 + (t4 - 1024) : nullptr;
       else if (t4 < 1024 + kChainMaxN2 + 256) src = a.b0 ? a.b0 + (t4 - 1024 - kChainMaxN2) : nullptr;
       else src = (MODE == 0 && a.b2) ? a.b2 + (t4 - 1024 - kChainMaxN2 - 256) : nullptr;
@@ -311,7 +333,7 @@ linear_chain_kernel(const ChainArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += stat[w * BM + i * 32 + (lane & 31)];
-      rstd[i] = rsqrtf(t * (1.0f / kChainC) + eps);
+      rstd[i] = rsqrtf(fma_scalar(t, 1.0f / kChainC, eps));     // (scalar_ops.h: the two rows' pair is not formed with eps from a high half)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -770,6 +792,38 @@ linear_chain_kernel(const ChainArgs a) {
       CHAIN_STAMP(5 + 3 * half);               // GEMM 2 (half)
     }
 
+    // ---------------------------------------------------------------- TP: the `first` panel travels under LayerNorm1
+    float4 ps[TP ? MT : 1][TP ? NT : 1][4];
+    __amdgpu_buffer_rsrc_t r3 = r0;
+    if constexpr (TP) {
+      const unsigned w3b = static_cast<unsigned>((a.N3 + 63) / 64 * 2) * 32 * 2 * 1024;
+      r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w3), 0, static_cast<int>(w3b), 0x00020000);
+      // (every wavefront is past both buffers: GEMM 1 of the second half read buffer 1, the barrier above closed GEMM 2)
+      const int d_rl = lane >> 3, d_cc = lane & 7;
+      const int row = panel_row_of(wave * PPW / 4, d_rl);
+      const int cx = d_cc ^ (row & 7);
+      long gm = m0 + row;
+      if (gm >= a.M) gm = a.M - 1;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float *src = a.tp_first + gm * a.ld_tp_first + (2 * p) * 32 + cx * 4;
+        unsigned char *dst = buf1 + (wave * 4 + p) * 2048;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                         (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32),
+                                         (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float *prow = a.tp_pos ? a.tp_pos + (mrow[i] < a.M ? mrow[i] : a.M - 1) * a.ld_tp_pos : nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            ps[i][j][g] = prow ? *reinterpret_cast<const float4 *>(prow + ncol(j) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+
     // ---------------------------------------------------------------- y = LN1(x + ffn(x))
     add_cols(acc2, c_b2, 0);
     if constexpr (DROP) { if (a.dk1) scale_tile(acc2, a.dk1, kChainC, NT * wave * 32); }
@@ -782,6 +836,77 @@ linear_chain_kernel(const ChainArgs a) {
     if constexpr (SAVE) store_tile(acc2, a.sv_z1, kChainC, NT * wave * 32);
     layernorm(acc2, c_g1, c_be1, a.eps1);
     CHAIN_STAMP(9);                            // bias + residual + LayerNorm 1
+    if constexpr (TP) {
+      // ---------------------------------------------------------------- p = [first | y + pos] W3^T + b3
+      const int ntile = a.N3 / (32 * NT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my own DMA slots (and the pos rows) have landed
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {                         // split `first` in place
+        unsigned char *slot = buf1 + (wave * 4 + p) * 2048 + lane * 16;
+        const float4 va = *reinterpret_cast<const float4 *>(slot);
+        const float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
+        uint4 hi, lo;
+        lin_split8<LO>(va, vb, hi, lo);
+        *reinterpret_cast<uint4 *>(slot) = hi;
+        if (LO) *reinterpret_cast<uint4 *>(slot + 1024) = lo;
+      }
+      // (the first weight fragments are requested BEFORE y's stores: the wavefront's memory counter retires in order)
+      if (wave < ntile) wprefetch(r3, wave, 32, 0);
+      store_tile(acc2, a.y, a.ld_y, NT * wave * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            acc2[i][j][4 * g] += ps[i][j][g].x; acc2[i][j][4 * g + 1] += ps[i][j][g].y;
+            acc2[i][j][4 * g + 2] += ps[i][j][g].z; acc2[i][j][4 * g + 3] += ps[i][j][g].w;
+          }
+      to_planes(acc2, buf0);
+      __syncthreads();                         // both halves of the projection's input are planes
+      CHAIN_STAMP(10);
+      // c += [planes(buf1) | planes(buf0)] x W3[column tile]^T over the 32 k16 steps of K = 512 (gemm16 twice over, one
+      // weight ring: no L2 round trip between the halves)
+      auto gemm32 = [&](auto &c, int tile) {
+        lin_bf16x8 af[2][MT][NPL];
+        auto aload = [&](int set, int s) {
+          const unsigned char *buf = s < 16 ? buf1 : buf0;
+          const unsigned base = f_addr[s & 3] + ((s & 15) >> 2) * 2048;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+              af[set][i][pl] = *reinterpret_cast<const lin_bf16x8 *>(buf + base + i * (4 * 4 * 2048) + pl * 1024);
+        };
+        aload(0, 0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          if (s + WD < 32) wload(r3, tile, 32, (s + WD) % (WD + 1), s + WD);
+          if (s + 1 < 32) aload((s + 1) & 1, s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              if constexpr (LO) {
+                c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][0], af[s & 1][i][1], c[i][j], 0, 0, 0);
+                c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][1], af[s & 1][i][0], c[i][j], 0, 0, 0);
+              }
+              c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s % (WD + 1)][j][0], af[s & 1][i][0], c[i][j], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#pragma unroll 1
+      for (int t = wave; t < ntile; t += NW) {
+        zero(acc);
+        gemm32(acc, t);
+        if (t + NW < ntile) wprefetch(r3, t + NW, 32, 0);
+        add_cols(acc, c_b1 + kChainF, (t - wave) * 32 * NT);
+        store_tile(acc, a.y3, a.ld_y3, t * 32 * NT);
+      }
+      return;
+    }
     store_tile(acc2, a.y, a.ld_y, NT * wave * 32);
     CHAIN_STAMP(10);                           // stores issued
   }

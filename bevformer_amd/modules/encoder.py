@@ -269,6 +269,32 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 tsa_vals = [y[i].view(nb, nv, M, -1) for i in range(L)]
         return sca_vals, tsa_vals
 
+    def tsa_seam(self, li, first, pos):
+        """The offer layer ``li`` gets to run the NEXT layer's TemporalSelfAttention offset / weight projection behind its own
+        last kernel (``ops.proj_ffn_chain(tail=...)``, csrc/linear_chain.h TP): that projection reads ``cat([first, query +
+        pos], -1)`` (temporal_self_attention.py:197-211) with query = the rows layer ``li`` is about to produce, so the
+        workgroup that holds them projects them on the spot — one launch and one read of the grid less per layer.  ``first``
+        (1, Q, 256): the history rows of the queries, ``pos`` (1, Q, 256).  Inference at bs = 1 between two stock layers only;
+        returns the holder ``{"first", "pos", "w", "b", "proj": None}`` (the layer fills ``proj``) or None."""
+        from .temporal_self_attention import TemporalSelfAttention
+        if li + 1 >= len(self.layers) or not ops.modes().tsa_seam or torch.is_grad_enabled() or self.training \
+                or first is None or pos is None or not first.is_cuda or first.dim() != 3 or first.shape[0] != 1 \
+                or first.shape != pos.shape or first.shape[-1] != 256 or first.dtype != torch.float32 \
+                or pos.dtype != torch.float32 or ops.gemm_mode() == "native":
+            return None
+        cur, nxt = self.layers[li], self.layers[li + 1]
+        if type(cur) is not BEVFormerLayer or type(nxt) is not BEVFormerLayer or cur.pre_norm or nxt.pre_norm \
+                or tuple(cur.operation_order[-4:]) != ("cross_attn", "norm", "ffn", "norm") \
+                or nxt.operation_order[0] != "self_attn":
+            return None
+        tsa = nxt.attentions[0]
+        if type(tsa) is not TemporalSelfAttention or not tsa.batch_first or tsa.num_bev_queue != 2 or tsa.embed_dims != 256:
+            return None
+        w, b = ops.merged_linear_params(tsa, tsa.sampling_offsets, tsa.attention_weights)
+        if tuple(w.shape) != (w.shape[0], 512) or w.shape[0] % 64 or w.shape[0] > 256:
+            return None
+        return {"first": first, "pos": pos, "w": w, "b": b, "proj": None, "module": tsa}
+
     def _stack_free(self, history, bev_query, bs):
         """May the layers run without the stacked [history, bev_query] tensor?  Inference at bs = 1 on the GPU with every
         layer a stock ``BEVFormerLayer`` whose first attention is the stock ``TemporalSelfAttention`` (a subclass or another
@@ -439,6 +465,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         """The layer loop of ``forward`` (encoder.py:211-233)."""
         output = bev_query          # (zero layers: the queries come back unchanged, encoder.py:211)
         intermediate = []
+        seam = None
         for li, layer in enumerate(self.layers):
             hoisted = {}
             if share is not None:
@@ -454,6 +481,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     hoisted["projected_value_ready"] = self._sca_ready
             if tsa_vals is not None:
                 hoisted["tsa_projected_value"] = tsa_vals[li]
+            if seam is not None and seam.get("proj") is not None:
+                hoisted["tsa_proj"] = seam["proj"]          # (made by the previous layer's last kernel)
+            seam = self.tsa_seam(li, history, bev_pos) if history is not None else None
+            if seam is not None:
+                hoisted["tsa_seam"] = seam
             output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
                            ref_3d=plan.ref_3d, bev_h=bev_h, bev_w=bev_w,
                            spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -516,7 +548,10 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
                 ref_3d=None, bev_h=None, bev_w=None, reference_points_cam=None, mask=None,
                 spatial_shapes=None, level_start_index=None, prev_bev=None, frame_plan=None,
-                **kwargs):
+                tsa_seam=None, tsa_proj=None, **kwargs):
+        """``tsa_seam``: the encoder's offer to project the rows this layer produces for the next layer's
+        TemporalSelfAttention in the layer's last kernel (``BEVFormerEncoder.tsa_seam``); ``tsa_proj``: that projection of
+        THIS layer's input rows, made by the previous layer."""
         norm_i = attn_i = ffn_i = 0
         identity = query
         if attn_masks is None:
@@ -583,6 +618,14 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                                             drop_p=(drop_p, ph, po))
                 if drop_p > 0:
                     return None
+                if tsa_seam is not None and i + 4 == len(order):
+                    # ... and the next layer's TemporalSelfAttention projection of the result behind it
+                    done = ops.proj_ffn_chain(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain",
+                                              tail=(tsa_seam["first"], tsa_seam["pos"], tsa_seam["w"], tsa_seam["b"]))
+                    if done is None:
+                        return None
+                    tsa_seam["proj"] = done[1]
+                    return done[0]
                 return ops.proj_ffn_chain(rows, w, b, res, n0, fc1, fc2, n1, gather=gather, tag="sca_out_ffn_chain")
             return run_s
 
@@ -626,7 +669,8 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_i],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                     spatial_shapes=bev_shapes, level_start_index=bev_start,
-                    defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain_t(i), **kwargs)
+                    defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain_t(i),
+                    offs_attn_proj=tsa_proj if i == 0 else None, **kwargs)
                 attn_i += 1
                 if isinstance(query, ops.NormedWithProj):
                     query, next_proj, skip_norm = query.t, query.proj, True

@@ -138,14 +138,16 @@ class TemporalSelfAttention(BaseModule):
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, flag="decoder", bev_slice=None, defer_residual=False,
-                tsa_projected_value=None, post_norm=None, chain=None, **kwargs):
+                tsa_projected_value=None, post_norm=None, chain=None, offs_attn_proj=None, **kwargs):
         """query (bs, Q, C) [batch_first]; value None or (bs*2, Q, C) with index
         b*2+queue; reference_points (bs*2, Q, num_levels, 2) -> (bs, Q, C).
 
         ``bev_slice=(q0, q1)`` (BEV tiling): ``query`` holds only queries
         [q0, q1) while ``value`` is the full grid.  ``tsa_projected_value``
         (bs*2, Q, M, D): ``value_proj(value)`` already computed by the encoder
-        for all layers at once (``hoisted_value_projections``)."""
+        for all layers at once (``hoisted_value_projections``).  ``offs_attn_proj`` (bs*Q, offsets + weights):
+        the merged ``sampling_offsets`` / ``attention_weights`` projection of ``cat([value[:bs], query + query_pos], -1)``
+        already made by the kernel that produced ``query`` (``BEVFormerEncoder.tsa_seam``)."""
         assert self.num_bev_queue == 2
         shared_value = value is None
         if shared_value:
@@ -197,7 +199,10 @@ class TemporalSelfAttention(BaseModule):
         n_off = self.sampling_offsets.out_features
         w, b = ops.merged_linear_params(self, self.sampling_offsets, self.attention_weights)
         proj = None
-        if self.batch_first:
+        if offs_attn_proj is not None and self.batch_first and not shared_value and key_padding_mask is None \
+                and offs_attn_proj.numel() == bs * Q * w.shape[0]:
+            proj = offs_attn_proj.view(bs, Q, w.shape[0])
+        if proj is None and self.batch_first:
             proj = ops.linear(first, w, b, x2=query_in, x2_add=query_pos, tag="tsa_offs_attn")
             if proj is None and chain is not None and torch.is_grad_enabled() and first.shape == query_in.shape \
                     and first.shape[-1] == 256 and (query_pos is None or query_pos.shape == query_in.shape):

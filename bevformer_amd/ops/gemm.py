@@ -378,6 +378,9 @@ KERNEL_SELECTION = {
     "first_64x256_rows":       (32768, "first kernel in 64-row x 256-column tiles (every input row staged once) for 128 < N <= 256 from this many rows on",
                                 "TemporalSelfAttention's two-source projection (N = 192, K = 512): 49.1 vs 51.8 us at 40,000 rows, level at 20,000 (32.7 vs 32.8), bit-identical results",
                                 "profiles/r6/r6c_first64x256_ab.txt"),
+    "tsa_seam":                (True,   "a layer's last chain kernel also makes the NEXT layer's TemporalSelfAttention offset / weight projection (modes.tsa_seam; 32-row workgroups at every row count: the library's rule for bevmsda_proj_ffn_chain_tail_f32)",
+                                "chain + tail 127 us (32-row) / 140 us (mixed) vs chain 100 + stand-alone projection 50 us at 40,000 rows; base frame 3.99-4.00 vs 4.05-4.06 ms, bf16 2.86-2.87 vs 2.92 ms",
+                                "profiles/r6/r6u_seam_ab2.txt"),
     # ---- in the library (constants of csrc/bevmsda_linear.hip)
     "pipe_max_rows":           (8192,   "kLinearPipeMaxRows: software-pipelined kernel for first-kernel calls of up to this many rows",
                                 "13.1-19.9 vs 14.7-23.0 us at 2,500-5,000 rows; level at 10,000, behind from 20,000 rows on",
@@ -786,13 +789,28 @@ class Chained:
         self.t = t
 
 
-def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=None, tag="proj_ffn_chain"):
+def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=None, tag="proj_ffn_chain", tail=None):
     """``norm1(x + fc2(relu(fc1(x))))`` with ``x = norm0(linear(A, weight, bias) + res)`` in ONE kernel
     (``bevmsda_proj_ffn_chain_f32``, csrc/linear_chain.h): the attention's output projection, "+ identity", the
     layer's norm, the FFN, "+ identity" and the next norm — every op local to a BEV row.  A = ``rows`` or, with
     ``gather = (idx (M, 2) int32, scale (M,))``, SpatialCrossAttention's camera mean over the rows.  ``fc1`` / ``fc2``:
     the FFN's ``nn.Linear`` layers (256 -> 512 -> 256), ``norm0`` / ``norm1``: ``nn.LayerNorm(256)``.  Returns
-    ``None`` when not covered (the caller runs the steps one by one)."""
+    ``None`` when not covered (the caller runs the steps one by one).
+
+    ``tail = (first, pos, w3, b3)``: the seam to the NEXT layer in the same launch (``bevmsda_proj_ffn_chain_tail_f32``) —
+    ``linear(cat([first, y + pos], -1), w3, b3)``, the next TemporalSelfAttention's merged offset / weight projection of the
+    rows ``y`` this launch produces (``first`` (M, 256) rows, ``pos`` (M, 256) rows or None, ``w3`` (N3, 512)).  Returns
+    ``(y, proj)`` then; a tail the kernel does not cover is dropped and ``(y, None)`` comes back."""
+    if tail is not None:
+        out = _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag, tail)
+        if out is not None:
+            return out
+        y = _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag, None)
+        return None if y is None else (y, None)
+    return _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag, None)
+
+
+def _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag, tail):
     m = _m()
     if not m.ln_fuse or m.gemm == "native" or not m.gemm_pack or m.gemm_variant is not None \
             or m.gemm_kernel in ("first", "pipe") or not rows.is_cuda or rows.dtype != torch.float32:
@@ -845,17 +863,46 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
     flops = 2.0 * M * (256 * 256 + 2 * 256 * 512)
     nbytes = 4.0 * ((min(x0.shape[0], 2 * M) if gather is not None else M) * 256 + M * 256 * (2 if res is not None else 1)
                     + 256 * 256 + 2 * 256 * 512)
+    tp = None
+    if tail is not None:
+        first, pos, w3, b3 = tail
+        if w3.dim() != 2 or w3.shape[1] != 512 or w3.shape[0] % 64 or w3.shape[0] > 256 or w3.dtype != torch.float32 \
+                or first.dtype != torch.float32 or first.shape[-1] != 256 or first.numel() != M * 256 \
+                or (pos is not None and (pos.dtype != torch.float32 or pos.shape[-1] != 256 or pos.numel() != M * 256)) \
+                or not fused_wanted(first, w3, b3, pos):
+            return None
+        f2, ldf = _rows2d(first, 256)
+        p2, ldp = _rows2d(pos, 256) if pos is not None else (None, 0)
+        w3 = w3 if (w3.stride(1) == 1 and w3.stride(0) % 4 == 0 and w3.data_ptr() % 16 == 0) else w3.contiguous()
+        blob3 = panel_weight(w3)
+        if f2 is None or (pos is not None and p2 is None) or blob3 is None:
+            return None
+        N3 = w3.shape[0]
+        pr = torch.empty((M, N3), dtype=torch.float32, device=rows.device)
+        tp = (f2, ldf, p2, ldp, blob3, b3.contiguous() if b3 is not None else None, N3, pr)
+        flops += 2.0 * M * 512 * N3
+        nbytes += 4.0 * (M * 256 * (2 if pos is not None else 1) + M * N3 + 512 * N3)
     ctx = cb(tag, flops, nbytes) if cb is not None else _NoTimer()
     p = lambda t: _ptr(t) if t is not None else None
     bc = lambda t: t.contiguous() if t is not None else None
     with torch.cuda.device(rows.device), ctx:
-        rc = lib.bevmsda_proj_ffn_chain_f32(
-            _ptr(x0), p(idx), p(scale), _ptr(ws[0]), p(bc(bias)), p(r2), _ptr(norm0.weight), _ptr(norm0.bias),
-            _ptr(ws[1]), p(bc(fc1.bias)), _ptr(ws[2]), p(bc(fc2.bias)), _ptr(norm1.weight), _ptr(norm1.bias),
-            ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
+        if tp is None:
+            rc = lib.bevmsda_proj_ffn_chain_f32(
+                _ptr(x0), p(idx), p(scale), _ptr(ws[0]), p(bc(bias)), p(r2), _ptr(norm0.weight), _ptr(norm0.bias),
+                _ptr(ws[1]), p(bc(fc1.bias)), _ptr(ws[2]), p(bc(fc2.bias)), _ptr(norm1.weight), _ptr(norm1.bias),
+                ctypes.byref(desc), _ptr(y), torch.cuda.current_stream().cuda_stream)
+        else:
+            f2, ldf, p2, ldp, blob3, b3c, N3, pr = tp
+            rc = lib.bevmsda_proj_ffn_chain_tail_f32(
+                _ptr(x0), p(idx), p(scale), _ptr(ws[0]), p(bc(bias)), p(r2), _ptr(norm0.weight), _ptr(norm0.bias),
+                _ptr(ws[1]), p(bc(fc1.bias)), _ptr(ws[2]), p(bc(fc2.bias)), _ptr(norm1.weight), _ptr(norm1.bias),
+                ctypes.byref(desc), _ptr(y), _ptr(f2), ldf, p(p2), ldp, _ptr(blob3), p(b3c), N3, _ptr(pr), N3,
+                torch.cuda.current_stream().cuda_stream)
     if rc in (_lib.ERR_UNSUPPORTED, _lib.ERR_MISALIGNED):
         return None
     _lib.check(rc, "proj_ffn_chain")
+    if tp is not None:
+        return y.view(*lead, 256), tp[-1]
     return y.view(*lead, 256)
 
 

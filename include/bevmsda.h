@@ -592,6 +592,22 @@ int bevmsda_proj_ffn_chain_f32(const float *rows, const int32_t *idx, const floa
                                const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
                                const bevmsda_chain_desc *desc, float *y, void *stream);
 
+/* The same launch with the seam to the NEXT layer behind it (csrc/linear_chain.h TP): besides y the workgroup forms
+ *     proj_out = [first | y + pos] w3^T + b3          (n3 columns, K = 512)
+ * = the next BEVFormerLayer's TemporalSelfAttention `sampling_offsets` / `attention_weights` projection of
+ * `cat([value[:bs], query + query_pos], -1)` (temporal_self_attention.py:197-211) with query = y, the rows this launch has
+ * just produced: `first` (M, ld_first) = the history BEV's rows, `pos` (M, ld_pos) = the positional encoding or NULL,
+ * w3p = the bevmsda_linear_panel_pack_weight_f32 image of the merged (n3, 512) weight, b3 (n3) or NULL.  Replaces one
+ * bevmsda_linear_f32 two-source launch per layer (y is not re-read).  Supported: n3 a multiple of 64, <= 256; else
+ * BEVMSDA_ERR_UNSUPPORTED and the caller runs the two launches.  Same arithmetic as that launch (split operands, fp32
+ * accumulation); results agree to fp32 summation order. */
+int bevmsda_proj_ffn_chain_tail_f32(const float *rows, const int32_t *idx, const float *scale, const uint16_t *w0p, const float *b0,
+                                    const float *res, const float *gamma0, const float *beta0, const uint16_t *w1p, const float *b1,
+                                    const uint16_t *w2p, const float *b2, const float *gamma1, const float *beta1,
+                                    const bevmsda_chain_desc *desc, float *y, const float *first, int64_t ld_first,
+                                    const float *pos, int64_t ld_pos, const uint16_t *w3p, const float *b3, int n3,
+                                    float *proj_out, int64_t ld_proj, void *stream);
+
 /* The same launch as the FORWARD of the autograd path: besides y it stores what the backward of the chain needs and the
  * inference launch keeps on chip — save_z0 (M, 256) = A w0^T + b0 + res (the input of LayerNorm0), save_x (M, 256) =
  * LayerNorm0(...), save_h (M, 512) = relu(x w1^T + b1), save_z1 (M, 256) = x + h w2^T + b2 (the input of LayerNorm1);

@@ -278,6 +278,59 @@ def test_value_projection_without_the_stacked_history_tensor(name, storage):
     torch.testing.assert_close(default, stacked, rtol=0, atol=5e-2 if storage == torch.bfloat16 else 2e-4)
 
 
+@pytest.mark.parametrize("name,mode", [("micro4", "split"), ("small4", "split"), ("small4", "bf16"), ("tiny", "split")])
+def test_next_layers_tsa_projection_made_by_the_previous_layers_last_kernel(name, mode):
+    """Inference with a history BEV at bs = 1: layer l's last kernel (output projection + norm + FFN + norm) also forms layer
+    l + 1's TemporalSelfAttention offset / weight projection of the rows it produces (``BEVFormerEncoder.tsa_seam``,
+    csrc/linear_chain.h TP) — the stand-alone ``tsa_offs_attn`` launch runs for the FIRST layer only, the output agrees with
+    the run that launches it per layer to GEMM summation order, and with the oracle at the encoder tolerance."""
+    saved = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        enc, sd = build_pair(name, device=DEV)
+        q, f, kw = S.make_inputs(name, seed=4, temporal=True)
+        qd, fd, kwd = q.to(DEV), f.to(DEV), _to_dev(kw)
+        tags = []
+
+        class _Ctx:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *exc):
+                return False
+
+        def cb(tag, flops, nbytes):
+            tags.append(tag)
+            return _Ctx()
+        ops.set_gemm_timer(cb)
+        try:
+            with torch.no_grad():
+                with ops.using(tsa_seam=True):
+                    on = enc(qd, fd, fd, **kwd)
+                n_on = tags.count("tsa_offs_attn")
+                del tags[:]
+                with ops.using(tsa_seam=False):
+                    off = enc(qd, fd, fd, **kwd)
+                n_off = tags.count("tsa_offs_attn")
+        finally:
+            ops.set_gemm_timer(None)
+        L = len(enc.layers)
+        assert n_off == L and n_on == 1, (n_on, n_off, L)
+        torch.testing.assert_close(on, off, rtol=0, atol=2e-4 if mode == "split" else 5e-2)
+        if mode == "split":
+            want = O.encoder_forward(sd, q, f, pc_range=S.PC_RANGE, **kw)
+            torch.testing.assert_close(on.cpu(), want, **TOL)
+        # the first frame of a scene (no history: TSA's `first` rows are the layer's own input) keeps the per-layer launch
+        q0, f0, kw0 = S.make_inputs(name, seed=4, temporal=False, device=DEV)
+        with torch.no_grad(), ops.using(tsa_seam=True):
+            a = enc(q0, f0, f0, **kw0)
+        with torch.no_grad(), ops.using(tsa_seam=False):
+            b = enc(q0, f0, f0, **kw0)
+        assert torch.equal(a, b)
+    finally:
+        ops.set_gemm_mode(saved)
+
+
 def test_inference_graph_replays_without_repacking_trainable_weights():
     """A forward step captured under ``torch.no_grad()`` over TRAINABLE parameters uses the cached weight images (round 5:
     the 24 ``lin_panel_pack_weight`` launches of every replayed step were 2.8 % of it); a capture with grad mode on

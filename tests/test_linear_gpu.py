@@ -567,6 +567,59 @@ def test_proj_ffn_chain_kernel_is_the_three_launch_sequence(gemm_mode, mode, M, 
     torch.testing.assert_close(got.double(), y64, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("shape,M,with_gather,with_pos", [(sh, M, wg, wp) for sh in (1, 2)
+                                                         for M, wg, wp in ((641, True, True), (4099, False, True), (64, True, False), (1, False, True))]
+                         + [(0, 40000, True, True), (0, 16500, False, True)])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_proj_ffn_chain_tail_is_the_chain_plus_the_two_source_projection(gemm_mode, mode, M, with_gather, with_pos, shape):
+    """``bevmsda_proj_ffn_chain_tail_f32`` (csrc/linear_chain.h TP): the chain kernel that also forms the NEXT layer's
+    TemporalSelfAttention projection ``[first | y + pos] W3^T + b3`` of the rows it produces — y bit-equal to the plain chain
+    launch, the projection against the stand-alone two-source launch on that y (same split operands: fp32 summation order
+    only) and against the fp64 statement.  Row counts with a partial last panel, one row, the base grid (mixed 64- / 32-row
+    launches) and a count whose tail launch starts at a row offset."""
+    gemm_mode(mode)
+    g = torch.Generator().manual_seed(M + 5)
+    R = max(M + 37, 100)
+    rows = _rand(R, 256, seed=181)
+    idx = scale = None
+    if with_gather:
+        idx = torch.randint(0, R, (M, 2), generator=g, dtype=torch.int32)
+        idx[torch.rand(M, generator=g) < 0.6, 1] = -1
+        scale = (1.0 / (idx >= 0).sum(1).clamp(min=1).float()).to(DEV)
+        idx = idx.to(DEV)
+    w0, b0, res = _rand(256, 256, seed=182) / 16, _rand(256, seed=183) * 0.1, _rand(M, 256, seed=184)
+    fc1, fc2 = torch.nn.Linear(256, 512).to(DEV), torch.nn.Linear(512, 256).to(DEV)
+    n0, n1 = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    first = _rand(1, M, 256, seed=185)
+    pos = _rand(1, M, 256, seed=186) if with_pos else None
+    w3, b3 = _rand(192, 512, seed=187) / 16, _rand(192, seed=188) * 0.1
+    with torch.no_grad():
+        for n, sd in ((n0, 85), (n1, 87)):
+            n.weight.copy_(_rand(256, seed=sd) * 0.2 + 1.0)
+            n.bias.copy_(_rand(256, seed=sd + 1) * 0.1)
+        gather = (idx, scale) if with_gather else None
+        src = rows if with_gather else rows[:M]
+        with ops.using(ln_fuse=True, chain_shape=shape):
+            plain = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather)
+            got = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather, tail=(first, pos, w3, b3))
+        assert plain is not None and got is not None and got[1] is not None
+        y, pr = got
+        assert torch.equal(y, plain) and pr.shape == (M, 192)
+        with ops.using(gemm_kernel="first"):
+            two = ops.linear(first, w3, b3, x2=y.view(1, M, 256), x2_add=pos)
+        assert two is not None
+        t2 = 5e-5 if mode == "split" else 2e-2
+        torch.testing.assert_close(pr, two.view(M, 192), rtol=t2, atol=t2)
+        q64 = y.double() + (pos.double().view(M, 256) if with_pos else 0.0)
+        p64 = torch.cat([first.double().view(M, 256), q64], -1) @ w3.double().t() + b3.double()
+    tol = 2e-4 if mode == "split" else 5e-2
+    torch.testing.assert_close(pr.double(), p64, rtol=tol, atol=tol)
+    # a weight the kernel does not tile (N3 = 96) is dropped, the chain itself still runs
+    with torch.no_grad(), ops.using(ln_fuse=True, chain_shape=shape):
+        fb = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather, tail=(first, pos, w3[:96].contiguous(), b3[:96].contiguous()))
+    assert fb is not None and fb[1] is None and torch.equal(fb[0], plain)
+
+
 @pytest.mark.parametrize("shape,M,N2", [(sh, M, n2) for sh in (1, 2) for M, n2 in ((641, 768), (4099, 192), (64, 96), (5000, 768))]
                          + [(0, 40000, 768)])
 @pytest.mark.parametrize("mode", ["split", "bf16"])
