@@ -599,8 +599,11 @@ def test_proj_ffn_chain_tail_is_the_chain_plus_the_two_source_projection(gemm_mo
             n.bias.copy_(_rand(256, seed=sd + 1) * 0.1)
         gather = (idx, scale) if with_gather else None
         src = rows if with_gather else rows[:M]
-        with ops.using(ln_fuse=True, chain_shape=shape):
+        # (left to the library the tail launch takes 32-row workgroups at every row count; the plain chain's LayerNorm sums
+        # its statistics in another order on 64-row workgroups: bit-equality is per shape)
+        with ops.using(ln_fuse=True, chain_shape=shape or 2):
             plain = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather)
+        with ops.using(ln_fuse=True, chain_shape=shape):
             got = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather, tail=(first, pos, w3, b3))
         assert plain is not None and got is not None and got[1] is not None
         y, pr = got
@@ -615,7 +618,7 @@ def test_proj_ffn_chain_tail_is_the_chain_plus_the_two_source_projection(gemm_mo
     tol = 2e-4 if mode == "split" else 5e-2
     torch.testing.assert_close(pr.double(), p64, rtol=tol, atol=tol)
     # a weight the kernel does not tile (N3 = 96) is dropped, the chain itself still runs
-    with torch.no_grad(), ops.using(ln_fuse=True, chain_shape=shape):
+    with torch.no_grad(), ops.using(ln_fuse=True, chain_shape=shape or 2):
         fb = ops.proj_ffn_chain(src, w0, b0, res, n0, fc1, fc2, n1, gather=gather, tail=(first, pos, w3[:96].contiguous(), b3[:96].contiguous()))
     assert fb is not None and fb[1] is None and torch.equal(fb[0], plain)
 
