@@ -400,7 +400,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   // desc->reserved[5] (kernel-body selection, A/B knob: values below) is validated HERE, for every path: it only acts on
   // the static-row fp32 launches, and the other paths (device-side row count: values 0, 1, 3; bf16 storage: 0, 1) must
   // not accept a value they would silently ignore — an A/B run would then report the knob as set and measure the default
-  if (d->reserved[5] < 0 || d->reserved[5] > 4) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->reserved[5] < 0 || d->reserved[5] > 5) return BEVMSDA_ERR_BAD_OPTION;
   if (sizeof(T) == 2 && d->reserved[5] > 1) return BEVMSDA_ERR_BAD_OPTION;
   if (nrows && d->reserved[5] == 2) return BEVMSDA_ERR_BAD_OPTION;
   bevmsda::FusedArgs f{};
@@ -513,7 +513,7 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
   // TemporalSelfAttention's shape (8 heads, one level, two queue entries) on the specialised body at 128 registers
   // (70 vs 72.4 us; at 64 registers it spills: 131 us); 1 = generic kernels only; 2 = that body at 64 registers;
   // 3 = SpatialCrossAttention's shape specialised too (no gain: the kernel is bound by the L1 / TA path)
-  if (d->reserved[5] < 0 || d->reserved[5] > 4) return BEVMSDA_ERR_BAD_OPTION;
+  if (d->reserved[5] < 0 || d->reserved[5] > 5) return BEVMSDA_ERR_BAD_OPTION;
   const bool specable = sizeof(T) == 4 && d->M == 8 && a.qtile == 8 && d->reserved[0] == 0;
   const bool spec = specable && d->reserved[5] == 3;
   // TemporalSelfAttention's shape in the resident, software-pipelined grid (msda_d32.h, round 6): 68.3 against 70.6 us per launch,
@@ -523,7 +523,21 @@ int fused_impl(const T *value, const int64_t *shapes, const int64_t *lstart, con
 #ifndef BEVMSDA_TSA_PIPE
 #define BEVMSDA_TSA_PIPE 0
 #endif
-  if (specable && (d->reserved[5] == 4 || (BEVMSDA_TSA_PIPE && d->reserved[5] == 0)) && d->P == 4 && d->K == 2 && d->L == 1 && nb >= 2 * kTsaPipeGrid && d->R < (1LL << 24) && !row_batch && !row_src && d->R == d->Q &&
+  // TemporalSelfAttention's shape with the tile's tap lines staged in LDS (msda_d32.h, round 6): reserved[5] = 5 and the HOST's
+  // copy of the sampled grid's shape in reserved[3] = (height << 16) | width (the launch is sized by it; the kernel reads the
+  // device's).  One batch entry, rows = the grid's cells in raster order, one reference point per (row, queue entry).
+#ifndef BEVMSDA_TSA_LDS
+#define BEVMSDA_TSA_LDS 0
+#endif
+  const int gh = d->reserved[3] >> 16, gw = d->reserved[3] & 0xffff;
+  if (specable && (d->reserved[5] == 5 || (BEVMSDA_TSA_LDS && d->reserved[5] == 0)) && d->P == 4 && d->K == 2 && d->L == 1 && d->A == 1 && d->ref_mode == 1 &&
+      gh > 0 && gw > 0 && static_cast<long long>(gh) * gw == d->R && d->R == d->Q && d->S >= d->R && !row_batch && !row_src &&
+      d->R * static_cast<long long>(d->proj_row) < (1LL << 31)) {
+    const int tiles = ((gw + bevmsda::kTsaLdsTX - 1) / bevmsda::kTsaLdsTX) * ((gh + bevmsda::kTsaLdsTY - 1) / bevmsda::kTsaLdsTY);
+    const int lnb = tiles * 8;
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL((bevmsda::msda_fused_d32_tsa_lds_kernel<4>), dim3(static_cast<unsigned>(((lnb + 7) / 8) * 8)), dim3(512), 0, st, f);
+  } else if (specable && (d->reserved[5] == 4 || (BEVMSDA_TSA_PIPE && d->reserved[5] == 0)) && d->P == 4 && d->K == 2 && d->L == 1 && nb >= 2 * kTsaPipeGrid && d->R < (1LL << 24) && !row_batch && !row_src && d->R == d->Q &&
       d->R * static_cast<long long>(d->proj_row) < (1LL << 29) && d->R * static_cast<long long>(d->K) * d->A < (1LL << 28)) {
 #ifndef BEVMSDA_TSA_PIPE_WPE
 #define BEVMSDA_TSA_PIPE_WPE 4

@@ -81,14 +81,15 @@ struct PointParams {
   uint32_t off;              // byte offset of value[n, level, y0, x0, m, 0], or kOobOffset
 };
 
-__device__ __forceinline__ PointParams point_params(float lx, float ly, float aw, int H, int W,
-                                                    uint32_t level_base, uint32_t pix_bytes) {
+// (x0, y0): the footprint's top-left pixel, for callers that address the taps themselves (the LDS-tile kernel)
+__device__ __forceinline__ PointParams point_params_xy(float lx, float ly, float aw, int H, int W,
+                                                       uint32_t level_base, uint32_t pix_bytes, int &x0, int &y0) {
   PointParams p;
   const float Wf = static_cast<float>(W), Hf = static_cast<float>(H);
   const float x = lx * Wf - 0.5f, y = ly * Hf - 0.5f;
   const bool inside = (x > -1.f) && (y > -1.f) && (x < Wf) && (y < Hf);
   const float xf = floorf(x), yf = floorf(y);
-  const int x0 = static_cast<int>(xf), y0 = static_cast<int>(yf);
+  x0 = static_cast<int>(xf); y0 = static_cast<int>(yf);
   const float fx = x - xf, fy = y - yf;
   const float gx = 1.f - fx, gy = 1.f - fy;
   const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W, y0ok = y0 >= 0, y1ok = y0 + 1 < H;
@@ -102,6 +103,12 @@ __device__ __forceinline__ PointParams point_params(float lx, float ly, float aw
   const uint32_t o = level_base + static_cast<uint32_t>(y0 * W + x0) * pix_bytes;
   p.off = inside ? o : kOobOffset;
   return p;
+}
+
+__device__ __forceinline__ PointParams point_params(float lx, float ly, float aw, int H, int W,
+                                                    uint32_t level_base, uint32_t pix_bytes) {
+  int x0, y0;
+  return point_params_xy(lx, ly, aw, H, W, level_base, pix_bytes, x0, y0);
 }
 
 // Broadcast the parameters of points J0 .. J0+CNT-1 (held by lanes J0.. of every
@@ -480,6 +487,185 @@ msda_fused_d32_tsa_pipe_kernel(const FusedArgs f) {
     }
     if (!more) break;
   }
+}
+
+// TemporalSelfAttention's shape with the tile's tap lines staged in LDS (round 6; the north star's "feature maps staged through
+// LDS tiles", for the one call of the path whose taps re-use lines densely).  TSA samples the BEV grid itself: the taps of a
+// TX x TY tile of queries fall within a few pixels of the tile (offset bias grid: point j at most j + 1 pixels out) — for the
+// history entry shifted by the ego motion.  A 128-byte tap line reaches the lanes at <= 60 B / clk / CU from the vector L1
+// (tools/probes/gather_path_probe.hip) and at 117-133 B / clk / CU from LDS, 97-112 when every staged line serves 4-6 taps
+// (tools/probes/lds_gather_probe.hip).  So: one workgroup (512 threads, two per CU) owns a 16 x 8 tile of queries of ONE head;
+// per queue entry it stages the (TX + 2 HALO + 2) x (TY + 2 HALO + 2) lines of that head around the tile (LDS-DMA, 70 KiB;
+// lines beyond the map repeat the border pixel: finite values under the zero coefficients of taps outside, as the global form's
+// in-range neighbour) and every 8-lane group serves its two rows' 16 taps of the entry with ds_read_b128.  A point whose
+// footprint leaves the staged region (offsets beyond the halo, points outside the map) sends its WAVEFRONT through the
+// global-memory taps of msda_fused_d32_kernel for that (row, queue entry) — any offsets are exact, only slower.
+// Same parameters, same coefficients, same order of sums: bit-equal to msda_fused_d32_kernel<float, 4, 2, 4, 1, 8>.
+#ifndef BEVMSDA_TSA_LDS_TY
+#define BEVMSDA_TSA_LDS_TY 8          // A/B builds: 16 (98 KiB regions, one workgroup per CU, four rows per lane group)
+#endif
+#ifndef BEVMSDA_TSA_LDS_DIAG
+#define BEVMSDA_TSA_LDS_DIAG 0        // diagnostic builds (wrong results): bit 0 no staging, bit 1 no taps, bit 2 no front-end loads
+#endif
+constexpr int kTsaLdsTX = 16, kTsaLdsTY = BEVMSDA_TSA_LDS_TY, kTsaLdsHalo = 5;
+constexpr int kTsaLdsRW = kTsaLdsTX + 2 * kTsaLdsHalo + 2, kTsaLdsRH = kTsaLdsTY + 2 * kTsaLdsHalo + 2;   // 28 x 20 lines
+constexpr uint32_t kTsaLdsNoLine = 0xffffffffu;
+
+template <int J0, int j, int CNT>
+struct IssuePointsLds {
+  static __device__ __forceinline__ void run(const PointParams &p, uint32_t my_line, const unsigned char *region, uint32_t lane_b,
+                                             f32x4 (&v)[CNT][4], float (&k)[CNT][4]) {
+    constexpr int J = J0 + j;
+    constexpr uint32_t dy = kTsaLdsRW * 128;
+    const uint32_t o = bcast8<J>(my_line) + lane_b;
+    k[j][0] = bcast8<J>(p.k00); k[j][1] = bcast8<J>(p.k01);
+    k[j][2] = bcast8<J>(p.k10); k[j][3] = bcast8<J>(p.k11);
+    v[j][0] = *reinterpret_cast<const f32x4 *>(region + o);
+    v[j][1] = *reinterpret_cast<const f32x4 *>(region + o + 128);
+    v[j][2] = *reinterpret_cast<const f32x4 *>(region + o + dy);
+    v[j][3] = *reinterpret_cast<const f32x4 *>(region + o + dy + 128);
+    if constexpr (j + 1 < CNT) IssuePointsLds<J0, j + 1, CNT>::run(p, my_line, region, lane_b, v, k);
+  }
+};
+
+template <int J0, int CNT>
+__device__ __forceinline__ void sample_points_lds(const PointParams &p, uint32_t my_line, const unsigned char *region, uint32_t lane_b,
+                                                  f32x4 &acc) {
+  f32x4 v[CNT][4];
+  float k[CNT][4];
+  IssuePointsLds<J0, 0, CNT>::run(p, my_line, region, lane_b, v, k);
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[0] = fmaf(k[j][t], v[j][t][0], acc[0]);
+      acc[1] = fmaf(k[j][t], v[j][t][1], acc[1]);
+      acc[2] = fmaf(k[j][t], v[j][t][2], acc[2]);
+      acc[3] = fmaf(k[j][t], v[j][t][3], acc[3]);
+    }
+  }
+}
+
+template <int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+msda_fused_d32_tsa_lds_kernel(const FusedArgs f) {
+  using T = float;
+  constexpr int D = 32, PT = 4, Mh = 8, TX = kTsaLdsTX, TY = kTsaLdsTY, RW = kTsaLdsRW, RH = kTsaLdsRH, HALO = kTsaLdsHalo;
+  constexpr int NLINES = RW * RH;                              // 560 lines = 70 KiB
+  static_assert(NLINES % 8 == 0, "whole wavefront DMA instructions (8 lines each)");
+  __shared__ __attribute__((aligned(16))) unsigned char region[NLINES * 128];
+  const KArgs &a = f.k;
+  const int tid = threadIdx.x, lig = tid & 7, grp = tid >> 3, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = static_cast<int>(a.shapes[0]), W = static_cast<int>(a.shapes[1]);
+  const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+  const int nb = tiles_x * tiles_y * Mh;
+  const int per = (nb + 7) >> 3;                                // XCD x walks the logical blocks [x per, (x + 1) per): one band of the grid
+  if (static_cast<int>(blockIdx.x >> 3) >= per) return;
+  const int lb = static_cast<int>(blockIdx.x & 7) * per + static_cast<int>(blockIdx.x >> 3);
+  if (lb >= nb) return;
+  const int m = lb & 7, tile = lb >> 3;                         // (the 8 heads of a tile run back to back on one XCD: same pixels)
+  const int x0 = (tile % tiles_x) * TX, y0 = (tile / tiles_x) * TY;
+  const uint32_t pix_bytes = static_cast<uint32_t>(Mh) * D * sizeof(T);
+  const uint32_t lane_term = lig * 4 * static_cast<uint32_t>(sizeof(T));
+  const uint32_t lbytes = static_cast<uint32_t>(a.lstart[0]) * pix_bytes;
+  const uint32_t total_bytes = static_cast<uint32_t>(static_cast<unsigned long long>(a.N) * a.S * pix_bytes);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0,
+                                                                  static_cast<int>(total_bytes), 0x00020000);
+  const float sc = f.out_scale;
+  const uint32_t q = lig / PT, pj = lig % PT;                   // my queue entry / point
+  const uint32_t nq = q * static_cast<uint32_t>(f.vadd);        // (batch entry 0)
+  const uint32_t level_base = static_cast<uint32_t>((static_cast<unsigned long long>(nq) * a.S * Mh + m) * D * sizeof(T)) + lbytes;
+  const float2 *__restrict__ rf2 = reinterpret_cast<const float2 *>(f.ref);
+  // the staged regions' origins: HALO pixels up and left of the tile's first query as the queue entry sees it
+  int ox[2], oy[2];
+  {
+    const long rc = static_cast<long>(y0) * W + x0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float2 c = rf2[(rc * f.K + e) * f.A];
+      ox[e] = static_cast<int>(floorf(c.x * static_cast<float>(W) - 0.5f)) - HALO;
+      oy[e] = static_cast<int>(floorf(c.y * static_cast<float>(H) - 0.5f)) - HALO;
+    }
+  }
+  // my NR rows: (x0 + gx, y0 + gy) and every 4th grid row below
+  constexpr int NR = TX * TY / 64;
+  const int gx = grp & 15, gy = grp >> 4;
+  PointParams pp[NR];
+  uint32_t line[NR];
+  uint32_t orow[NR];
+  bool act[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int x = x0 + gx, y = y0 + gy + 4 * i;
+    act[i] = x < W && y < H;
+    const long r = act[i] ? static_cast<long>(y) * W + x : a.NQ - 1;
+    orow[i] = static_cast<uint32_t>((r * Mh + m) * D + lig * 4);
+#if BEVMSDA_TSA_LDS_DIAG & 4
+    const float lg = 0.1f * pj;
+    const float2 of = make_float2(1.f + pj, 0.5f * q);
+    const float2 rf = make_float2((x + 0.5f) / W, (y + 0.5f) / H);
+#else
+    const float lg = f.logits[r * f.proj_row + m * f.lg_head + q * f.lg_k + pj];
+    const float2 of = reinterpret_cast<const float2 *>(f.offs + r * f.proj_row + m * f.off_head + q * f.off_k)[pj];
+    const float2 rf = rf2[(r * f.K + q) * f.A];
+#endif
+    const float mx = lanes_max<PT>(lg);
+    const float e = expf(lg - mx);
+    const float sum = lanes_sum<PT>(e);
+    const float lx = rf.x + of.x / static_cast<float>(W);
+    const float ly = rf.y + of.y / static_cast<float>(H);
+    const float aw = act[i] ? e / sum : 0.f;
+    int fx0, fy0;
+    pp[i] = point_params_xy(lx, ly, aw, H, W, level_base, pix_bytes, fx0, fy0);
+    // the footprint's top-left pixel inside my queue entry's region
+    const int px = fx0 - (q ? ox[1] : ox[0]);
+    const int py = fy0 - (q ? oy[1] : oy[0]);
+    const bool in = pp[i].off != kOobOffset && px >= 0 && px + 1 < RW && py >= 0 && py + 1 < RH;
+    line[i] = in ? static_cast<uint32_t>(py * RW + px) * 128u : kTsaLdsNoLine;
+  }
+  f32x4 acc[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char *vbase = static_cast<const char *>(a.value);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (e) __syncthreads();                                     // every wavefront is done with the first entry's lines
+    {
+      const unsigned long long ebase = (static_cast<unsigned long long>(e) * f.vadd * a.S + static_cast<unsigned long long>(a.lstart[0])) * pix_bytes
+                                       + static_cast<unsigned long long>(m) * D * sizeof(T) + lane_term;
+#pragma nounroll
+      for (int l0 = wave * 8; l0 < ((BEVMSDA_TSA_LDS_DIAG & 1) ? 0 : NLINES); l0 += 64) {          // 8 lines per wavefront instruction
+        const int li = l0 + (lane >> 3);
+        const int ry = li / RW, rx = li - ry * RW;
+        int sx = ox[e] + rx, sy = oy[e] + ry;
+        sx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+        sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+        const char *src = vbase + ebase + static_cast<unsigned long long>(sy * W + sx) * pix_bytes;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                         (__attribute__((address_space(3))) void *)(region + l0 * 128), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ((BEVMSDA_TSA_LDS_DIAG & 2) ? 0 : NR); ++i) {
+      // (lanes 4 e .. 4 e + 3 of a group own this entry's points; `line` of the other lanes is not read)
+      const bool mine = (lig >> 2) == e;
+      const bool slow = __builtin_amdgcn_ballot_w64(mine && line[i] == kTsaLdsNoLine) != 0;
+      if (slow) {
+        if (e == 0) sample_points<0, PT, T>(pp[i], rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc[i]);
+        else sample_points<PT, PT, T>(pp[i], rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc[i]);
+      } else {
+        if (e == 0) sample_points_lds<0, PT>(pp[i], line[i], region, lane_term, acc[i]);
+        else sample_points_lds<PT, PT>(pp[i], line[i], region, lane_term, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (act[i])
+      *reinterpret_cast<float4 *>(static_cast<T *>(a.out) + orow[i]) = make_float4(acc[i][0] * sc, acc[i][1] * sc, acc[i][2] * sc, acc[i][3] * sc);
 }
 
 // The same kernel over a device-side row count (DynRows): head = one workgroup per logical block of

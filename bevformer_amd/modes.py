@@ -44,7 +44,8 @@ class Modes:
         # fused sampling kernels with compile-time head / level counts (msda_d32.h LC / MC), the library's reserved[5]: 0 =
         # default (TemporalSelfAttention's shape specialised at 128 registers), 1 = generic kernels only, 2 = TSA's at 64
         # registers, 3 = SpatialCrossAttention's shape specialised too (A/B knobs; profiles/r5), 4 = TSA's shape on the
-        # resident, software-pipelined grid (round 6: 3 % faster, twice the L2 misses — opt-in; profiles/r6x)
+        # resident, software-pipelined grid (round 6: 3 % faster, twice the L2 misses — opt-in; profiles/r6x), 5 = TSA's shape with
+        # each 16 x 8 tile's tap lines staged in LDS (round 6: bit-equal, level with the default — opt-in; DESIGN K1-LDS)
         self.fused_spec = int(env("BEVMSDA_FUSED_SPEC", "0"))
         # sampling launches over a device-side row count: 1 = ONE launch sized by the row CAPACITY (surplus workgroups return on
         # their first instruction), 0 = a launch sized by the host's hint + a small strided tail launch for rows beyond it

@@ -670,7 +670,8 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                     spatial_shapes=bev_shapes, level_start_index=bev_start,
                     defer_residual=_defer(i), post_norm=_post_norm(i), chain=_chain_t(i),
-                    offs_attn_proj=tsa_proj if i == 0 else None, **kwargs)
+                    offs_attn_proj=tsa_proj if i == 0 else None,
+                    bev_hw=(bev_h, bev_w) if (bev_h and bev_w and frame_plan is not None) else None, **kwargs)
                 attn_i += 1
                 if isinstance(query, ops.NormedWithProj):
                     query, next_proj, skip_norm = query.t, query.proj, True

@@ -223,7 +223,8 @@ class TemporalSelfAttention(BaseModule):
                                  ref, None, M=M, L=L, P=P, K=nq, off_head=nq * L * P * 2,
                                  off_k=L * P * 2, lg_head=nq * L * P, lg_k=L * P, ref_mode=1,
                                  vmul=1 if shared_value else nq, vadd=0 if shared_value else 1,
-                                 Q=Q, tag="tsa_fwd")
+                                 Q=Q, tag="tsa_fwd",
+                                 grid_hw=kwargs.get("bev_hw") if (bs == 1 and not shared_value and num_value == Q) else None)
             if out is not None:
                 out = out.to(query.dtype).view(bs, Q, C)
         vsink = kwargs.get("tsa_projected_value_sink") if v is tsa_projected_value else None

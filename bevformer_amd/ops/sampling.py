@@ -139,7 +139,7 @@ _RETIRED_FUSED_KWARGS = frozenset(("cam_start", "max_cam_rows", "lds_pixels"))
 
 def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_batch, *, M, L, P,
                K, off_head, off_k, lg_head, lg_k, ref_mode, vmul, vadd, Q=0, row_src=None,
-               tag="msda_fwd", nrows=None, launch_rows=0, save=None, **retired):
+               tag="msda_fwd", nrows=None, launch_rows=0, save=None, grid_hw=None, **retired):
     """Sampling with the softmax / location prologue and the queue mean fused in
     (C ABI: ``bevmsda_fused_forward_*``, include/bevmsda.h).
 
@@ -156,7 +156,9 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
     ``launch_rows`` is the host's hint of that count (sizes the main launch; 0 = no hint).
     ``save = (loc (R, M, L, P, 2) or None, attn (R, M, L, P))`` fp32 (with ``nrows``; K = 1, P = 8, L >= 2): the kernel also
     writes the sampling locations and attention weights its rows used (``bevmsda_fused_forward_rows_save_*``) — what the
-    operator's backward reads."""
+    operator's backward reads.  ``grid_hw = (height, width)``: the caller's HOST copy of the one level's shape when the rows
+    are that grid's cells in raster order (TemporalSelfAttention over the BEV grid): lets the library take the kernel that stages
+    a tile's tap lines in LDS (``modes.fused_spec = 5``, ``bevmsda_fused_desc.reserved[5]``)."""
     unknown = set(retired) - _RETIRED_FUSED_KWARGS
     if unknown:         # (the options of the retired LDS-staged kernels are still accepted and ignored; a typo is not)
         raise TypeError(f"msda_fused() got unexpected keyword arguments {sorted(unknown)}")
@@ -182,6 +184,9 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
                           lg_k=lg_k, vmul=vmul, vadd=vadd)
     if _m().fused_spec:                     # A/B knob of the specialised bodies (modes.Modes.fused_spec)
         desc.reserved[5] = _m().fused_spec
+    if grid_hw is not None and nrows is None and L == 1 and 0 < grid_hw[0] < 32768 and 0 < grid_hw[1] < 65536 \
+            and grid_hw[0] * grid_hw[1] == R:
+        desc.reserved[3] = (int(grid_hw[0]) << 16) | int(grid_hw[1])
     if _m().fused_wpe and nrows is None:   # benchmark sweeps: register budget of the kernel
         desc.reserved[0] = _m().fused_wpe
     if _m().fused_lds_pad_kb and L > 1:    # occupancy cap of the multi-level (SCA) launch

@@ -232,7 +232,11 @@ typedef struct bevmsda_fused_desc {
                             0 = default (the 8-head, one-level, two-entry shape of TemporalSelfAttention at 128
                             registers), 1 = generic kernels only, 2 = that body at 64 registers, 3 = the 8-head,
                             4-level shape of SpatialCrossAttention specialised too (no gain: profiles/r5), 4 = TemporalSelfAttention's
-                            shape on a resident, software-pipelined grid (3 % faster, twice the L2 misses: profiles/r6x) */
+                            shape on a resident, software-pipelined grid (3 % faster, twice the L2 misses: profiles/r6x), 5 =
+                            that shape with the tile's tap lines staged in LDS (csrc/msda_d32.h, msda_fused_d32_tsa_lds_kernel): the
+                            rows must be the cells of the sampled grid in raster order (one batch entry, no row_batch / row_src)
+                            and [3] (static-row entry points) carries the HOST's copy of that grid's shape, (height << 16) | width,
+                            which sizes the launch; anything else runs the default kernel */
 } bevmsda_fused_desc;
 
 int bevmsda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
