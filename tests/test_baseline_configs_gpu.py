@@ -158,7 +158,8 @@ def test_fused_tsa_kernel_at_the_full_base_grid():
 
 
 @pytest.mark.parametrize("gh,gw,spread,shift", [(200, 200, 1.0, (0.013, -0.021)), (200, 200, 6.0, (0.0, 0.0)), (37, 53, 1.0, (0.2, 0.1)),
-                                                 (8, 16, 1.0, (0.0, 0.0)), (50, 50, 2.5, (-0.04, 0.03)), (150, 150, 1.0, (1.5, 0.0))])
+                                                 (8, 16, 1.0, (0.0, 0.0)), (50, 50, 2.5, (-0.04, 0.03)), (150, 150, 1.0, (1.5, 0.0)),
+                                                 (120, 130, 2.5, (0.0, 0.0))])
 def test_tsa_kernel_with_the_tiles_tap_lines_staged_in_lds_is_bit_equal(gh, gw, spread, shift):
     """``msda_fused_d32_tsa_lds_kernel`` (``bevmsda_fused_desc.reserved[5] = 5``, ``grid_hw``): TemporalSelfAttention's call over the
     BEV grid with each 16 x 8 tile's tap lines staged in LDS — same parameters, coefficients and order of sums as the default
@@ -178,16 +179,19 @@ def test_tsa_kernel_with_the_tiles_tap_lines_staged_in_lds_is_bit_equal(gh, gw, 
     ys, xs = torch.meshgrid((torch.arange(gh) + 0.5) / gh, (torch.arange(gw) + 0.5) / gw, indexing="ij")
     cur = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)                      # (Q, 2) normalised (x, y)
     ref = torch.stack([cur + torch.tensor(shift), cur], 1).reshape(Q, K, L, 2).contiguous()
+    if spread == 2.5:           # (one case with reference points that are NOT the grid: every footprint is tested against the region)
+        ref = torch.rand(Q, K, L, 2, generator=g)
     kw = dict(M=M, L=L, P=P, K=K, off_head=K * L * P * 2, off_k=L * P * 2, lg_head=K * L * P, lg_k=L * P,
               ref_mode=1, vmul=2, vadd=1, Q=Q)
     args = (value.to(DEV), shapes.to(DEV), start.to(DEV), proj.to(DEV), n_off, ref.to(DEV), None)
     want = ops.msda_fused(*args, **kw)
-    with ops.using(fused_spec=5):
-        got = ops.msda_fused(*args, grid_hw=(gh, gw), **kw)
-        same = ops.msda_fused(*args, **kw)              # (without the host's copy of the grid shape: the default kernel)
-    assert got is not None and torch.equal(same, want)
-    assert torch.equal(got, want), (got - want).abs().max().item()
-    assert torch.isfinite(got).all()
+    for spec in (5,):
+        with ops.using(fused_spec=spec):
+            got = ops.msda_fused(*args, grid_hw=(gh, gw), **kw)
+            same = ops.msda_fused(*args, **kw)              # (without the host's copy of the grid shape: the default kernel)
+        assert got is not None and torch.equal(same, want)
+        assert torch.equal(got, want), (spec, (got - want).abs().max().item())
+        assert torch.isfinite(got).all()
 
 
 def _gradient_case(name, storage, l2_tol, max_tol):
