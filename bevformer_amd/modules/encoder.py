@@ -293,7 +293,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         w, b = ops.merged_linear_params(tsa, tsa.sampling_offsets, tsa.attention_weights)
         if tuple(w.shape) != (w.shape[0], 512) or w.shape[0] % 64 or w.shape[0] > 256:
             return None
-        return {"first": first, "pos": pos, "w": w, "b": b, "proj": None, "module": tsa}
+        return {"first": first, "pos": pos, "w": w, "b": b, "proj": None}
 
     def _stack_free(self, history, bev_query, bs):
         """May the layers run without the stacked [history, bev_query] tensor?  Inference at bs = 1 on the GPU with every
