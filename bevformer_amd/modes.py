@@ -51,7 +51,7 @@ class Modes:
         # their first instruction), 0 = a launch sized by the host's hint + a small strided tail launch for rows beyond it
         self.fused_capacity_launch = env("BEVMSDA_FUSED_CAPACITY", "0") == "1"
         # A/B knob: re-pack the weight images of trainable parameters inside EVERY captured graph (round 4's behaviour; the
-        # default re-packs only in graphs captured with grad mode on: ops.gemm._cache_ok)
+        # default re-packs only in graphs captured with grad mode on: ops.images._cache_ok)
         self.graph_repack = env("BEVMSDA_GRAPH_REPACK", "0") == "1"
         self.fused_lds_pad_kb = int(env("BEVMSDA_FUSED_LDS_PAD", "0"))                                    # co-scheduling probe: occupancy cap of the sampling kernel
         self.stack_free = env("BEVMSDA_STACK_FREE", "1") == "1"      # inference: TSA's [history ; queries] value projected without forming the stack

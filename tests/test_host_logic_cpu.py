@@ -257,7 +257,7 @@ def test_ops_package_has_no_dangling_globals_and_keeps_its_substitution_points()
     import inspect
     import types
     from bevformer_amd import ops
-    from bevformer_amd.ops import _base, gemm, prologue, sampling
+    from bevformer_amd.ops import _base, chains, gemm, images, prologue, sampling
 
     def code_objects(co):
         yield co
@@ -265,7 +265,7 @@ def test_ops_package_has_no_dangling_globals_and_keeps_its_substitution_points()
             if isinstance(c, types.CodeType):
                 yield from code_objects(c)
 
-    for mod in (_base, sampling, gemm, prologue):
+    for mod in (_base, sampling, images, gemm, chains, prologue):
         missing = set()
         for v in vars(mod).values():
             fns = [v] if isinstance(v, types.FunctionType) else \
@@ -323,14 +323,14 @@ def test_captured_weight_images_report_stale_weights(monkeypatch):
     (weight, version, address) at capture so that ``ops.assert_graph_weights_fresh`` can tell a changed weight."""
     import torch
     from bevformer_amd import ops
-    from bevformer_amd.ops import gemm
+    from bevformer_amd.ops import images
     ops.release_captured_images()
     w = torch.nn.Parameter(torch.randn(8, 4))
     image = torch.zeros(16, dtype=torch.int16)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
-    assert gemm._cached_image(("key", image), w) is image
-    assert gemm._cached_image(("key", image), w) is image          # same image again: one record
-    assert len(gemm._CAPTURED_IMAGES) == 1
+    assert images._cached_image(("key", image), w) is image
+    assert images._cached_image(("key", image), w) is image        # same image again: one record
+    assert len(images._CAPTURED_IMAGES) == 1
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     assert ops.graph_weights_stale() == []
     ops.assert_graph_weights_fresh()
