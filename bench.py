@@ -336,10 +336,16 @@ class Config:
             return self.enc(self.q, self.f, self.f, **self.kw)
 
     def rows(self):
-        """Ragged SCA rows of the current frame (one device read; after the timed region)."""
+        """Ragged SCA rows of the current frame (one device read; after the timed region) — under BEV tiling THIS rank's rows:
+        the sampling launches the kernel timer saw cover the rank's tile, and so must their algorithmic bytes."""
+        tile = {}
+        if getattr(self.enc, "bev_tiling", None) is not None and self.enc.device_plans:
+            from bevformer_amd import bev_tiling
+            _, _, qr, cell_perm, _, _ = bev_tiling.rank_tile(self.enc, self.w["bev_h"], self.w["bev_w"], self.dev)
+            tile = dict(tile=qr, cell_perm=cell_perm)
         with torch.set_grad_enabled(self.backward):
             plan = self.enc.frame_plan(self.w["bev_h"], self.w["bev_w"], 1, self.kw["img_metas"], self.dev,
-                                       torch.float32)
+                                       torch.float32, **tile)
         if plan.dynamic:
             assert plan.dropped_rows() == 0, "frame plan: rows dropped (row capacity too small)"
             return int(plan.nrows_dev.item())
@@ -979,7 +985,8 @@ def main():
         if dom is None:         # --no-kernel-timers: whole-step timing only
             dom = dict(GBs=float("nan"), avg_us=None, alg_bytes=None, launches=0)
         traffic = None
-        if os.path.exists(args.traffic_json):
+        # (the profile was taken on the untiled frame: a tiled rank's launches cover its tile only — no counter figure for them)
+        if os.path.exists(args.traffic_json) and not tiling:
             try:
                 tj = json.load(open(args.traffic_json))
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -1026,6 +1033,7 @@ def main():
                        "gemm": gemm_desc,
                        "global_batch": 1, "parallelism": (f"bev-{cfg.enc.bev_tiling.layout if getattr(cfg.enc, 'bev_tiling', None) is not None else 'row'}-tiles x{world}"
                                        if world > 1 else "single GPU"),
+                       # (BEV tiling: the rows of rank 0's tile — what its sampling launches, and the roofline below, cover)
                        "sca_rows_per_frame": rows_per_frame},
             "windows": {"ms_per_step": [round(p, 4) for p in per], "min": min(per), "median": statistics.median(per),
                         "n": len(per), "note": "ms_per_step / value = the median window"},

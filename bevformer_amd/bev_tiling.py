@@ -190,6 +190,26 @@ def all_gather_rows(local, blocks, bev_w, group=None, simulate=None, inverse=Non
     return torch.cat([buf[r, :, :sizes[r]] for r in range(world)], 1)
 
 
+def rank_tile(encoder, bev_h, bev_w, device):
+    """This rank's share of the queries under ``encoder.bev_tiling``: ``(blocks, unit, (q0, q1), cell_perm, rows_idx,
+    inverse)`` — the blocks of every rank in units of ``unit`` queries, my range of the (row- or sector-ordered) queries, the
+    sector permutation handed to the frame plan (None for row tiles), the grid cells of my queries and the grid-order
+    inverse of the sector order (both None for row tiles)."""
+    tiling = encoder.bev_tiling
+    group, world, rank = tiling.group, tiling.world, tiling.rank
+    if tiling.layout == "sectors":
+        # queries in sector order: tile = a contiguous range of that order; blocks in units of ONE query
+        pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, device, group=group,
+                                                      collective=tiling.simulate is None,
+                                                      cache=encoder.__dict__.setdefault("_sector_orders", {}))
+        blocks, unit = query_blocks(bev_h * bev_w, world), 1
+        q0, q1 = blocks[rank]
+        return blocks, unit, (q0, q1), (pname, perm_cpu), perm[q0:q1], inverse
+    blocks, unit = row_blocks(bev_h, world), bev_w
+    h0, h1 = blocks[rank]
+    return blocks, unit, (h0 * bev_w, h1 * bev_w), None, None, None
+
+
 def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                   spatial_shapes=None, level_start_index=None, prev_bev=None, shift=0.0,
                   **kwargs):
@@ -203,20 +223,7 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
         raise RuntimeError("BEV tiling is an inference schedule (its all-gather has no autograd); "
                            "call it under torch.no_grad() or disable_bev_tiling() for training")
     sectors = tiling.layout == "sectors"
-    cell_perm = rows_idx = inverse = None
-    if sectors:
-        # queries in sector order: tile = a contiguous range of that order; blocks in units of ONE query
-        pname, perm, inverse, perm_cpu = sector_order(bev_h, bev_w, encoder.pc_range, bev_query.device, group=group,
-                                                      collective=tiling.simulate is None,
-                                                      cache=encoder.__dict__.setdefault("_sector_orders", {}))
-        cell_perm = (pname, perm_cpu)
-        blocks, unit = query_blocks(bev_h * bev_w, world), 1
-        q0, q1 = blocks[rank]
-        rows_idx = perm[q0:q1]                  # the grid cells of my queries
-    else:
-        blocks, unit = row_blocks(bev_h, world), bev_w
-        h0, h1 = blocks[rank]
-        q0, q1 = h0 * bev_w, h1 * bev_w
+    blocks, unit, (q0, q1), cell_perm, rows_idx, inverse = rank_tile(encoder, bev_h, bev_w, bev_query.device)
     if encoder.device_plans and bev_query.is_cuda:
         # device-side plan of my tile: rows only for queries [q0, q1), tile-local slot numbering
         tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
