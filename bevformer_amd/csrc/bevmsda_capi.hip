@@ -27,7 +27,10 @@ using bevmsda::KArgs;
 using bevmsda::bf16_t;
 
 // library defaults (chosen from the sweeps recorded in DESIGN.md)
-constexpr int kDefaultQtileFwd = 8;
+#ifndef BEVMSDA_QTILE_FWD
+#define BEVMSDA_QTILE_FWD 8          // A/B builds: rows of one head in adjacent lane groups (a power of two; 8 = one wavefront)
+#endif
+constexpr int kDefaultQtileFwd = BEVMSDA_QTILE_FWD;
 constexpr int kDefaultQtileBwd = 8;
 constexpr int kTsaPipeGrid = 1024;           // resident workgroups of the pipelined TSA sampling kernel: 4 per CU, 128 per XCD
 constexpr long kDynGridBlocks = 2048;        // grid of the device-row-count sampling launches (multiple of 8)

@@ -339,15 +339,28 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
 
   // softmax over the L*PT logits of my (row, head, queue entry): ONE batch of loads (my
   // point's logit of every level), one exp per level, butterflies over the PT lanes
+#ifndef BEVMSDA_SCA_DIAG
+#define BEVMSDA_SCA_DIAG 0          // diagnostic builds (wrong results): 1 = no softmax arithmetic, 2 = no front-end loads either
+#endif
+#if BEVMSDA_SCA_DIAG >= 2
+  float e0 = 0.1f * pj, e1 = 0.2f, e2 = 0.3f, e3 = 0.4f;
+  float2 of = make_float2(1.f + pj, 2.f - pj);
+  float2 rf = make_float2(0.3f + 1e-5f * (r & 1023), 0.4f + 1e-5f * m);
+#else
   float e0 = lgp[0];
   float e1 = L > 1 ? lgp[PT] : -INFINITY;
   float e2 = L > 2 ? lgp[2 * PT] : -INFINITY;
   float e3 = L > 3 ? lgp[3 * PT] : -INFINITY;
   float2 of = ofp[0];
   float2 rf = rfp[f.ref_mode == 0 ? pj % f.A : 0];
+#endif
+#if BEVMSDA_SCA_DIAG >= 1
+  const float sum = 32.f;
+#else
   const float mx = lanes_max<PT>(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
   e0 = expf(e0 - mx); e1 = expf(e1 - mx); e2 = expf(e2 - mx); e3 = expf(e3 - mx);   // exp(-inf) = 0
   const float sum = lanes_sum<PT>((e0 + e1) + (e2 + e3));
+#endif
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // (a known level count is NOT unrolled: four levels' taps in one body spill at 128 registers — 1.6 KB of scratch, measured)
@@ -369,10 +382,12 @@ __device__ __forceinline__ void msda_fused_d32_body(const FusedArgs &f, int lblo
         f.save_attn[o] = aw;
       }
     }
+#if BEVMSDA_SCA_DIAG < 2
     if (l + 1 < L) {                // next level's record travels under this level's taps
       of = ofp[(l + 1) * PT];
       if (f.ref_mode == 1) rf = rfp[l + 1];
     }
+#endif
     sample_points<0, NP, T>(p, rsrc, lane_term, pix_bytes, static_cast<uint32_t>(W) * pix_bytes, acc);
   }
   if (active) {
