@@ -78,7 +78,7 @@ class Modes:
         # inference: a layer's last kernel also makes the NEXT layer's TemporalSelfAttention offset / weight projection of
         # the rows it produces (csrc/linear_chain.h TP, BEVFormerEncoder.tsa_seam; round 6)
         self.tsa_seam = env("BEVMSDA_TSA_SEAM", "1") == "1"
-        self.overlap_value_proj = env("BEVMSDA_OVERLAP", "0") == "1"  # inference: hoisted SCA value projection on a side stream
+        self.overlap_value_proj = env("BEVMSDA_OVERLAP", "1") == "1"  # inference: hoisted SCA value projection on a side stream (its tail rounds and the TSA chain's fill each other: -2 % of the base frame, round 6)
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 
     def snapshot(self):

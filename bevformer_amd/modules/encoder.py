@@ -71,10 +71,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # sync, row count on the device); False keeps the torch-op builder with its host syncs
         self.device_plans = True
         self._planners = {}
-        # inference, opt-in (``ops.using(overlap_value_proj=True)`` / BEVMSDA_OVERLAP=1 at import): issue the hoisted SCA value projection on a second stream so
-        # that it runs beside the first layer's TemporalSelfAttention chain, joined before the first
-        # SpatialCrossAttention.  Measured: 4.956 vs 4.995 ms per base frame (0.8 %: the chain's kernels
-        # leave few CUs idle) — not worth a second stream by default.
+        # inference (``ops.using(overlap_value_proj=...)`` / BEVMSDA_OVERLAP at import; on by default since round 6): the hoisted
+        # SCA value projection is issued on a second stream, so that it runs beside the TSA value projection and the first
+        # layer's TemporalSelfAttention chain, joined before the first SpatialCrossAttention.  Two chip-filling kernels do not
+        # interleave (§4 "co-scheduling"), but each of these launches ends in a partial round of workgroups (the camera-value
+        # GEMM: 5.6 rounds of one 128-row workgroup per CU) and the other stream's workgroups fill those tails: 4.00-4.04 against
+        # 4.09-4.11 ms per base frame, four interleaved rounds (profiles/r6/r6z_overlap_ab.txt; round 2, on slower kernels: 0.8 %).
         self.overlap_value_proj = None      # None: the ``overlap_value_proj`` mode (bevformer_amd/modes.py)
         self._side_stream = None
 
@@ -226,13 +228,16 @@ class BEVFormerEncoder(TransformerLayerSequence):
             seg = (plan.cam_start, S, spatial_shapes.contiguous())
         self._last_segments = seg            # (bench.py reports how many cameras a rank projects)
         overlap = ops.modes().overlap_value_proj if self.overlap_value_proj is None else self.overlap_value_proj
-        if overlap and ops._GEMM_TIMER["cb"] is None:
+        if overlap and not ops.gemm_timer_active():     # (a recording timer brackets launches with events on ONE stream)
             cur = torch.cuda.current_stream(value.device)
             if self._side_stream is None or self._side_stream.device != value.device:
                 self._side_stream = torch.cuda.Stream(value.device)
             side = self._side_stream
-            ops.packed_weight(w)                       # (weight image built on the main stream, once)
+            ops.packed_weight(w)                       # (weight images built on the main stream, once)
+            if w.is_contiguous():
+                ops.panel_weight(w)
             side.wait_stream(cur)
+            feats.record_stream(side)                  # (bs > 1: a copy made on the main stream, read by the side stream's kernel)
             with torch.cuda.stream(side):
                 y = ops.linear(feats, w, b, groups=L, out_dtype=store, tag="sca_value_proj", segments=seg)
                 if y is not None:

@@ -173,6 +173,16 @@ def set_gemm_kernel(name):
     _modes.process_defaults().gemm_kernel = name
 
 
+def gemm_timer_active():
+    """Is a GEMM timer registered AND recording?  A registered callback whose owner says ``enabled = False`` (bench.py's
+    ``KernelTimer`` between its eager timing passes, e.g. while the step is captured into a HIP graph) brackets nothing — the
+    schedule need not keep its launches on one stream for it."""
+    cb = _GEMM_TIMER["cb"]
+    if cb is None:
+        return False
+    return bool(getattr(getattr(cb, "__self__", None), "enabled", True))
+
+
 def set_gemm_timer(cb):
     """``cb(tag, flops, bytes)`` -> context manager around every ``linear`` launch."""
     _GEMM_TIMER["cb"] = cb

@@ -331,6 +331,57 @@ def test_next_layers_tsa_projection_made_by_the_previous_layers_last_kernel(name
         ops.set_gemm_mode(saved)
 
 
+@pytest.mark.parametrize("name,bs", [("micro4", 1), ("micro4", 2), ("small4", 1)])
+def test_hoisted_camera_value_projection_on_a_second_stream(name, bs):
+    """``overlap_value_proj`` (default on): the hoisted SCA value projection is issued on a side stream and joined before the
+    first SpatialCrossAttention — the same kernels on the same operands: bit-equal to the one-stream schedule, eagerly (ten
+    frames back to back: a missing join or a recycled operand would show), inside a captured graph, and with a recording GEMM
+    timer registered (which keeps every launch on one stream)."""
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=9, bs=bs, temporal=True, device=DEV)
+    with torch.no_grad():
+        with ops.using(overlap_value_proj=False):
+            want = enc(q, f, f, **kw)
+        with ops.using(overlap_value_proj=True):
+            for _ in range(10):
+                got = enc(q, f, f, **kw)
+            assert enc._sca_ready is not None, "the projection stayed on the main stream"
+            assert torch.equal(got, want)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                enc(q, f, f, **kw)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = enc(q, f, f, **kw)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
+
+            class _Timer:
+                enabled = True
+
+                def cb(self, tag, flops, nbytes):
+                    import contextlib
+                    return contextlib.nullcontext()
+            t = _Timer()
+            ops.set_gemm_timer(t.cb)
+            try:
+                assert ops.gemm_timer_active()
+                timed = enc(q, f, f, **kw)
+                assert enc._sca_ready is None                 # a recording timer: one stream
+                t.enabled = False
+                assert not ops.gemm_timer_active()
+                enc(q, f, f, **kw)
+                assert enc._sca_ready is not None
+            finally:
+                ops.set_gemm_timer(None)
+            assert torch.equal(timed, want)
+
+
 def test_inference_graph_replays_without_repacking_trainable_weights():
     """A forward step captured under ``torch.no_grad()`` over TRAINABLE parameters uses the cached weight images (round 5:
     the 24 ``lin_panel_pack_weight`` launches of every replayed step were 2.8 % of it); a capture with grad mode on
