@@ -352,6 +352,9 @@ class Config:
         return int(plan.row_batch.numel())
 
 
+HOST_ENQUEUE = []       # seconds the host spent ISSUING each timed window (before its closing fence): launch-bound or not
+
+
 def timed_windows(cfg, step, fence, steps, windows, graph):
     """``windows`` x (``steps`` steps between fences) -> list of seconds."""
     out = []
@@ -364,6 +367,7 @@ def timed_windows(cfg, step, fence, steps, windows, graph):
                 graph.replay()
             else:
                 step()
+        HOST_ENQUEUE.append(time.perf_counter() - t0)
         fence()
         out.append(time.perf_counter() - t0)
     return out
@@ -779,6 +783,7 @@ def compact_line(line):
         p = line["parity"]
         c["parity"] = {k: p.get(k) for k in ("ok", "max_abs", "worst_ratio", "rtol", "atol", "graph_replay_equals_eager")}
     c["launch_mode"] = line.get("launch_mode")
+    c["host_issue_ms_per_step"] = line.get("host_issue_ms_per_step")
     c["ranks"] = line.get("ranks")
     w = line.get("windows") or {}
     c["windows"] = {k: w.get(k) for k in ("min", "median", "n")}
@@ -939,6 +944,7 @@ def main():
         graph_note = queue_step.launch_mode
     elif graph is None:
         timer.enabled = not timer.events
+    del HOST_ENQUEUE[:]
     ts = timed_windows(cfg, step, fence, args.steps, 1, graph)       # window 0 carries the in-region events
     timer.enabled = False
     ts += timed_windows(cfg, step, fence, args.steps, max(0, args.windows - 1), graph)
@@ -1012,6 +1018,9 @@ def main():
             else f"BEV-encoder queries/sec ({args.workload})",
             "value": Q * max(1, args.queue) * args.steps / dt, "unit": "BEV queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            # the host's share: time to ISSUE a step (median over windows; the fence is not in it).  Well under ms_per_step
+            # = the host runs ahead of the GPU and the step is device-bound
+            "host_issue_ms_per_step": statistics.median(HOST_ENQUEUE[:len(ts)]) / args.steps * 1e3 if HOST_ENQUEUE else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             # arithmetic of the path: fp32 storage / sampling / softmax / LayerNorm / accumulation always;
             # GEMM products from bf16x3-split fp32 operands ("f32/bf16x3"), bf16-rounded operands ("bf16")

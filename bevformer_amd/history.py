@@ -10,6 +10,7 @@ callable ``bev_fn(mlvl_feats, img_metas, prev_bev) -> (bs, Q, C)`` (e.g. a parti
 ``PerceptionTransformer.get_bev_features``); backbone, head and boxes stay out of scope.
 """
 import copy
+import os
 
 import torch
 
@@ -110,11 +111,22 @@ class GraphedBevHistory(BevHistory):
 
     ``bev_fn(mlvl_feats, img_metas, prev_bev)`` as for ``BevHistory``; ``mlvl_feats`` are STATIC buffers (the
     backbone writes each frame's features into them; ``step`` copies when handed other tensors).  The
-    returned BEV is a static buffer too: it is overwritten by the next ``step``."""
+    returned BEV is a static buffer too: it is overwritten by the next ``step``.
 
-    def __init__(self, bev_fn, mlvl_feats, video_test_mode=True):
+    ``overlap_value_proj``: the encoder's two-stream form of the hoisted camera-value projection (modes.overlap_value_proj)
+    inside the captured frames.  Off by default HERE although it is on for a bare encoder step: a frame's kernels do finish
+    0.12 ms earlier with it (3.93 against 4.05 ms at base), but a two-queue graph that alternates with stream work (the
+    pose copies) pays cross-queue signals at every graph boundary — 17.31 against 17.08 ms per four base frames, 12.95
+    against 12.59 with bf16 arithmetic (``tools/history_staging_ab.sh``; None / BEVMSDA_QUEUE_OVERLAP=1 turn it on)."""
+
+    STAGING_SLOTS = int(os.environ.get("BEVMSDA_STAGING_SLOTS", "8"))
+
+    def __init__(self, bev_fn, mlvl_feats, video_test_mode=True, overlap_value_proj=None):
         super().__init__(video_test_mode)
         self.bev_fn = bev_fn
+        if overlap_value_proj is None:
+            overlap_value_proj = os.environ.get("BEVMSDA_QUEUE_OVERLAP", "0") == "1"
+        self.overlap_value_proj = bool(overlap_value_proj)
         self.feats = list(mlvl_feats)
         self.device = self.feats[0].device
         self.graphs = {}
@@ -123,6 +135,8 @@ class GraphedBevHistory(BevHistory):
         self.static_metas = None
         self.prev = None               # (bs, Q, C): the history the next frame reads
         self.out = {}
+        self._staging = []             # pinned host slots of the per-frame can-bus / camera-matrix copies
+        self._staged = 0
 
     def _static_inputs(self, metas):
         import numpy as np
@@ -147,11 +161,32 @@ class GraphedBevHistory(BevHistory):
                 m["lidar2img"] = self.l2i[i]
                 self.static_metas.append(m)
         else:
-            self.can_bus.copy_(cb)          # (two small host -> device copies per frame: 144 + 384 bytes per sample)
-            self.l2i.copy_(l2i)
+            # two small host -> device copies per frame (144 + 384 bytes per sample), asynchronous: out of pageable memory a
+            # copy blocks the host until the stream reaches it, i.e. until the previous frame's graph has finished, and every
+            # frame then pays its own launch latency.  A ring of pinned staging slots lets the host run ahead of the GPU; a
+            # slot is reused only after the copy that read it has executed.
+            if self.STAGING_SLOTS <= 0:           # (A/B: the blocking copies)
+                self.can_bus.copy_(cb)
+                self.l2i.copy_(l2i)
+                return
+            if not self._staging:
+                self._staging = [dict(cb=torch.empty_like(cb).pin_memory(), l2i=torch.empty_like(l2i).pin_memory(), done=None)
+                                 for _ in range(self.STAGING_SLOTS)]
+            slot = self._staging[self._staged % len(self._staging)]
+            self._staged += 1
+            if slot["done"] is not None:
+                slot["done"].synchronize()
+            slot["cb"].copy_(cb)
+            slot["l2i"].copy_(l2i)
+            self.can_bus.copy_(slot["cb"], non_blocking=True)
+            self.l2i.copy_(slot["l2i"], non_blocking=True)
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(torch.cuda.current_stream(self.device))
 
     def _run(self, has_prev):
-        out = self.bev_fn(self.feats, self.static_metas, self.prev if has_prev else None)
+        from . import modes
+        with modes.using(overlap_value_proj=self.overlap_value_proj):
+            out = self.bev_fn(self.feats, self.static_metas, self.prev if has_prev else None)
         if self.prev is None:
             self.prev = torch.empty_like(out)
         self.prev.copy_(out)           # the next frame's history (inside the captured step)

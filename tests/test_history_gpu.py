@@ -88,3 +88,39 @@ def test_graph_replayed_history_queue_equals_the_eager_one(name):
                      != kernel_rotation_index(kw["bev_h"], kw["bev_w"], angle, ctr, DEV, device_pose=True)).sum())
         assert int((err > 1e-3).sum()) <= 512 * moved, (moved, err.max().item())
     assert set(graphed.graphs) == {False, True}
+
+
+def test_graphed_queue_forms_agree_and_the_staging_ring_wraps():
+    """The captured frames as one-stream graphs (the queue's default) and as two-stream graphs
+    (``overlap_value_proj=True``), each fed through the ring of pinned pose slots for MORE frames than the ring
+    has slots (a slot is rewritten only after the copy that read it ran), and the blocking-copy form
+    (``STAGING_SLOTS = 0``): the same BEV, bit for bit, frame by frame."""
+    name = "micro4"
+    frames = _video(name, 2 * history.GraphedBevHistory.STAGING_SLOTS + 3, scene_break=9)
+    t, _ = build_transformer_pair(name, device=DEV)
+    mlvl0, _, bq, kw = frames[0]
+    feats = [x.to(DEV) for x in mlvl0]
+    bq_d, pos_d = bq.to(DEV), kw["bev_pos"].to(DEV)
+
+    def bev_fn(f, m, p):
+        return t.get_bev_features(f, bq_d, kw["bev_h"], kw["bev_w"], grid_length=kw["grid_length"],
+                                  bev_pos=pos_d, prev_bev=p, img_metas=m)
+
+    one = history.GraphedBevHistory(bev_fn, feats)
+    two = history.GraphedBevHistory(bev_fn, feats, overlap_value_proj=True)
+    blocking = history.GraphedBevHistory(bev_fn, feats)
+    blocking.STAGING_SLOTS = 0
+    assert one.overlap_value_proj is False and two.overlap_value_proj is True
+    outs = {k: [] for k in ("one", "two", "blocking")}
+    for mlvl, metas, _, _ in frames:           # no synchronisation between frames: the host runs ahead through the ring
+        f = [x.to(DEV) for x in mlvl]
+        outs["one"].append(one.step(None, f, metas).clone())
+    for mlvl, metas, _, _ in frames:
+        outs["two"].append(two.step(None, [x.to(DEV) for x in mlvl], metas).clone())
+    for mlvl, metas, _, _ in frames:
+        outs["blocking"].append(blocking.step(None, [x.to(DEV) for x in mlvl], metas).clone())
+    torch.cuda.synchronize()
+    assert one._staged > len(one._staging) > 0 and not blocking._staging
+    for i in range(len(frames)):
+        assert torch.equal(outs["one"][i], outs["blocking"][i]), i
+        assert torch.equal(outs["one"][i], outs["two"][i]), i
