@@ -579,6 +579,9 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   // (4 wavefronts, two workgroups per CU); 0 = default
   int shape = d->reserved[1];
   if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
+  // desc->reserved[2]: columns of idx (0 = 2; J > 2: rows idx[m, 2..] >= 0 are added to the first row's — inference launches only)
+  const int gst = d->reserved[2] == 0 ? 2 : d->reserved[2];
+  if (gst < 2 || gst > 64 || (gst > 2 && (!idx || save))) return BEVMSDA_ERR_BAD_OPTION;
   // default: 32-row panels up to kChainSmallRows rows, mixed from one whole round of 64-row panels on (measured at 40,000
   // rows, interleaved runs on one box: 103.2-103.6 vs 106.6-107.2 us; profiles/r4/r4f_chain_mixed_shape_ab.txt)
   // (with the next layer's projection behind it the 32-row shape wins at every row count: two workgroups per CU cover each
@@ -612,7 +615,7 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
       if (tt.pos) tt.pos += o * tp->ld_pos;
       tt.proj += o * tp->ld_proj;
     }
-    return ffn_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * 2 : nullptr, scale ? scale + o : nullptr, w0p, b0,
+    return ffn_chain_launch(idx ? rows : rows + o * d->ld_rows, idx ? idx + o * gst : nullptr, scale ? scale + o : nullptr, w0p, b0,
                             res ? res + o * d->ld_res : nullptr, gamma0, beta0, w1p, b1, w2p, b2, gamma1, beta1, &dt,
                             y + o * d->ld_y, stream, save, save ? sv_z0 + o * 256 : nullptr, save ? sv_x + o * 256 : nullptr,
                             save ? sv_h + o * 512 : nullptr, save ? sv_z1 + o * 256 : nullptr, dk0 ? dk0 + o * 256 : nullptr,
@@ -622,7 +625,7 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   const long long nb = (d->M + bm - 1) / bm;
   if (nb >= (1LL << 31)) return BEVMSDA_ERR_TOO_LARGE;
   bevmsda::ChainArgs a{};
-  a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale;
+  a.rows = rows; a.ld_rows = d->ld_rows; a.gidx = idx; a.gscale = scale; a.gstride = gst;
   a.w0 = w0p; a.w1 = w1p; a.w2 = w2p; a.b0 = b0; a.b1 = b1; a.b2 = b2;
   a.res = res; a.ld_res = d->ld_res; a.gamma0 = gamma0; a.beta0 = beta0; a.gamma1 = gamma1; a.beta1 = beta1;
   a.eps0 = d->eps0; a.eps1 = d->eps1; a.y = y; a.ld_y = d->ld_y; a.M = d->M;

@@ -49,7 +49,9 @@ namespace bevmsda {
 struct ChainArgs {
   const float *rows;                // A source rows (ld_rows); with gidx: gathered (two rows per output row)
   long ld_rows;
-  const int32_t *gidx;              // (M, 2) or nullptr: A[m] = rows[m]
+  const int32_t *gidx;              // (M, gstride) or nullptr: A[m] = rows[m]
+  int gstride;                      // 0 / 2: two-row gather; J > 2: columns 2.. (while >= 0) are added to the first row's
+                                    // values before the two-row sum — the plan's slots seen by more than two cameras
   const float *gscale;
   const uint16_t *w0, *w1, *w2;     // fragment-order weight images: (256, 256), (512, 256), (256, 512)
   const float *b0, *b1, *b2;
@@ -678,11 +680,13 @@ linear_chain_kernel(const ChainArgs a) {
     long gm = m0 + row;
     if (gm >= a.M) gm = a.M - 1;               // clamped rows are computed and never stored
     long srow = gm, arow = gm;
-    int g0 = 0, g1 = -1;
+    int g0 = 0, g1 = -1, g2 = -1;
     float gs = 1.f;
+    const int gst = a.gstride > 2 ? a.gstride : 2;
     if (PRE == 2) {
-      g0 = a.gidx[gm * 2];
-      g1 = a.gidx[gm * 2 + 1];
+      g0 = a.gidx[gm * gst];
+      g1 = a.gidx[gm * gst + 1];
+      if (gst > 2) g2 = a.gidx[gm * gst + 2];
       gs = a.gscale[gm];
       srow = g0 < 0 ? 0 : g0;
       arow = g1 < 0 ? 0 : g1;
@@ -712,6 +716,18 @@ linear_chain_kernel(const ChainArgs a) {
       float4 va = *reinterpret_cast<const float4 *>(slot);
       float4 vb = *reinterpret_cast<const float4 *>(slot + 1024);
       if (PRE == 2) {
+        if (g2 >= 0) {
+          // rows of a third.. camera (rare): added to the first row's values in column order, as the stand-alone fold launch
+          // (frame_plan.h: fold_extra_rows_kernel) adds them — the same sums, without that launch
+          for (int j = 2; j < gst; ++j) {
+            const int r = a.gidx[gm * gst + j];
+            if (r < 0) break;
+            const float *sx = a.rows + static_cast<long>(r) * a.ld_rows + (2 * p) * 32 + cx * 4;
+            const float4 xa = *reinterpret_cast<const float4 *>(sx), xb = *reinterpret_cast<const float4 *>(sx + 32);
+            va.x += xa.x; va.y += xa.y; va.z += xa.z; va.w += xa.w;
+            vb.x += xb.x; vb.y += xb.y; vb.z += xb.z; vb.w += xb.w;
+          }
+        }
         va = panel_gsum(va, g0 >= 0, ad[PRE == 2 ? p : 0][0], g1 >= 0, gs);
         vb = panel_gsum(vb, g0 >= 0, ad[PRE == 2 ? p : 0][1], g1 >= 0, gs);
       }

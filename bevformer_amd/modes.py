@@ -24,7 +24,7 @@ GEMM_KERNELS = (None, "first", "first64", "pipe", "panel", "panel64", "panel128"
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch", "graph_repack", "tsa_seam")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch", "graph_repack", "tsa_seam", "chain_gather_all")
 
     def __init__(self):
         env = os.environ.get
@@ -78,6 +78,9 @@ class Modes:
         # inference: a layer's last kernel also makes the NEXT layer's TemporalSelfAttention offset / weight projection of
         # the rows it produces (csrc/linear_chain.h TP, BEVFormerEncoder.tsa_seam; round 6)
         self.tsa_seam = env("BEVMSDA_TSA_SEAM", "1") == "1"
+        # inference: SpatialCrossAttention's chain kernel walks every camera's row of a slot (idx = q_rows_all) instead of two
+        # rows after a stand-alone fold launch (a no-op on most frames, 5 us per layer in a replayed graph)
+        self.chain_gather_all = env("BEVMSDA_CHAIN_GATHER_ALL", "1") == "1"
         self.overlap_value_proj = env("BEVMSDA_OVERLAP", "1") == "1"  # inference: hoisted SCA value projection on a side stream (its tail rounds and the TSA chain's fill each other: -2 % of the base frame, round 6)
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 

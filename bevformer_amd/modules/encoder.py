@@ -606,8 +606,11 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 return None
             fc1, fc2 = ffn.layers[0][0], ffn.layers[-2]
 
-            def run_s(rows, w, b, res, post_norm, gather, plan=None, drop_p=0.0):
-                if post_norm is not n0:
+            def run_s(rows, w, b, res, post_norm, gather, plan=None, drop_p=0.0, unfolded=False):
+                # (unfolded: gather[0] holds EVERY camera's row of a slot, not the first two after a fold launch — the
+                # inference kernel only)
+                if post_norm is not n0 or (unfolded and (torch.is_grad_enabled() or drop_p > 0
+                                                         or not ops.modes().chain_gather_all)):
                     return None
                 if torch.is_grad_enabled():         # the same kernel as an autograd Function (train_ops.py)
                     if plan is None or plan.row_query32 is None:

@@ -267,11 +267,19 @@ class SpatialCrossAttention(BaseModule):
                 frame_plan.row_query32, spatial_shapes, level_start_index, frame_plan=frame_plan,
                 proj=query_proj if query_pos is None else None)
             if out_rows is not None:
+                # slots seen by more than two cameras (rare; known to the device only): the chain kernel walks every
+                # camera's row of a slot itself (idx = q_rows_all); any other consumer gathers TWO rows per slot, and a
+                # stand-alone launch folds the third.. rows into the first beforehand (a no-op launch on most frames)
+                extra = frame_plan.dynamic and frame_plan.q_rows_all is not None and frame_plan.q_rows_all.shape[1] > 2
+                chain_ok = post_norm is not None and chain is not None and not (self.training and self.dropout.p > 0)
+                if chain_ok and extra:
+                    done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
+                                 (frame_plan.q_rows_all, inv_count), frame_plan, unfolded=True)
+                    if done is not None:
+                        return ops.Chained(done.view(bs, Q, C))
                 if frame_plan.dynamic:
-                    # slots seen by more than two cameras (rare; known to the device only): fold their
-                    # third.. rows into the first so the two-row gather below sums all of them
                     ops.fold_extra_rows(out_rows, frame_plan.q_rows_all, frame_plan.n_extra_dev)
-                if post_norm is not None and chain is not None and not (self.training and self.dropout.p > 0):
+                if chain_ok:
                     # ... and the FFN and its norm behind them: the whole row-local tail of the layer in one kernel
                     done = chain(out_rows, self.output_proj.weight, self.output_proj.bias, inp_residual, post_norm,
                                  (frame_plan.q_rows, inv_count), frame_plan)

@@ -99,7 +99,9 @@ def proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, *, gather=No
     """``norm1(x + fc2(relu(fc1(x))))`` with ``x = norm0(linear(A, weight, bias) + res)`` in ONE kernel
     (``bevmsda_proj_ffn_chain_f32``, csrc/linear_chain.h): the attention's output projection, "+ identity", the
     layer's norm, the FFN, "+ identity" and the next norm — every op local to a BEV row.  A = ``rows`` or, with
-    ``gather = (idx (M, 2) int32, scale (M,))``, SpatialCrossAttention's camera mean over the rows.  ``fc1`` / ``fc2``:
+    ``gather = (idx (M, 2) int32, scale (M,))``, SpatialCrossAttention's camera mean over the rows (idx (M, J > 2): every
+    camera's row of a slot, -1 = absent, present ones first — the rare slots with a third.. row are summed in the kernel in the
+    order the stand-alone ``fold_extra_rows`` launch would: bit-equal, one launch less).  ``fc1`` / ``fc2``:
     the FFN's ``nn.Linear`` layers (256 -> 512 -> 256), ``norm0`` / ``norm1``: ``nn.LayerNorm(256)``.  Returns
     ``None`` when not covered (the caller runs the steps one by one).
 
@@ -136,7 +138,7 @@ def _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag
     idx = scale = None
     if gather is not None:
         idx, scale = gather
-        if idx.dim() != 2 or idx.shape[1] != 2 or idx.dtype != torch.int32:
+        if idx.dim() != 2 or not 2 <= idx.shape[1] <= 64 or idx.dtype != torch.int32:
             return None
         idx = idx.contiguous()
         scale = scale.reshape(-1).float().contiguous()
@@ -164,6 +166,8 @@ def _proj_ffn_chain(rows, weight, bias, res, norm0, fc1, fc2, norm1, gather, tag
     desc = _lib.ChainDesc(M=M, ld_rows=ldx, ld_res=ldres, ld_y=256, C=256, F=512, precision=0 if m.gemm == "split" else 1,
                           eps0=float(norm0.eps), eps1=float(norm1.eps))
     desc.reserved[1] = m.chain_shape
+    if idx is not None and idx.shape[1] > 2:
+        desc.reserved[2] = idx.shape[1]     # every camera's row of a slot: columns 2.. are added to the first row's (no fold launch)
     lib = _lib.load()
     cb = _GEMM_TIMER["cb"]
     flops = 2.0 * M * (256 * 256 + 2 * 256 * 512)

@@ -163,6 +163,33 @@ def test_encoder_on_device_plans_with_three_cameras_per_query(name, temporal):
     torch.testing.assert_close(got, want, rtol=5e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("name,temporal", [("micro4", True), ("tiny", True), ("micro", False)])
+def test_chain_kernel_walking_every_camera_row_equals_the_fold_launch(name, temporal):
+    """``modes.chain_gather_all`` (default): SpatialCrossAttention's chain kernel takes idx = q_rows_all and adds the third..
+    rows of a slot itself, in the order the stand-alone fold launch adds them — bit-equal to fold + two-row gather, on a rig
+    with three cameras per visible query and on the stock rig (no such slot), with and without the next layer's seam."""
+    from bevformer_amd import ops
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=1, temporal=temporal)
+    for metas in (_overlapping_metas(name), S.make_img_metas(name)):
+        kw["img_metas"] = metas
+        kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        outs, folds = [], []
+        orig = ops.fold_extra_rows
+        try:
+            for gather_all in (True, False):
+                calls = []
+                ops.fold_extra_rows = lambda *a, _c=calls, **k: (_c.append(1), orig(*a, **k))[1]
+                with torch.no_grad(), ops.using(chain_gather_all=gather_all):
+                    outs.append(enc(q.to(DEV), f.to(DEV), f.to(DEV), **kwd).clone())
+                folds.append(len(calls))
+        finally:
+            ops.fold_extra_rows = orig
+        assert folds[0] == 0 and folds[1] == len(enc.layers), folds       # (the launch is gone / one per layer)
+        assert torch.equal(outs[0], outs[1])
+        assert torch.isfinite(outs[0]).all()
+
+
 @pytest.mark.parametrize("name,bs", [("micro4", 2), ("tiny", 1)])
 def test_encoder_device_plans_equal_host_plans(name, bs):
     """Same frames through the torch-op plan builder (host syncs) and the device planner: the row
