@@ -411,7 +411,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
         plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
                                bev_query.dtype, train_fast=train_fast)
         ref_2d = plan.ref_2d
-        shift_ref_2d = ref_2d + shift[:, None, None, :]
 
         bev_query = bev_query.permute(1, 0, 2)
         # (through get_bev_features the positional encoding arrives as a transposed view of (bs, C, H*W): made contiguous
@@ -423,7 +422,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             prev_bev = prev_bev.permute(1, 0, 2)
             history = prev_bev
             prev_bev = None                 # stack([history, bev_query]): built below, only if something reads it
-            hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
+            hybird_ref_2d = geometry.hybrid_ref_2d(ref_2d, shift)      # (= stack([ref_2d + shift, ref_2d], 1), one launch)
         else:
             hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
 

@@ -45,6 +45,31 @@ def get_reference_points(H, W, Z=8, num_points_in_pillar=4, dim="3d", bs=1, devi
     raise ValueError(dim)
 
 
+_HYBRID_MASK = {}
+
+
+def hybrid_ref_2d(ref_2d, shift):
+    """``stack([ref_2d + shift[:, None, None, :], ref_2d], 1).reshape(bs * 2, Q, 1, 2)`` (encoder.py:226-237: the history
+    entry of TemporalSelfAttention's BEV queue looks at the ego-motion-shifted anchors, the current entry at the plain ones)
+    from ONE elementwise launch instead of three (add, stack, and the per-row copy ``temporal_self_attention._rows_layout``
+    makes of it): the anchors are written in the kernels' row layout ``(bs * Q, 2, 1, 2)`` as ``ref + mask[k] * shift``
+    (mask = (1, 0): exact — one rounding for k = 0, ``ref + 0`` for k = 1), and the reference's layout is handed out as a view
+    of that memory, so ``_rows_layout`` finds its result already contiguous.  Single-level BEV anchors only (``(bs, Q, 1, 2)``);
+    anything else takes the reference's statement."""
+    import os
+    import torch
+    if os.environ.get("BEVMSDA_HYBRID_REF", "1") == "0" or ref_2d.dim() != 4 or ref_2d.shape[2] != 1 or ref_2d.shape[3] != 2 or not ref_2d.is_cuda or shift.shape != (ref_2d.shape[0], 2) \
+            or shift.dtype != ref_2d.dtype or shift.device != ref_2d.device or not torch.is_floating_point(ref_2d):
+        return torch.stack([ref_2d + shift[:, None, None, :], ref_2d], 1).reshape(ref_2d.shape[0] * 2, ref_2d.shape[1], 1, 2)
+    bs, Q = ref_2d.shape[0], ref_2d.shape[1]
+    key = (ref_2d.device, ref_2d.dtype)
+    mask = _HYBRID_MASK.get(key)
+    if mask is None:
+        mask = _HYBRID_MASK[key] = torch.tensor([1.0, 0.0], device=ref_2d.device, dtype=ref_2d.dtype).view(1, 1, 2, 1, 1)
+    rows = torch.addcmul(ref_2d.reshape(bs, Q, 1, 1, 2).expand(bs, Q, 2, 1, 2), mask, shift.view(bs, 1, 1, 1, 2))
+    return rows.permute(0, 2, 1, 3, 4).reshape(bs * 2, Q, 1, 2)     # (bs = 1: a view; bs > 1: the reference's layout, copied)
+
+
 def point_sampling(reference_points, pc_range, img_metas):
     """Project pillar anchors into every camera (encoder.py:95-144), fp32.
 

@@ -352,3 +352,22 @@ def test_tiled_rank_skips_the_value_projection_of_cameras_it_cannot_see(name, wo
         ops._SEGMENT_POISON["on"] = False
     assert len(seen) == world and ops._SEGMENT_POISON["launches"] == world
     assert sum(seen) > 0, f"no rank of {world} could skip a camera on workload {name}: {seen}"
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_hybrid_anchors_from_one_launch_equal_the_reference_statement(bs):
+    """``geometry.hybrid_ref_2d``: stack([ref_2d + shift, ref_2d], 1) (encoder.py:226-237) written by one elementwise launch in
+    the sampling kernels' row layout — bit-equal values in the reference's layout, and (bs = 1) TemporalSelfAttention's row
+    layout of it is the same memory, not a copy."""
+    from bevformer_amd.modules.temporal_self_attention import _rows_layout
+    Q = 50 * 50
+    g = torch.Generator().manual_seed(5)
+    ref = torch.rand(bs, Q, 1, 2, generator=g).to(DEV)
+    shift = (torch.randn(bs, 2, generator=g) * 0.05).to(DEV)
+    want = torch.stack([ref + shift[:, None, None, :], ref], 1).reshape(bs * 2, Q, 1, 2)
+    got = G.hybrid_ref_2d(ref, shift)
+    assert got.shape == want.shape and torch.equal(got, want)
+    rows = _rows_layout(got, bs, 2, Q, 1)
+    assert rows.is_contiguous() and torch.equal(rows, _rows_layout(want, bs, 2, Q, 1))
+    if bs == 1:
+        assert rows.data_ptr() == got.data_ptr()
