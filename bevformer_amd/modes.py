@@ -24,7 +24,7 @@ GEMM_KERNELS = (None, "first", "first64", "pipe", "panel", "panel64", "panel128"
 
 class Modes:
     __slots__ = ("value_storage", "fused", "fused_train", "gemm", "gemm_variant", "gemm_pack", "train_forward_mfma",
-                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch", "graph_repack", "tsa_seam", "chain_gather_all")
+                 "gemm_kernel", "ln_fuse", "wgrad", "bf16_lanes8", "fused_wpe", "fused_lds_pad_kb", "chain_shape", "grad_thread", "train_chain", "wgrad_workgroups", "wgrad_variant", "stack_free", "weight_views", "flatten_params", "fused_save", "chain_backward", "grad_arena", "overlap_value_proj", "use_grad_arena", "fused_spec", "fused_capacity_launch", "graph_repack", "tsa_seam", "chain_gather_all", "plan_on_side")
 
     def __init__(self):
         env = os.environ.get
@@ -81,6 +81,9 @@ class Modes:
         # inference: SpatialCrossAttention's chain kernel walks every camera's row of a slot (idx = q_rows_all) instead of two
         # rows after a stand-alone fold launch (a no-op on most frames, 5 us per layer in a replayed graph)
         self.chain_gather_all = env("BEVMSDA_CHAIN_GATHER_ALL", "1") == "1"
+        # inference with overlap_value_proj: the frame-plan kernels are issued on the side stream too, ahead of the camera-value
+        # projection (nothing on the main stream reads the plan before the first SpatialCrossAttention joins that stream)
+        self.plan_on_side = env("BEVMSDA_PLAN_SIDE", "1") == "1"
         self.overlap_value_proj = env("BEVMSDA_OVERLAP", "1") == "1"  # inference: hoisted SCA value projection on a side stream (its tail rounds and the TSA chain's fill each other: -2 % of the base frame, round 6)
         assert self.gemm in GEMM_MODES, f"BEVMSDA_GEMM must be one of {GEMM_MODES}"
 

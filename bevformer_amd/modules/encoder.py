@@ -408,8 +408,25 @@ class BEVFormerEncoder(TransformerLayerSequence):
         bs = bev_query.size(1)
         train_fast = bev_query.is_cuda and value.is_cuda and self._train_fast_path(
             value.device, (bev_query, value, bev_pos, prev_bev))
-        plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                               bev_query.dtype, train_fast=train_fast)
+        overlap = ops.modes().overlap_value_proj if self.overlap_value_proj is None else self.overlap_value_proj
+        plan_ready = None
+        if overlap and ops.modes().plan_on_side and not torch.is_grad_enabled() and bev_query.is_cuda and value.is_cuda \
+                and self.device_plans and not ops.gemm_timer_active():
+            # the plan kernels go first on the stream that will carry the hoisted camera-value projection: the main stream
+            # starts the BEV-value projection at once and meets the plan where it meets the projected camera values — at
+            # the first SpatialCrossAttention (``_sca_ready``, recorded behind both); the side stream waits for the main
+            # one first, i.e. for the previous frame's readers of the planner's buffers
+            cur = torch.cuda.current_stream(value.device)
+            if self._side_stream is None or self._side_stream.device != value.device:
+                self._side_stream = torch.cuda.Stream(value.device)
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                       bev_query.dtype, train_fast=train_fast)
+                plan_ready = self._side_stream.record_event()
+        else:
+            plan = self.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                   bev_query.dtype, train_fast=train_fast)
         ref_2d = plan.ref_2d
 
         bev_query = bev_query.permute(1, 0, 2)
@@ -434,6 +451,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         if history is not None and not stack_free:
             prev_bev = torch.stack([history, bev_query], 1).reshape(bs * 2, len_bev, -1)
         sca_vals, tsa_vals = self.hoisted_value_projections(value, (history, bev_query) if stack_free else prev_bev)
+        if plan_ready is not None and getattr(self, "_sca_ready", None) is None:
+            torch.cuda.current_stream(value.device).wait_event(plan_ready)      # (no side-stream projection to meet: join now)
         if stack_free:
             prev_bev = history.expand(2, len_bev, history.shape[-1]) if tsa_vals is not None \
                 else torch.stack([history, bev_query], 1).reshape(bs * 2, len_bev, -1)

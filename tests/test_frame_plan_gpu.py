@@ -371,3 +371,36 @@ def test_hybrid_anchors_from_one_launch_equal_the_reference_statement(bs):
     assert rows.is_contiguous() and torch.equal(rows, _rows_layout(want, bs, 2, Q, 1))
     if bs == 1:
         assert rows.data_ptr() == got.data_ptr()
+
+
+@pytest.mark.parametrize("name,temporal", [("small4", True), ("micro4", False)])
+def test_plan_kernels_on_the_side_stream_equal_the_main_stream_schedule(name, temporal):
+    """``modes.plan_on_side`` (default with ``overlap_value_proj``): the frame-plan kernels run on the side stream ahead of the
+    hoisted camera-value projection and meet the main stream at the first SpatialCrossAttention.  Eight frames back to back,
+    NEW camera matrices in the same device tensor before every frame and no synchronisation in between — a plan that overwrote
+    its buffers under the previous frame's readers, or a reader that ran ahead of its plan, would show — against the
+    one-stream schedule, frame by frame, bit for bit."""
+    from bevformer_amd import ops
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=4, temporal=temporal)
+    rigs = [torch.tensor(np.asarray(_perturbed_metas(name, 1, seed=s)[0]["lidar2img"]), dtype=torch.float32, device=DEV)
+            for s in range(8)]
+    l2i = torch.zeros_like(rigs[0])
+    kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    kwd["img_metas"] = [dict(lidar2img=l2i, img_shape=S.make_img_metas(name)[0]["img_shape"])]
+    qd, fd = q.to(DEV), f.to(DEV)
+    outs = {}
+    for side in (False, True):
+        with torch.no_grad(), ops.using(overlap_value_proj=True, plan_on_side=side):
+            l2i.copy_(rigs[0])
+            enc(qd, fd, fd, **kwd)                  # (planner, weight images)
+            torch.cuda.synchronize()
+            frames = []
+            for r in rigs:
+                l2i.copy_(r)
+                frames.append(enc(qd, fd, fd, **kwd).clone())
+            torch.cuda.synchronize()
+        outs[side] = frames
+    for i in range(len(rigs)):
+        assert torch.equal(outs[True][i], outs[False][i]), i
+    assert not torch.equal(outs[True][0], outs[True][1])        # (the rigs do differ)
