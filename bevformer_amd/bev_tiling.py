@@ -215,6 +215,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                   **kwargs):
     """Same contract as ``BEVFormerEncoder.forward``; every rank returns the
     full (bs, Q, C) grid."""
+    from . import ops
+    from .modules import geometry
     tiling = encoder.bev_tiling
     group, world, rank = tiling.group, tiling.world, tiling.rank
     bs = bev_query.size(1)
@@ -224,10 +226,24 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
                            "call it under torch.no_grad() or disable_bev_tiling() for training")
     sectors = tiling.layout == "sectors"
     blocks, unit, (q0, q1), cell_perm, rows_idx, inverse = rank_tile(encoder, bev_h, bev_w, bev_query.device)
+    plan_ready = None
     if encoder.device_plans and bev_query.is_cuda:
         # device-side plan of my tile: rows only for queries [q0, q1), tile-local slot numbering
-        tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
-                                  bev_query.dtype, tile=(q0, q1), cell_perm=cell_perm)
+        overlap = ops.modes().overlap_value_proj if encoder.overlap_value_proj is None else encoder.overlap_value_proj
+        if overlap and ops.modes().plan_on_side and value.is_cuda and not ops.gemm_timer_active():
+            # (as BEVFormerEncoder._forward: the plan kernels ahead of the camera-value projection on ITS stream — that
+            # projection reads the plan's camera segments — and the main stream meets both at the first SpatialCrossAttention)
+            cur = torch.cuda.current_stream(value.device)
+            if encoder._side_stream is None or encoder._side_stream.device != value.device:
+                encoder._side_stream = torch.cuda.Stream(value.device)
+            encoder._side_stream.wait_stream(cur)
+            with torch.cuda.stream(encoder._side_stream):
+                tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                          bev_query.dtype, tile=(q0, q1), cell_perm=cell_perm)
+                plan_ready = encoder._side_stream.record_event()
+        else:
+            tile = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
+                                      bev_query.dtype, tile=(q0, q1), cell_perm=cell_perm)
         full_ref_2d = tile.ref_2d_full
     else:
         plan = encoder.frame_plan(bev_h, bev_w, bs, kwargs["img_metas"], bev_query.device,
@@ -241,7 +257,6 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
             tile = cache[(q0, q1)] = slice_plan(plan, q0, q1)
 
     ref_2d = full_ref_2d
-    shift_ref_2d = ref_2d + shift[:, None, None, :]
     full_query = bev_query.permute(1, 0, 2)
     take = (lambda t: t.index_select(1, rows_idx)) if sectors else (lambda t: t[:, q0:q1])
     pos_local = take(bev_pos.permute(1, 0, 2)).contiguous()     # (once per frame, not once per layer)
@@ -252,11 +267,11 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
         # (inference, bs = 1: the value projection reads history and queries where they lie — encoder.py, ``_stack_free``)
         stack_free = encoder._stack_free(history, full_query, bs)
         tsa_value = (history, full_query) if stack_free else torch.stack([history, full_query], 1).reshape(bs * 2, Q, -1)
-        hybrid = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
+        # (my queries' anchors only: stack([ref + shift, ref], 1)[:, q0:q1], one launch — geometry.hybrid_ref_2d)
+        hybrid = geometry.hybrid_ref_2d(ref_2d[:, q0:q1], shift)
     else:
         tsa_value = None
-        hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)
-    hybrid = hybrid[:, q0:q1].contiguous()
+        hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, Q, 1, 2)[:, q0:q1].contiguous()
 
     x = take(full_query).contiguous()
     history_local = take(prev_bev.permute(1, 0, 2)).contiguous() if (prev_bev is not None and bs == 1) else None
@@ -265,6 +280,8 @@ def tiled_forward(encoder, bev_query, key, value, *args, bev_h=None, bev_w=None,
     # (the tile's plan tells the camera-value projection which cameras this rank's queries can see at all)
     sca_vals, tsa_vals = encoder.hoisted_value_projections(value, tsa_value, plan=tile if world > 1 else None,
                                                             spatial_shapes=spatial_shapes)
+    if plan_ready is not None and getattr(encoder, "_sca_ready", None) is None:
+        torch.cuda.current_stream(value.device).wait_event(plan_ready)      # (no side-stream projection to meet: join now)
     if stack_free:
         tsa_value = history.expand(2, Q, history.shape[-1]) if tsa_vals is not None \
             else torch.stack([history, full_query], 1).reshape(bs * 2, Q, -1)
