@@ -47,9 +47,12 @@ class Modes:
         # resident, software-pipelined grid (round 6: 3 % faster, twice the L2 misses — opt-in; profiles/r6x), 5 = TSA's shape with
         # each 16 x 8 tile's tap lines staged in LDS (round 6: bit-equal, level with the default — opt-in; DESIGN K1-LDS)
         self.fused_spec = int(env("BEVMSDA_FUSED_SPEC", "0"))
-        # sampling launches over a device-side row count: 1 = ONE launch sized by the row CAPACITY (surplus workgroups return on
-        # their first instruction), 0 = a launch sized by the host's hint + a small strided tail launch for rows beyond it
-        self.fused_capacity_launch = env("BEVMSDA_FUSED_CAPACITY", "0") == "1"
+        # sampling launches over a device-side row count: True = ONE launch sized by the row CAPACITY (surplus workgroups return
+        # on their first instruction), False = a launch sized by the host's hint + a small strided tail launch for rows beyond
+        # it, "auto" (default) = the capacity launch when it has at most FUSED_CAPACITY_AUTO_ROWS surplus rows (tiles of the BEV
+        # grid, small grids: the surplus workgroups cost less than the tail launch's 5 us; at the base grid's 190,000 surplus
+        # rows the two are level — profiles/r6z/r6zz_capacity_launch_ab.txt)
+        self.fused_capacity_launch = {"0": False, "1": True}.get(env("BEVMSDA_FUSED_CAPACITY", "auto"), "auto")
         # A/B knob: re-pack the weight images of trainable parameters inside EVERY captured graph (round 4's behaviour; the
         # default re-packs only in graphs captured with grad mode on: ops.images._cache_ok)
         self.graph_repack = env("BEVMSDA_GRAPH_REPACK", "0") == "1"

@@ -213,7 +213,11 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, n_off, ref, row_b
             if nrows is not None:
                 _req(nrows.dtype == torch.int32 and nrows.is_cuda and nrows.numel() >= 1,
                      "bevmsda: nrows must be an int32 device tensor")
-                desc.reserved[3] = R if _m().fused_capacity_launch else int(max(0, min(launch_rows, R)))
+                hint = int(max(0, min(launch_rows, R)))
+                cap_launch = _m().fused_capacity_launch
+                if cap_launch == "auto":
+                    cap_launch = 0 < hint and R - hint <= FUSED_CAPACITY_AUTO_ROWS
+                desc.reserved[3] = R if cap_launch else hint
                 extra = ()
                 if save is not None:
                     sl, sa = save
@@ -466,6 +470,9 @@ def msda_fused_autograd(value, spatial_shapes, level_start_index, proj, n_off, r
              "bevmsda: q_rows must be a contiguous int32 (slots, J) device tensor")
     return _FusedSampleFunction.apply(value, proj, spatial_shapes, level_start_index, ref, row_batch, row_src, n_off,
                                       meta, tag, q_rows, nrows, launch_rows, value_sink, n_extra)
+
+
+FUSED_CAPACITY_AUTO_ROWS = 65536       # (modes.fused_capacity_launch = "auto": surplus rows up to which ONE capacity-sized launch is used)
 
 
 def fold_extra_rows(rows, q_rows_all, n_extra):

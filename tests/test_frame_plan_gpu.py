@@ -404,3 +404,23 @@ def test_plan_kernels_on_the_side_stream_equal_the_main_stream_schedule(name, te
     for i in range(len(rigs)):
         assert torch.equal(outs[True][i], outs[False][i]), i
     assert not torch.equal(outs[True][0], outs[True][1])        # (the rigs do differ)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small4"])
+def test_capacity_sized_sampling_launch_equals_hint_plus_tail(name):
+    """``modes.fused_capacity_launch``: SpatialCrossAttention's sampling over the device-side row count as ONE launch sized by
+    the row capacity (the "auto" default where the surplus is small: tiny; not at small4), as a hint-sized launch + a strided
+    tail, and by the default policy — the same rows, bit for bit."""
+    from bevformer_amd import ops
+    from bevformer_amd.ops import sampling
+    enc, _ = build_pair(name, device=DEV)
+    q, f, kw = S.make_inputs(name, seed=6, temporal=True)
+    kwd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    outs = []
+    for mode in (False, True, "auto"):
+        with torch.no_grad(), ops.using(fused_capacity_launch=mode):
+            outs.append(enc(q.to(DEV), f.to(DEV), f.to(DEV), **kwd).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    (planner,) = enc._planners.values()
+    surplus = planner.cap - planner.launch_rows
+    assert (surplus <= sampling.FUSED_CAPACITY_AUTO_ROWS) == (name == "tiny"), surplus
