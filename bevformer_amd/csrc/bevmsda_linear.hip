@@ -590,11 +590,11 @@ static int ffn_chain_launch(const float *rows, const int32_t *idx, const float *
   // (round 6, last day — at FRAME level, in a replayed graph, the inference launches are fastest as ONE launch of 32-row panels at
   // every row count: the mixed shape's isolated 3 us per launch do not pay for its second launch and the round of one workgroup
   // per CU — base frame 4.00 against 4.03 ms, bf16 2.78 against 2.81, first frame 3.94 against 4.03, small4 1.29 against 1.32,
-  // queue 17.02 against 17.27; profiles/r6z/r6zz_chain_shape_frame_ab.txt.  The training launches (save) keep the policy above:
-  // the step is indifferent, profiles/r6/r6v_chain_shape_train_ab.txt)
+  // queue 17.02 against 17.27; the training step too, by less: small4 bf16 4.96-4.97 against 4.98-5.00 ms, base 18.65-18.73 against
+  // 18.70-18.76; profiles/r6z/r6zz_chain_shape_frame_ab.txt)
   // (between 8,192 and 16,384 rows — a tile of four ranks — one partial round of 64-row panels stays ahead: rank 1 of 4 1.61
   // against 1.66 ms)
-  if (shape == 0) shape = (tp || d->M <= kChainSmallRows) ? 2 : (d->M >= 256LL * 64 ? (save ? 3 : 2) : 1);
+  if (shape == 0) shape = (tp || d->M <= kChainSmallRows) ? 2 : (d->M >= 256LL * 64 ? 2 : 1);
   if (shape == 3) {
     // mixed (round 4): whole rounds of the 64-row shape (one workgroup per CU: 256 x 64 rows per round)
     // and the remainder — a partial round that would leave most CUs idle behind a few 64-row workgroups — on the 32-row
@@ -802,7 +802,7 @@ static int ln_proj_chain_launch(const float *rows, const int32_t *idx, const flo
   int shape = d->reserved[1];
   if (shape < 0 || shape > 3) return BEVMSDA_ERR_BAD_OPTION;
   // (isolated: mixed 100.4-101.5 vs 103.8-105.7 us at 40,000 rows; in the frame one launch of 32-row panels wins — see ffn_chain_launch)
-  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : (d->M >= 256LL * 64 ? (save ? 3 : 2) : 1);
+  if (shape == 0) shape = d->M <= kChainSmallRows ? 2 : (d->M >= 256LL * 64 ? 2 : 1);
   if (d->F % 64 != 0) shape = 1;               // the 32-row shape walks 64-column tiles
   if (shape == 3) {                            // mixed: whole rounds on the 64-row shape, the tail on the 32-row shape
     const long long round64 = 256LL * 64;

@@ -586,8 +586,7 @@ typedef struct bevmsda_chain_desc {
   int32_t precision;             /* as bevmsda_linear_desc */
   float eps0, eps1;
   int32_t reserved[5];           /* [0]: bevmsda_proj_ln_proj_chain_f32: row stride of proj_out in floats; [1]: workgroup
-                                    shape, 0 = default (by row count: 2, or 1 between 8,192 and 16,384 rows; the launches
-                                    that save for a backward: 3 from 16,384 rows on), 1 = 64-row panels (one workgroup per
+                                    shape, 0 = default (by row count: 2, or 1 between 8,192 and 16,384 rows), 1 = 64-row panels (one workgroup per
                                     CU), 2 = 32-row panels (two), 3 = mixed: whole rounds of 256 x 64 rows on shape 1, the
                                     remaining rows on shape 2 (a second launch); [2]: bevmsda_proj_ffn_chain_f32 / _tail_f32: columns J of idx (0 = 2;
                                     2 < J <= 64: idx is (M, J), present rows first, and rows idx[m, 2..] >= 0 are added to
