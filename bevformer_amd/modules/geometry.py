@@ -58,7 +58,7 @@ def hybrid_ref_2d(ref_2d, shift):
     anything else takes the reference's statement."""
     import os
     import torch
-    if os.environ.get("BEVMSDA_HYBRID_REF", "1") == "0" or ref_2d.dim() != 4 or ref_2d.shape[2] != 1 or ref_2d.shape[3] != 2 or not ref_2d.is_cuda or shift.shape != (ref_2d.shape[0], 2) \
+    if os.environ.get("BEVMSDA_HYBRID_REF", "1") == "0" or not torch.is_tensor(shift) or ref_2d.dim() != 4 or ref_2d.shape[2] != 1 or ref_2d.shape[3] != 2 or not ref_2d.is_cuda or shift.shape != (ref_2d.shape[0], 2) \
             or shift.dtype != ref_2d.dtype or shift.device != ref_2d.device or not torch.is_floating_point(ref_2d):
         return torch.stack([ref_2d + shift[:, None, None, :], ref_2d], 1).reshape(ref_2d.shape[0] * 2, ref_2d.shape[1], 1, 2)
     bs, Q = ref_2d.shape[0], ref_2d.shape[1]
