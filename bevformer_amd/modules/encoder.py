@@ -441,7 +441,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             prev_bev = None                 # stack([history, bev_query]): built below, only if something reads it
             hybird_ref_2d = geometry.hybrid_ref_2d(ref_2d, shift)      # (= stack([ref_2d + shift, ref_2d], 1), one launch)
         else:
-            hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, 1, 2)
+            hybird_ref_2d = geometry.hybrid_ref_2d(ref_2d, None)       # (= stack([ref_2d, ref_2d], 1))
 
         # TSA's value is stack([history, bev_query]).  Inference, bs = 1: the grouped value projection reads the two tensors
         # where they lie and every layer's TSA gets its projected value and the history rows — nothing reads the stacked

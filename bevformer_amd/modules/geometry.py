@@ -55,9 +55,16 @@ def hybrid_ref_2d(ref_2d, shift):
     makes of it): the anchors are written in the kernels' row layout ``(bs * Q, 2, 1, 2)`` as ``ref + mask[k] * shift``
     (mask = (1, 0): exact — one rounding for k = 0, ``ref + 0`` for k = 1), and the reference's layout is handed out as a view
     of that memory, so ``_rows_layout`` finds its result already contiguous.  Single-level BEV anchors only (``(bs, Q, 1, 2)``);
-    anything else takes the reference's statement."""
+    anything else takes the reference's statement.  ``shift = None``: ``stack([ref_2d, ref_2d], 1)`` the same way."""
     import os
     import torch
+    if shift is None:
+        # a scene's first frame: both queue entries look at the plain anchors (encoder.py:236-237) — one copy in the row layout
+        if os.environ.get("BEVMSDA_HYBRID_REF", "1") == "0" or ref_2d.dim() != 4 or ref_2d.shape[2] != 1 or not ref_2d.is_cuda:
+            return torch.stack([ref_2d, ref_2d], 1).reshape(ref_2d.shape[0] * 2, ref_2d.shape[1], 1, ref_2d.shape[3])
+        bs, Q = ref_2d.shape[0], ref_2d.shape[1]
+        rows = ref_2d.reshape(bs, Q, 1, 1, 2).expand(bs, Q, 2, 1, 2).contiguous()
+        return rows.permute(0, 2, 1, 3, 4).reshape(bs * 2, Q, 1, 2)
     if os.environ.get("BEVMSDA_HYBRID_REF", "1") == "0" or not torch.is_tensor(shift) or ref_2d.dim() != 4 or ref_2d.shape[2] != 1 or ref_2d.shape[3] != 2 or not ref_2d.is_cuda or shift.shape != (ref_2d.shape[0], 2) \
             or shift.dtype != ref_2d.dtype or shift.device != ref_2d.device or not torch.is_floating_point(ref_2d):
         return torch.stack([ref_2d + shift[:, None, None, :], ref_2d], 1).reshape(ref_2d.shape[0] * 2, ref_2d.shape[1], 1, 2)

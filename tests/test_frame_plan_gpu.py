@@ -371,6 +371,10 @@ def test_hybrid_anchors_from_one_launch_equal_the_reference_statement(bs):
     assert rows.is_contiguous() and torch.equal(rows, _rows_layout(want, bs, 2, Q, 1))
     if bs == 1:
         assert rows.data_ptr() == got.data_ptr()
+    first_want = torch.stack([ref, ref], 1).reshape(bs * 2, Q, 1, 2)           # (a scene's first frame)
+    first = G.hybrid_ref_2d(ref, None)
+    assert first.shape == first_want.shape and torch.equal(first, first_want)
+    assert torch.equal(_rows_layout(first, bs, 2, Q, 1), _rows_layout(first_want, bs, 2, Q, 1))
 
 
 @pytest.mark.parametrize("name,temporal", [("small4", True), ("micro4", False)])
